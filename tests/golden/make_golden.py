@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only NAME]
+
+The reference (/root/reference, read-only) cannot travel to the GPU box, and its own tests hold no
+numeric golden values, so this script imports it here, feeds it weights and
+inputs from the framework-independent seeded generator (oracle/seeded.py) and stores the reference's
+outputs -- data only, no reference source -- as small fixtures.  The oracle (oracle/numpy_forward.py),
+and through it the HIP path, are pinned against these files.
+
+Fixture families
+  fwd_*      eval forward: stage taps (hooked run) + final (separated, masks) (un-hooked run, i.e. with
+             torch's fused encoder fast path exactly as demo.py:42-49 executes it)
+  trained_*  same, with weights after a few Adam steps of the reference's own recipe (demo.py:83-113)
+             incl. non-trivial BatchNorm running stats; weights are committed
+  dataset_*  SyntheticAVDataset items (dataset.py:70-151)
+  losses     si_snr / SeparationLoss known answers (losses.py:14-73)
+"""
+import argparse
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import seeded  # noqa: E402
+import av_separation as ref  # noqa: E402  (the reference package)
+from av_separation.losses import SeparationLoss, si_snr  # noqa: E402
+
+assert ref.__file__.startswith("/root/reference/"), ref.__file__
+
+# name -> model/input configuration.  B is the golden batch, `full` keeps whole tensors, otherwise
+# strided slices + float64 checksums are stored (the big BASELINE configs).
+CONFIGS = {
+    # the reference's own test-suite shapes (tests/test_model.py:29-36), 1+1 layers
+    "tiny": dict(F=65, T=32, d=64, h=4, Le=1, Lf=1, S=2, N=10, H=16, W=16, B=2, full=True, seed=11),
+    # odd everything: S=3, dh=32, odd frame size, T not a multiple of anything, 2+2 layers
+    "odd": dict(F=33, T=19, d=64, h=2, Le=2, Lf=2, S=3, N=7, H=15, W=13, B=3, full=True, seed=12),
+    # T < N (downsampling interpolate; legal but untested in the reference), T=1 edge
+    "down": dict(F=17, T=5, d=32, h=2, Le=1, Lf=1, S=2, N=12, H=8, W=8, B=2, full=True, seed=13),
+    "t1": dict(F=9, T=1, d=32, h=4, Le=1, Lf=1, S=2, N=1, H=4, W=4, B=1, full=True, seed=14),
+    # BASELINE config 1/2 model (d=256,h=4,2+2; 1 s @ 8 kHz) on SyntheticAVDataset items 0,1
+    "cfg1": dict(F=257, T=63, d=256, h=4, Le=2, Lf=2, S=2, N=50, H=32, W=32, B=2, full=False, seed=21,
+                 dataset=dict(sample_rate=8000, duration=1.0, num_frames=25, frame_h=32, frame_w=32,
+                              speaker_freqs=(220.0, 440.0))),
+    # BASELINE config 3 (d=512,h=8,6+4, 2 s @ 16 kHz), B=1
+    "cfg3": dict(F=257, T=251, d=512, h=8, Le=6, Lf=4, S=2, N=50, H=32, W=32, B=1, full=False, seed=23),
+    # BASELINE config 4 forward (3 speakers 220/440/660, N=75)
+    "cfg4": dict(F=257, T=251, d=512, h=8, Le=6, Lf=4, S=3, N=75, H=32, W=32, B=1, full=False, seed=24),
+    # BASELINE config 5 (4 s @ 16 kHz, 48x48 lips, 8 fusion layers)
+    "cfg5": dict(F=257, T=501, d=512, h=8, Le=6, Lf=8, S=2, N=50, H=48, W=48, B=1, full=False, seed=25),
+}
+
+
+def build_reference(c, state_np=None):
+    torch.manual_seed(0)
+    m = ref.AVSeparationTransformer(freq_bins=c["F"], d_model=c["d"], nhead=c["h"],
+                                    num_encoder_layers=c["Le"], num_fusion_layers=c["Lf"],
+                                    num_speakers=c["S"], dropout=0.0)
+    if state_np is not None:
+        sd = m.state_dict()
+        for k, v in state_np.items():
+            assert k in sd and tuple(sd[k].shape) == tuple(v.shape), (k, v.shape)
+            sd[k] = torch.from_numpy(np.ascontiguousarray(v))
+        m.load_state_dict(sd)
+    return m.eval()
+
+
+def check_shapes(c, m):
+    want = seeded.model_shapes(c["F"], c["d"], c["h"], c["Le"], c["Lf"], c["S"])
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert want == got, set(want.items()) ^ set(got.items())
+
+
+def hooked_taps(m, mixed, lips):
+    taps, hs = {}, []
+
+    def grab(name, fn=lambda o: o):
+        def hook(_m, _i, o):
+            taps[name] = fn(o).detach().numpy().copy()
+        return hook
+
+    ae, ve, fu, de = m.audio_encoder, m.visual_encoder, m.fusion, m.decoder
+    hs.append(ae.input_proj[1].register_forward_hook(grab("a_conv1", lambda o: o.permute(0, 2, 1))))
+    hs.append(ae.input_proj.register_forward_hook(grab("a_conv2", lambda o: o.permute(0, 2, 1))))
+    hs.append(ae.pos_enc.register_forward_hook(grab("a_pe")))
+    for i, l in enumerate(ae.transformer.layers):
+        hs.append(l.register_forward_hook(grab(f"a_enc{i}")))
+    for j, idx in enumerate((2, 5, 8)):
+        hs.append(ve.conv[idx].register_forward_hook(grab(f"v_conv{j}")))
+    hs.append(ve.conv.register_forward_hook(grab("v_pool", lambda o: o.flatten(1))))
+    hs.append(ve.frame_proj.register_forward_hook(grab("v_proj")))
+    for i, l in enumerate(ve.transformer.layers):
+        hs.append(l.register_forward_hook(grab(f"v_enc{i}")))
+    hs.append(ve.register_forward_hook(grab("v_interp")))
+    for i, l in enumerate(fu.layers):
+        hs.append(l.register_forward_hook(grab(f"f_layer{i}")))
+    hs.append(fu.norm.register_forward_hook(grab("f_norm")))
+    hs.append(de.decoder.register_forward_hook(grab("d_logits")))
+    with torch.no_grad():
+        m(mixed, lips)
+    for h in hs:
+        h.remove()
+    return taps
+
+
+def sliced(a, step):
+    """Deterministic strided sample of a tensor + float64 checksums."""
+    flat = np.ascontiguousarray(a).reshape(-1)
+    return dict(slice=flat[::step].copy(), sum=np.float64(flat.astype(np.float64).sum()),
+                abssum=np.float64(np.abs(flat.astype(np.float64)).sum()))
+
+
+def pack_outputs(out, c, taps, sep, masks, sep64, masks64):
+    # memory order of the reference's outputs is (B,T,S,F); goldens are stored in
+    # logical (B,S,F,T) order, C-contiguous.
+    if c["full"]:
+        for k, v in taps.items():
+            if k.startswith("v_proj"):
+                v = v.reshape(c["B"], c["N"], c["d"])
+            out["tap." + k] = v.astype(np.float32)
+        out["separated"], out["masks"] = sep, masks
+        out["separated64"], out["masks64"] = sep64, masks64
+    else:
+        for k, v in taps.items():
+            s = sliced(v, 97)
+            out["tap." + k + ".slice"], out["tap." + k + ".sum"], out["tap." + k + ".abssum"] = \
+                s["slice"], s["sum"], s["abssum"]
+        for name, a, a64 in (("separated", sep, sep64), ("masks", masks, masks64)):
+            s = sliced(a, 7)
+            out[name + ".slice"], out[name + ".sum"], out[name + ".abssum"] = s["slice"], s["sum"], s["abssum"]
+            out[name + "64.slice"] = sliced(a64, 7)["slice"]
+
+
+def make_forward(name, c, outdir):
+    shapes = seeded.model_shapes(c["F"], c["d"], c["h"], c["Le"], c["Lf"], c["S"])
+    state = seeded.fill_state(shapes, c["seed"])
+    m = build_reference(c, state)
+    check_shapes(c, m)
+    if "dataset" in c:
+        ds = ref.SyntheticAVDataset(num_samples=8, **c["dataset"])
+        items = [ds[i] for i in range(c["B"])]
+        mixed = torch.stack([it["mixed_spec"] for it in items])
+        lips = torch.stack([it["lip_frames"] for it in items])
+    else:
+        mx, lp = seeded.inputs(c["seed"], c["B"], c["F"], c["T"], c["N"], c["H"], c["W"])
+        mixed, lips = torch.from_numpy(mx), torch.from_numpy(lp)
+    assert tuple(mixed.shape) == (c["B"], c["F"], c["T"]), mixed.shape
+    assert tuple(lips.shape) == (c["B"], c["N"], c["H"], c["W"]), lips.shape
+    with torch.no_grad():
+        sep, masks = m(mixed, lips)
+        if c["T"] > 1:
+            assert masks.stride() == (c["S"] * c["F"] * c["T"], c["F"], 1, c["S"] * c["F"]), masks.stride()
+        m64 = build_reference(c, state).double()
+        sep64, masks64 = m64(mixed.double(), lips.double())
+    taps = hooked_taps(m, mixed, lips)
+    out = {"config": np.array(json.dumps({k: v for k, v in c.items() if k != "dataset"}))}
+    # the reference's own pe buffer rows actually used (so the GPU box needs no torch-vs-numpy sin/cos
+    # agreement): only for small configs
+    if c["full"]:
+        out["pe"] = m.audio_encoder.pos_enc.pe[0, :max(c["T"], c["N"])].numpy().copy()
+    pack_outputs(out, c, taps, sep.contiguous().numpy(), masks.contiguous().numpy(),
+                 sep64.contiguous().numpy(), masks64.contiguous().numpy())
+    if "dataset" in c:
+        out["in.mixed"], out["in.lips"] = mixed.numpy(), lips.numpy()
+    path = os.path.join(outdir, f"fwd_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB  masks[{masks.min():.4f},{masks.max():.4f}] "
+          f"fp32-vs-fp64 masks {np.abs(masks.double() - masks64).max():.2e}")
+
+
+def make_trained(outdir):
+    """Weights after the reference's own quick_train recipe (demo.py:83-113: Adam lr 3e-4... here lr 2e-3
+    for 60 steps so the masks saturate, clip 1.0, SeparationLoss(0.5)) on the tiny test-suite shape."""
+    c = dict(CONFIGS["tiny"], Le=2, Lf=2, seed=31)
+    torch.manual_seed(1234)
+    m = ref.AVSeparationTransformer(freq_bins=c["F"], d_model=c["d"], nhead=c["h"], num_encoder_layers=c["Le"],
+                                    num_fusion_layers=c["Lf"], num_speakers=c["S"], dropout=0.0)
+    ds = ref.SyntheticAVDataset(num_samples=64, sample_rate=8000, duration=0.496, n_fft=128, hop_length=128,
+                                num_frames=5, frame_h=16, frame_w=16)
+    it0 = ds[0]
+    assert tuple(it0["mixed_spec"].shape) == (c["F"], c["T"]), it0["mixed_spec"].shape
+    assert tuple(it0["lip_frames"].shape) == (c["N"], c["H"], c["W"])
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3)
+    crit = SeparationLoss(l1_weight=0.5)
+    m.train()
+    g = torch.Generator().manual_seed(7)
+    losses = []
+    for step in range(60):
+        idx = torch.randint(0, 64, (8,), generator=g).tolist()
+        items = [ds[i] for i in idx]
+        mixed = torch.stack([x["mixed_spec"] for x in items])
+        lips = torch.stack([x["lip_frames"] for x in items])
+        tg = torch.stack([x["clean_specs"] for x in items])
+        opt.zero_grad()
+        sep, _ = m(mixed, lips)
+        loss = crit(sep, tg)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss))
+    m.eval()
+    items = [ds[i] for i in (0, 1)]
+    mixed = torch.stack([x["mixed_spec"] for x in items])
+    lips = torch.stack([x["lip_frames"] for x in items])
+    with torch.no_grad():
+        sep, masks = m(mixed, lips)
+        sep64, masks64 = build_reference(c, {k: v.numpy() for k, v in m.state_dict().items()}).double()(
+            mixed.double(), lips.double())
+    taps = hooked_taps(m, mixed, lips)
+    out = {"config": np.array(json.dumps(c)), "in.mixed": mixed.numpy(), "in.lips": lips.numpy(),
+           "losses": np.array(losses)}
+    for k, v in m.state_dict().items():
+        if not k.endswith(".pe"):
+            out["w." + k] = v.numpy()
+    out["pe"] = m.audio_encoder.pos_enc.pe[0, :c["T"]].numpy().copy()
+    pack_outputs(out, c, taps, sep.contiguous().numpy(), masks.contiguous().numpy(),
+                 sep64.contiguous().numpy(), masks64.contiguous().numpy())
+    path = os.path.join(outdir, "trained_tiny.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB loss {losses[0]:.2f}->{losses[-1]:.2f} "
+          f"masks[{masks.min():.5f},{masks.max():.5f}]")
+
+
+def make_dataset(outdir):
+    out = {}
+    small = dict(num_samples=8, sample_rate=8000, duration=0.496, n_fft=128, hop_length=128, num_frames=5,
+                 frame_h=16, frame_w=16)
+    cfg1 = dict(num_samples=8)                                   # all defaults = BASELINE config 1
+    cfg4 = dict(num_samples=8, sample_rate=16000, duration=2.0, speaker_freqs=(220.0, 440.0, 660.0))
+    cfg5 = dict(num_samples=8, sample_rate=16000, duration=4.0, frame_h=48, frame_w=48)
+    for tag, kw, full in (("small", small, True), ("cfg1", cfg1, False), ("cfg4", cfg4, False),
+                          ("cfg5", cfg5, False)):
+        ds = ref.SyntheticAVDataset(**kw)
+        out[f"{tag}.kwargs"] = np.array(json.dumps(kw))
+        out[f"{tag}.dims"] = np.array([ds.freq_bins, ds.T, len(ds)])
+        for idx in (0, 1, 3):
+            it = ds[idx]
+            for key in ("mixed_spec", "lip_frames", "clean_specs"):
+                a = it[key].numpy()
+                if full or (tag == "cfg1" and idx == 0 and key != "lip_frames"):
+                    out[f"{tag}.{idx}.{key}"] = a
+                else:
+                    s = sliced(a, 13)
+                    out[f"{tag}.{idx}.{key}.slice"] = s["slice"]
+                    out[f"{tag}.{idx}.{key}.sum"] = s["sum"]
+                    out[f"{tag}.{idx}.{key}.shape"] = np.array(a.shape)
+    path = os.path.join(outdir, "dataset.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def make_losses(outdir):
+    out = {}
+    est = torch.from_numpy(seeded.tensor(41, "loss.est", (4, 3, 17, 11), 0.0, 2.0))
+    tgt = torch.from_numpy(seeded.tensor(41, "loss.tgt", (4, 3, 17, 11), 0.0, 2.0))
+    out["est"], out["tgt"] = est.numpy(), tgt.numpy()
+    out["si_snr_4d"] = np.float64(si_snr(est, tgt))
+    out["si_snr_3d"] = np.float64(si_snr(est[:, 0], tgt[:, 0]))
+    out["si_snr_self"] = np.float64(si_snr(tgt, tgt))
+    for s in (2, 3):
+        for w in (0.5, 0.0):
+            out[f"sep_loss_S{s}_w{w}"] = np.float64(SeparationLoss(l1_weight=w)(est[:, :s], tgt[:, :s]))
+    # permuted target: PIT must find it
+    out["sep_loss_perm"] = np.float64(SeparationLoss(0.5)(tgt[:, [2, 0, 1]] * 0.9, tgt))
+    e = est.clone().requires_grad_(True)
+    SeparationLoss(0.5)(e, tgt).backward()
+    out["sep_loss_grad"] = e.grad.numpy()
+    path = os.path.join(outdir, "losses.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--out", default=HERE)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    for name, c in CONFIGS.items():
+        if a.only in (None, name):
+            make_forward(name, c, a.out)
+    if a.only in (None, "trained"):
+        make_trained(a.out)
+    if a.only in (None, "dataset"):
+        make_dataset(a.out)
+    if a.only in (None, "losses"):
+        make_losses(a.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""Pins the CPU oracle (oracle/numpy_forward.py) against the golden vectors produced by the reference
+(tests/golden/make_golden.py).  Tolerances: the reference's own fp32 noise floor is ~2e-7 on masks
+(SURVEY.md §8(c)); the oracle must sit within 2e-6 of the fp32 goldens and 1e-6 of the fp64 goldens
+(float64 mode), far inside the 1e-4 hard gate of BASELINE.json."""
+import numpy as np
+import pytest
+
+from oracle import numpy_forward as onp
+from oracle import seeded
+from helpers import golden_state, golden_inputs, sliced, maxabs
+
+FULL = ["fwd_tiny", "fwd_odd", "fwd_down", "fwd_t1", "trained_tiny"]
+BIG = ["fwd_cfg1", "fwd_cfg3", "fwd_cfg4", "fwd_cfg5"]
+
+
+def _run(g, dtype, taps=None):
+    c = g["config"]
+    state = golden_state(g)
+    if "pe" in g:   # the reference's own pe rows (torch sin/cos), so numpy-vs-torch trig does not enter
+        L, d = g["pe"].shape
+        pe = np.zeros((1, L, d), np.float32)
+        pe[0] = g["pe"]
+        state["audio_encoder.pos_enc.pe"] = pe
+        state["visual_encoder.pos_enc.pe"] = pe
+    mixed, lips = golden_inputs(g)
+    return onp.forward(state, mixed, lips, c["h"], c["S"], dtype=dtype, taps=taps)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_oracle_full_fixtures_fp32(golden, name):
+    g = golden(name)
+    taps = {}
+    sep, masks = _run(g, np.float32, taps)
+    assert masks.shape == g["masks"].shape
+    assert maxabs(masks, g["masks"]) < 2e-6
+    scale = max(1.0, float(np.abs(golden_inputs(g)[0]).max()))
+    assert maxabs(sep, g["separated"]) < 2e-6 * scale
+    for k, v in taps.items():
+        ref = g["tap." + k]
+        tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+        assert maxabs(v.reshape(ref.shape), ref) < tol, k
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_oracle_full_fixtures_fp64(golden, name):
+    g = golden(name)
+    sep, masks = _run(g, np.float64)
+    # pe is float32 in both; everything else float64 -> agreement to ~1e-12 would need identical op
+    # order; 1e-9 shows the formulas are the same ones
+    assert maxabs(masks, g["masks64"]) < 1e-9
+    assert maxabs(sep, g["separated64"]) < 1e-7
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_oracle_baseline_configs(golden, name):
+    g = golden(name)
+    taps = {}
+    sep, masks = _run(g, np.float32, taps)
+    c = g["config"]
+    assert masks.shape == (c["B"], c["S"], c["F"], c["T"])
+    assert maxabs(sliced(masks, 7), g["masks.slice"]) < 5e-6
+    assert maxabs(sliced(masks, 7), g["masks64.slice"]) < 5e-6
+    scale = max(1.0, float(np.abs(golden_inputs(g)[0]).max()))
+    assert maxabs(sliced(sep, 7), g["separated.slice"]) < 5e-6 * scale
+    assert abs(masks.astype(np.float64).sum() - g["masks.sum"]) < 1e-6 * g["masks.abssum"]
+    for k, v in taps.items():
+        ref = g["tap." + k + ".slice"]
+        tol = 5e-5 * max(1.0, float(np.abs(ref).max()))
+        assert maxabs(sliced(v, 97), ref) < tol, k
+
+
+def test_seeded_generator_known_answers():
+    # splitmix64 reference values (seed 0): published test vector of the algorithm
+    z = seeded.splitmix64(0, 3)
+    assert [int(x) for x in z] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    assert seeded.fnv1a64("") == 0xCBF29CE484222325
+    assert seeded.fnv1a64("a") == 0xAF63DC4C8601EC8C
+    t = seeded.tensor(5, "x", (4,), -1.0, 1.0)
+    assert t.dtype == np.float32 and np.all(np.abs(t) <= 1)
+
+
+def test_interp_matches_definition():
+    # upsample 2 -> 4 with align_corners=False: src = (i+0.5)*0.5-0.5 -> [-0.25->0, 0.25, 0.75, 1.25->clamped]
+    x = np.array([[[0.0], [1.0]]], dtype=np.float32)
+    y = onp.interp_linear(x, 4)[0, :, 0]
+    np.testing.assert_allclose(y, [0.0, 0.25, 0.75, 1.0], atol=1e-7)
