@@ -1,0 +1,85 @@
+"""ctypes binding of libavsep_hip.so (C ABI: include/avsep.h).
+
+The HIP library IS the product path.  There is no CPU or eager-PyTorch fallback anywhere in this
+package: if the shared library is missing or an entry point fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libavsep_hip.so")
+
+# every symbol include/avsep.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "avsep_abi_version", "avsep_last_error", "avsep_create", "avsep_destroy", "avsep_set_weight",
+    "avsep_finalize_weights", "avsep_workspace_bytes", "avsep_forward", "avsep_forward_graph",
+    "avsep_audio_encoder", "avsep_visual_encoder", "avsep_fusion", "avsep_decoder",
+    "avsep_set_debug_taps", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_layernorm",
+    "avsep_op_attention", "avsep_op_interp_linear",
+)
+
+
+class AvsepConfig(C.Structure):
+    _fields_ = [("freq_bins", C.c_int32), ("d_model", C.c_int32), ("nhead", C.c_int32),
+                ("num_encoder_layers", C.c_int32), ("num_fusion_layers", C.c_int32),
+                ("num_speakers", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(`python -c 'import __graft_entry__ as g; g.build()'` at the repo root, or "
+            "`make -C av-separation-transformer_amd/csrc`).  There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    p, i, i64, sz, fp = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_void_p
+    lib.avsep_abi_version.restype = i
+    lib.avsep_last_error.restype = C.c_char_p
+    lib.avsep_create.argtypes = [C.POINTER(AvsepConfig), C.POINTER(p)]
+    lib.avsep_destroy.argtypes = [p]
+    lib.avsep_destroy.restype = None
+    lib.avsep_set_weight.argtypes = [p, C.c_char_p, fp, C.POINTER(i64), i]
+    lib.avsep_finalize_weights.argtypes = [p, p]
+    lib.avsep_workspace_bytes.argtypes = [p, i, i, i, i, i]
+    lib.avsep_workspace_bytes.restype = sz
+    fwd = [p, fp, fp, fp, fp, p, sz, i, i, i, i, i, p]
+    lib.avsep_forward.argtypes = fwd
+    lib.avsep_forward_graph.argtypes = fwd
+    lib.avsep_audio_encoder.argtypes = [p, fp, fp, p, sz, i, i, p]
+    lib.avsep_visual_encoder.argtypes = [p, fp, fp, p, sz, i, i, i, i, i, p]
+    lib.avsep_fusion.argtypes = [p, fp, fp, fp, p, sz, i, i, p]
+    lib.avsep_decoder.argtypes = [p, fp, fp, fp, fp, p, sz, i, i, p]
+    lib.avsep_set_debug_taps.argtypes = [p, i]
+    lib.avsep_read_tap.argtypes = [p, C.c_char_p, fp, i64, p, i, i, i, i, i, p]
+    lib.avsep_read_tap.restype = i64
+    lib.avsep_profile_begin.argtypes = [p]
+    lib.avsep_profile_end.argtypes = [p, C.c_char_p, sz]
+    lib.avsep_profile_end.restype = i64
+    lib.avsep_op_linear.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, p]
+    lib.avsep_op_layernorm.argtypes = [fp, fp, fp, fp, i, i, C.c_float, p]
+    lib.avsep_op_attention.argtypes = [fp, i, fp, i, fp, i, fp, i, i, i, i, i, i, p]
+    lib.avsep_op_interp_linear.argtypes = [fp, fp, i, i, i, i, p]
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)     # AttributeError here = ABI drift between header and library
+        if fn.restype is C.c_int and name not in ("avsep_abi_version",):
+            fn.restype = i
+    if lib.avsep_abi_version() != 1:
+        raise RuntimeError("libavsep_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what="avsep call"):
+    if rc is not None and rc < 0:
+        msg = load().avsep_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else 'unknown error'}")
+    return rc

@@ -1,0 +1,187 @@
+// attention.hip -- softmax(q k^T) v for one (batch, head, 16-query tile) per wavefront, fp32 on the
+// matrix cores, online softmax, no score matrix in memory.
+//
+// Replaces the score/softmax/PV part of nn.MultiheadAttention for both the self-attention of
+// nn.TransformerEncoderLayer (model.py:48-52, 97-101) and the audio-queries-visual cross-attention
+// (model.py:155,169).  q arrives already multiplied by 1/sqrt(dh): the weight packer folds the scale into
+// Wq/bq, which is where torch's fast path applies it too.
+//
+// Layout trick (CDNA4 16x16x4 fp32 MFMA, C/D: col = lane&15, row = 4*(lane>>4)+reg):
+//   S^T = K Q^T  (A = K rows, B = Q^T)  ->  lane (c = query, g) holds S^T[key = 4g+r][c] in reg r
+//   O^T = V^T P^T (A = V^T, B = P^T)    ->  the P^T operand of MFMA step r is exactly reg r of S^T:
+//                                           no LDS round trip, no cross-lane movement for P
+//   the softmax statistics of query c live on the 4 lanes {c, c+16, c+32, c+48}: two shuffles per tile.
+// V^T rows are assigned dv = NB*i + blk so each lane's V read is NB contiguous floats and each lane ends
+// up owning 4 consecutive dv per accumulator register -> float4 stores.
+// K/V are read straight from L2 (a head's K and V are <= 2*Lk*dh*4 B, shared by the 4 waves of the
+// workgroup through the CU's L1); fp32 MFMA needs 1 operand dword per lane per 32 cycles, so there is
+// nothing for an LDS stage to win here.
+#include "kernels.h"
+
+namespace {
+
+// NB = ceil(dh / 16).  REG = (dh == 16*NB): the fast path with unpredicated vector loads; otherwise the head
+// is zero-extended to 16*NB (k >= dh contributes 0 to S, rows dv >= dh of O^T are never stored).
+template <int NB, bool REG>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq,
+                                                        const float* __restrict__ k, int ldk,
+                                                        const float* __restrict__ v, int ldv,
+                                                        float* __restrict__ o, int ldo, int nhead, int Lq,
+                                                        int Lk, int nqt, int DH) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c = lane & 15;    // query column (as B operand / C column); key row (as A operand of S^T)
+  const int g = lane >> 4;    // k-quarter of the MFMA
+  const int wg_per_head = (nqt + 3) >> 2;
+  const int bh = blockIdx.x / wg_per_head;
+  const int qt = (blockIdx.x - bh * wg_per_head) * 4 + wave;
+  if (qt >= nqt) return;      // no barriers in this kernel: a wave may leave early
+  const int b = bh / nhead, h = bh - b * nhead;
+
+  const float* qb = q + (size_t)b * Lq * ldq + h * DH;
+  const float* kb = k + (size_t)b * Lk * ldk + h * DH;
+  const float* vb = v + (size_t)b * Lk * ldv + h * DH;
+  float* ob = o + (size_t)b * Lq * ldo + h * DH;
+
+  // Q^T fragments: lane (c,g) holds Q[q0+c][16s+4g .. +3], s < NB   (k-permuted, same as K below)
+  const int qrow = min(qt * 16 + c, Lq - 1);
+  f32x4 qf[NB];
+#pragma unroll
+  for (int s = 0; s < NB; ++s)
+    qf[s] = (REG || 16 * s + 4 * g < DH) ? *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrun = -INFINITY, lrun = 0.0f;
+
+  const int nkt = (Lk + 15) >> 4;
+  // software prefetch of the next key tile's K and V fragments
+  f32x4 kf[NB];
+  float vf[4][NB];
+  auto load_tile = [&](int kt) {
+    const int krow = min(kt * 16 + c, Lk - 1);
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+      kf[s] = (REG || 16 * s + 4 * g < DH) ? *reinterpret_cast<const f32x4*>(kb + (size_t)krow * ldk + 16 * s + 4 * g)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int vrow = min(kt * 16 + 4 * g + r, Lk - 1);
+      const float* src = vb + (size_t)vrow * ldv + NB * c;
+      if constexpr (!REG) {
+#pragma unroll
+        for (int e = 0; e < NB; ++e) vf[r][e] = (NB * c + e < DH) ? src[e] : 0.0f;
+      } else if constexpr (NB == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        vf[r][0] = t[0]; vf[r][1] = t[1]; vf[r][2] = t[2]; vf[r][3] = t[3];
+      } else if constexpr (NB == 8) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[r][e] = t0[e]; vf[r][4 + e] = t1[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < NB; ++e) vf[r][e] = src[e];
+      }
+    }
+  };
+
+  load_tile(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x4 kc[NB];
+    float vc[4][NB];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) kc[s] = kf[s];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int e = 0; e < NB; ++e) vc[r][e] = vf[r][e];
+    if (kt + 1 < nkt) load_tile(kt + 1);
+
+    // S^T tile: 16 keys x 16 queries, contraction over dh
+    f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[s][j], qf[s][j], st, 0, 0, 0);
+
+    // mask keys beyond Lk, online softmax over this tile's 16 keys of query c
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      st[r] = key < Lk ? st[r] : -INFINITY;
+      tmax = fmaxf(tmax, st[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float mnew = fmaxf(mrun, tmax);          // finite: tile 0 always holds key 0
+    const float alpha = __expf(mrun - mnew);       // 0 on the first tile (mrun = -inf)
+    float psum = 0.0f;
+    float pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = __expf(st[r] - mnew);
+      psum += pr[r];
+    }
+    lrun = lrun * alpha + psum;                    // per-lane partial (own 4 keys per tile); reduced at the end
+    mrun = mnew;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] *= alpha;
+
+    // O^T += V^T P^T : step r contracts keys {4g'+r}, A row i <-> dv = NB*i + blk
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[r][blk], pr[r], acc[blk], 0, 0, 0);
+  }
+
+  lrun += __shfl_xor(lrun, 16);
+  lrun += __shfl_xor(lrun, 32);
+  const float inv = 1.0f / lrun;
+  const int qo = qt * 16 + c;
+  if (qo < Lq) {
+    // lane (c, g) holds O[qo][dv = NB*(4g+reg) + blk]; for a fixed reg the NB blks are contiguous
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* dst = ob + (size_t)qo * ldo + NB * (4 * g + r);
+      if constexpr (!REG) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+          if (NB * (4 * g + r) + blk < DH) dst[blk] = acc[blk][r] * inv;
+      } else if constexpr (NB == 4) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
+      } else {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) dst[blk] = acc[blk][r] * inv;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                            int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s) {
+  if (B <= 0 || nhead <= 0 || Lq <= 0 || Lk <= 0) return hipErrorInvalidValue;
+  if ((ldq | ldk | ldv | ldo) & 3) return hipErrorInvalidValue;   // float4 row alignment
+  const int nqt = (Lq + 15) / 16;
+  const int wg_per_head = (nqt + 3) / 4;
+  const dim3 grid((unsigned)(B * nhead * wg_per_head)), block(256);
+  if (dh <= 0 || dh > 128 || (dh & 3)) return hipErrorInvalidValue;
+  const int nb = (dh + 15) / 16;
+  const bool reg = (dh == 16 * nb);
+#define AVSEP_ATT(NB_)                                                                                              \
+  if (nb == NB_) {                                                                                                  \
+    if (reg) hipLaunchKernelGGL((attention_kernel<NB_, true>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,   \
+                                nhead, Lq, Lk, nqt, dh);                                                            \
+    else hipLaunchKernelGGL((attention_kernel<NB_, false>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,      \
+                            nhead, Lq, Lk, nqt, dh);                                                                \
+  }
+  AVSEP_ATT(1) AVSEP_ATT(2) AVSEP_ATT(3) AVSEP_ATT(4) AVSEP_ATT(5) AVSEP_ATT(6) AVSEP_ATT(7) AVSEP_ATT(8)
+#undef AVSEP_ATT
+  return hipGetLastError();
+}

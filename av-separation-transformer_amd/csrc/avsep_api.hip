@@ -1,0 +1,874 @@
+// avsep_api.hip -- context, weight packer, workspace carving and the forward schedule behind the C ABI
+// of include/avsep.h.  Host-side C++ only; every device kernel lives in gemm.hip / attention.hip /
+// rowops.hip.  The schedule follows AVSeparationTransformer.forward (model.py:268-276): audio encoder
+// and visual encoder are independent until fusion, so they are enqueued on two HIP streams.
+#include "../../include/avsep.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return AVSEP_EHIP;
+}
+#define HCK(x)                                         \
+  do {                                                 \
+    hipError_t e_ = (x);                               \
+    if (e_ != hipSuccess) return fail_hip(e_, #x);     \
+  } while (0)
+#define RCK(x)                  \
+  do {                          \
+    int r_ = (x);               \
+    if (r_ != AVSEP_OK) return r_; \
+  } while (0)
+
+inline size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
+inline int conv_out(int x) { return (x - 1) / 2 + 1; }   // k3 s2 p1 (model.py:82)
+
+struct RawW {
+  const float* ptr = nullptr;
+  std::vector<int64_t> shape;
+};
+
+struct EncLayerW {   // nn.TransformerEncoderLayer (model.py:48-52)
+  float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2, *g1, *be1, *g2, *be2;
+};
+struct FusLayerW {   // CrossAttentionLayer (model.py:152-164); its K/V rows live in wkv_all
+  float *wq, *bq, *wo, *bo, *w1, *b1, *w2, *b2, *g1, *be1, *g2, *be2;
+};
+
+struct Workspace {   // all float*, carved from the caller's buffer
+  float *xt, *a_h0, *a_x, *ln, *qkv, *att, *ffn;
+  float *act1, *act2, *act3, *pool, *v_x, *v_ln, *v_qkv, *v_att, *v_ffn, *v_up;
+  float *kv_all, *f_q;
+  float* taps;
+  size_t floats;
+};
+
+struct GraphEntry {
+  const void *mixed, *lips, *masks, *sep, *ws;
+  size_t ws_bytes;
+  int B, T, N, H, W;
+  hipGraphExec_t exec;
+};
+
+}  // namespace
+
+struct avsep_ctx {
+  avsep_config cfg;
+  int F, Fp, d, h, dh, Le, Lf, S;
+  std::unordered_map<std::string, RawW> raw;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  bool finalized = false;
+  bool ok_audio = false, ok_visual = false, ok_fusion = false, ok_decoder = false;
+  int pe_len_a = 0, pe_len_v = 0;
+  // packed weights
+  float *a_w1, *a_b1, *a_w2, *a_b2, *a_pe;
+  std::vector<EncLayerW> a_layers, v_layers;
+  float *c1_w, *c1_b, *c2_w, *c2_b, *c3_w, *c3_b, *fp_w, *fp_b, *v_pe;
+  float *wkv_all, *bkv_all;
+  std::vector<FusLayerW> f_layers;
+  float *fn_g, *fn_b, *d_w1, *d_b1, *d_w2, *d_b2;
+  // streams / events for the audio || visual fork-join and graph replay
+  hipStream_t side = nullptr, gstream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gin = nullptr, ev_gout = nullptr;
+  std::vector<GraphEntry> graphs;
+  // live per-kernel profiler (HIP events around every launch, on the launch's own stream)
+  struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  // debug taps
+  bool keep_taps = false;
+  struct Tap { std::string name; size_t off, n; };
+  std::vector<Tap> taps;
+  size_t tap_cursor = 0;
+};
+
+namespace {
+
+constexpr int PE_MAX_LEN = 5000;   // PositionalEncoding(max_len=5000), model.py:286
+
+// ------------------------------------------------------------------------------------------ arena
+template <typename F>
+void layout_arena(avsep_ctx* c, F&& take) {
+  const int d = c->d, Fp = c->Fp, F_ = c->F, S = c->S;
+  (void)F_;
+  c->a_w1 = take((size_t)d * 3 * Fp);
+  c->a_b1 = take(d);
+  c->a_w2 = take((size_t)d * 3 * d);
+  c->a_b2 = take(d);
+  c->a_pe = take((size_t)PE_MAX_LEN * d);
+  auto enc = [&](std::vector<EncLayerW>& v) {
+    v.resize(c->Le);
+    for (auto& L : v) {
+      L.wqkv = take((size_t)3 * d * d); L.bqkv = take(3 * d);
+      L.wo = take((size_t)d * d); L.bo = take(d);
+      L.w1 = take((size_t)4 * d * d); L.b1 = take(4 * d);
+      L.w2 = take((size_t)4 * d * d); L.b2 = take(d);
+      L.g1 = take(d); L.be1 = take(d); L.g2 = take(d); L.be2 = take(d);
+    }
+  };
+  enc(c->a_layers);
+  c->c1_w = take(9 * 32); c->c1_b = take(32);
+  c->c2_w = take(64 * 9 * 32); c->c2_b = take(64);
+  c->c3_w = take(128 * 9 * 64); c->c3_b = take(128);
+  c->fp_w = take((size_t)d * 128); c->fp_b = take(d);
+  c->v_pe = take((size_t)PE_MAX_LEN * d);
+  enc(c->v_layers);
+  c->wkv_all = take((size_t)c->Lf * 2 * d * d);
+  c->bkv_all = take((size_t)c->Lf * 2 * d);
+  c->f_layers.resize(c->Lf);
+  for (auto& L : c->f_layers) {
+    L.wq = take((size_t)d * d); L.bq = take(d);
+    L.wo = take((size_t)d * d); L.bo = take(d);
+    L.w1 = take((size_t)4 * d * d); L.b1 = take(4 * d);
+    L.w2 = take((size_t)4 * d * d); L.b2 = take(d);
+    L.g1 = take(d); L.be1 = take(d); L.g2 = take(d); L.be2 = take(d);
+  }
+  c->fn_g = take(d); c->fn_b = take(d);
+  c->d_w1 = take((size_t)2 * d * d); c->d_b1 = take(2 * d);
+  c->d_w2 = take((size_t)S * c->F * 2 * d); c->d_b2 = take((size_t)S * c->F);
+}
+
+// ------------------------------------------------------------------------------------------ raw weights
+const RawW* find(const avsep_ctx* c, const std::string& key) {
+  auto it = c->raw.find(key);
+  return it == c->raw.end() ? nullptr : &it->second;
+}
+bool has_shape(const RawW* w, std::initializer_list<int64_t> shp) {
+  if (!w || w->shape.size() != shp.size()) return false;
+  size_t i = 0;
+  for (int64_t s : shp)
+    if (w->shape[i++] != s) return false;
+  return true;
+}
+
+__global__ void pe_fill_kernel(float* pe, int max_len, int d) {
+  // fallback when the caller supplied no `pe` buffer: same formula as model.py:289-297
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)max_len * d) return;
+  const int p = (int)(idx / d), j = (int)(idx % d);
+  const float div = expf((float)(j & ~1) * (-logf(10000.0f) / (float)d));
+  const float a = (float)p * div;
+  pe[idx] = (j & 1) ? cosf(a) : sinf(a);
+}
+
+struct Packer {
+  avsep_ctx* c;
+  hipStream_t s;
+  hipError_t err = hipSuccess;
+  bool missing = false;
+  std::string first_missing;
+
+  const float* need(const std::string& key, std::initializer_list<int64_t> shp) {
+    const RawW* w = find(c, key);
+    if (!has_shape(w, shp)) {
+      if (!missing) first_missing = key;
+      missing = true;
+      return nullptr;
+    }
+    return w->ptr;
+  }
+  void keep(hipError_t e) {
+    if (err == hipSuccess && e != hipSuccess) err = e;
+  }
+  void copy(const std::string& key, float* dst, int64_t n) {
+    const float* p = need(key, {n});
+    if (p) keep(launch_scale_copy(p, dst, (int)n, 1.0f, 0, s));
+  }
+  void rows(const std::string& key, float* dst, int64_t r, int64_t k) {
+    const float* p = need(key, {r, k});
+    if (p) keep(launch_pack_rows(p, dst, (int)r, (int)k, (int)k, 1.0f, 0, s));
+  }
+};
+
+bool pack_encoder(Packer& P, const std::string& pre, std::vector<EncLayerW>& layers) {
+  avsep_ctx* c = P.c;
+  const int d = c->d;
+  const float qs = 1.0f / std::sqrt((float)c->dh);
+  for (size_t i = 0; i < layers.size(); ++i) {
+    const std::string p = pre + "transformer.layers." + std::to_string(i) + ".";
+    EncLayerW& L = layers[i];
+    // packed in_proj rows = [Wq;Wk;Wv]; fold 1/sqrt(dh) into the q rows and q bias
+    if (const float* w = P.need(p + "self_attn.in_proj_weight", {3 * d, d}))
+      P.keep(launch_pack_rows(w, L.wqkv, 3 * d, d, d, qs, d, P.s));
+    if (const float* b = P.need(p + "self_attn.in_proj_bias", {3 * d}))
+      P.keep(launch_scale_copy(b, L.bqkv, 3 * d, qs, d, P.s));
+    P.rows(p + "self_attn.out_proj.weight", L.wo, d, d);
+    P.copy(p + "self_attn.out_proj.bias", L.bo, d);
+    P.rows(p + "linear1.weight", L.w1, 4 * d, d);
+    P.copy(p + "linear1.bias", L.b1, 4 * d);
+    P.rows(p + "linear2.weight", L.w2, d, 4 * d);
+    P.copy(p + "linear2.bias", L.b2, d);
+    P.copy(p + "norm1.weight", L.g1, d);
+    P.copy(p + "norm1.bias", L.be1, d);
+    P.copy(p + "norm2.weight", L.g2, d);
+    P.copy(p + "norm2.bias", L.be2, d);
+  }
+  return !P.missing;
+}
+
+int pack_pe(Packer& P, const std::string& key, float* dst, int* len_out) {
+  avsep_ctx* c = P.c;
+  const RawW* w = find(c, key);
+  if (w) {
+    if (w->shape.size() != 3 || w->shape[0] != 1 || w->shape[2] != c->d || w->shape[1] > PE_MAX_LEN)
+      return fail(AVSEP_EINVAL, key + ": expected shape (1, <=5000, d_model)");
+    *len_out = (int)w->shape[1];
+    P.keep(launch_scale_copy(w->ptr, dst, (int)(w->shape[1] * c->d), 1.0f, 0, P.s));
+  } else {
+    *len_out = PE_MAX_LEN;
+    const size_t n = (size_t)PE_MAX_LEN * c->d;
+    hipLaunchKernelGGL(pe_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, P.s, dst, PE_MAX_LEN, c->d);
+    P.keep(hipGetLastError());
+  }
+  return AVSEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+size_t carve(const avsep_ctx* c, Workspace* w, float* base, int B, int T, int N, int H, int W) {
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    float* p = base ? base + off : nullptr;
+    off += align_up(n ? n : 1, 64);
+    return p;
+  };
+  const size_t Ma = (size_t)B * T, Mv = (size_t)B * N;
+  const int d = c->d;
+  const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2),
+            W3 = conv_out(W2);
+  Workspace t{};
+  t.xt = take(Ma * c->Fp);
+  t.a_h0 = take(Ma * d);
+  t.a_x = take(Ma * d);
+  t.ln = take(Ma * d);
+  t.qkv = take(Ma * 3 * d);
+  t.att = take(Ma * d);
+  t.ffn = take(Ma * 4 * d);
+  t.act1 = take(Mv * H1 * W1 * 32);
+  t.act2 = take(Mv * H2 * W2 * 64);
+  t.act3 = take(Mv * H3 * W3 * 128);
+  t.pool = take(Mv * 128);
+  t.v_x = take(Mv * d);
+  t.v_ln = take(Mv * d);
+  t.v_qkv = take(Mv * 3 * d);
+  t.v_att = take(Mv * d);
+  t.v_ffn = take(Mv * 4 * d);
+  t.v_up = take(Ma * d);
+  t.kv_all = take(Ma * (size_t)c->Lf * 2 * d);
+  t.f_q = take(Ma * d);
+  if (c->keep_taps) {
+    // generous bound: every tap is at most one (M, d)-sized activation or one conv activation
+    size_t n = (size_t)(2 + 2 * c->Le + c->Lf + 3) * align_up(Ma * d > Mv * d ? Ma * d : Mv * d, 64);
+    n += align_up(Mv * H1 * W1 * 32, 64) + align_up(Mv * H2 * W2 * 64, 64) + align_up(Mv * H3 * W3 * 128, 64) +
+         align_up(Mv * 128, 64);
+    t.taps = take(n);
+  }
+  t.floats = off;
+  if (w) *w = t;
+  return off;
+}
+
+int record_tap(avsep_ctx* c, const Workspace& w, const char* name, const float* src, size_t n, hipStream_t s) {
+  if (!c->keep_taps) return AVSEP_OK;
+  HCK(hipMemcpyAsync(w.taps + c->tap_cursor, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  c->taps.push_back({name, c->tap_cursor, n});
+  c->tap_cursor += align_up(n, 64);
+  return AVSEP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ profiled launches
+// Every kernel of the forward goes through one of these wrappers.  With the profiler off they are plain
+// launches; with it on, each launch is bracketed by two HIP events recorded on the stream it runs on, and
+// carries its ALGORITHMIC flops/bytes (DESIGN.md "roofline accounting"), so bench.py can price every kernel
+// live, on hardware, without an external profiler.
+template <typename L>
+int profiled(avsep_ctx* c, const char* name, double flops, double bytes, hipStream_t s, L&& launch) {
+  if (!c->prof_on) {
+    HCK(launch());
+    return AVSEP_OK;
+  }
+  avsep_ctx::ProfRec r{name, flops, bytes, nullptr, nullptr};
+  HCK(hipEventCreate(&r.e0));
+  HCK(hipEventCreate(&r.e1));
+  HCK(hipEventRecord(r.e0, s));
+  hipError_t e = launch();
+  HCK(hipEventRecord(r.e1, s));
+  c->prof.push_back(r);
+  HCK(e);
+  return AVSEP_OK;
+}
+
+// kalg: algorithmic K (un-padded) for the flop count
+int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
+  const double k = kalg > 0 ? kalg : p.K;
+  const double flops = 2.0 * p.M * p.N * k;
+  double a_bytes = (double)p.M * k * 4;
+  if (p.amode == AMODE_TAPS3) a_bytes /= 3;                      // each input row feeds 3 taps
+  if (p.amode == AMODE_CONV2D) a_bytes = a_bytes / 9 * 4;        // stride-2 3x3: each input pixel read once
+  double bytes = a_bytes + (double)p.N * k * 4 + (double)p.M * p.N * 4 * (p.C2 ? 2 : 1);
+  if (p.R) bytes += (double)(p.rperiod > 0 ? p.rperiod : p.M) * p.N * 4;
+  if (p.C2) bytes += (double)p.M * p.F * 4;
+  return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm(p, s); });
+}
+int run_layernorm(avsep_ctx* c, const float* x, const float* g, const float* b, float* y, int M, int d, hipStream_t s) {
+  return profiled(c, "layernorm_kernel", 8.0 * M * d, 2.0 * M * d * 4, s,
+                  [&] { return launch_layernorm(x, g, b, y, M, d, 1e-5f, s); });
+}
+int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                  int ldo, int B, int Lq, int Lk, hipStream_t s) {
+  const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh;
+  const double bytes = 4.0 * B * c->d * (2.0 * Lq + 2.0 * Lk);
+  return profiled(c, "attention_kernel", flops, bytes, s,
+                  [&] { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, s); });
+}
+
+// ------------------------------------------------------------------------------------------ building blocks
+GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
+                         int M, int N, int act) {
+  GemmParams p{};
+  p.A = A; p.W = W; p.bias = bias; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldw = K; p.ldc = ldc;
+  p.amode = AMODE_PLAIN;
+  p.act = act;
+  return p;
+}
+
+// one pre-norm encoder layer: x += Wo*Attn(LN1 x); x += W2*relu(W1*LN2 x)   (model.py:48-52, norm_first)
+int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
+                  int Lseq, hipStream_t s) {
+  const int d = c->d, M = B * Lseq;
+  RCK(run_layernorm(c, x, L.g1, L.be1, ln, M, d, s));
+  RCK(run_gemm(c, linear_params(ln, d, L.wqkv, d, L.bqkv, qkv, 3 * d, M, 3 * d, ACT_NONE), s));
+  RCK(run_attention(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, d, B, Lseq, Lseq, s));
+  GemmParams po = linear_params(att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
+  po.R = x; po.ldr = d; po.rperiod = 0;
+  RCK(run_gemm(c, po, s));
+  RCK(run_layernorm(c, x, L.g2, L.be2, ln, M, d, s));
+  RCK(run_gemm(c, linear_params(ln, d, L.w1, d, L.b1, ffn, 4 * d, M, 4 * d, ACT_RELU), s));
+  GemmParams p2 = linear_params(ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
+  p2.R = x; p2.ldr = d; p2.rperiod = 0;
+  RCK(run_gemm(c, p2, s));
+  return AVSEP_OK;
+}
+
+int check_common(const avsep_ctx* c, int B, int T) {
+  if (!c) return fail(AVSEP_EINVAL, "null context");
+  if (!c->finalized) return fail(AVSEP_ESTATE, "avsep_finalize_weights() has not been called");
+  if (B <= 0 || T <= 0) return fail(AVSEP_EINVAL, "B and T must be positive");
+  return AVSEP_OK;
+}
+
+// AudioEncoder.forward (model.py:54-60); result left in w.a_x.  Also fills w.xt (mixed^T, padded).
+int audio_branch(avsep_ctx* c, const Workspace& w, const float* mixed, int B, int T, hipStream_t s) {
+  if (!c->ok_audio) return fail(AVSEP_ENOWEIGHT, "audio_encoder weights are incomplete");
+  if (T > c->pe_len_a)
+    return fail(AVSEP_EINVAL, "sequence length exceeds PositionalEncoding max_len (model.py:286,300)");
+  const int d = c->d, M = B * T;
+  RCK(profiled(c, "transpose_pad_kernel", 0.0, 4.0 * B * T * (c->F + c->Fp), s,
+               [&] { return launch_transpose_pad(mixed, w.xt, B, c->F, T, c->Fp, s); }));
+  GemmParams p{};
+  p.A = w.xt; p.lda = c->Fp; p.W = c->a_w1; p.ldw = 3 * c->Fp; p.bias = c->a_b1; p.C = w.a_h0; p.ldc = d;
+  p.M = M; p.N = d; p.K = 3 * c->Fp; p.amode = AMODE_TAPS3; p.T = T; p.Kt = c->Fp; p.act = ACT_RELU;
+  RCK(run_gemm(c, p, s, 3 * c->F));
+  RCK(record_tap(c, w, "a_conv1", w.a_h0, (size_t)M * d, s));
+  GemmParams p2{};
+  p2.A = w.a_h0; p2.lda = d; p2.W = c->a_w2; p2.ldw = 3 * d; p2.bias = c->a_b2; p2.C = w.a_x; p2.ldc = d;
+  p2.M = M; p2.N = d; p2.K = 3 * d; p2.amode = AMODE_TAPS3; p2.T = T; p2.Kt = d; p2.act = ACT_RELU;
+  p2.R = c->a_pe; p2.ldr = d; p2.rperiod = T;   // x + pe[:, :T]  (model.py:300), fused after the ReLU
+  RCK(run_gemm(c, p2, s));
+  RCK(record_tap(c, w, "a_pe", w.a_x, (size_t)M * d, s));
+  for (int i = 0; i < c->Le; ++i) {
+    RCK(encoder_layer(c, c->a_layers[i], w.a_x, w.ln, w.qkv, w.att, w.ffn, B, T, s));
+    RCK(record_tap(c, w, ("a_enc" + std::to_string(i)).c_str(), w.a_x, (size_t)M * d, s));
+  }
+  return AVSEP_OK;
+}
+
+// VisualEncoder.forward (model.py:103-117); result (B,T,d) left in w.v_up.
+int visual_branch(avsep_ctx* c, const Workspace& w, const float* lips, int B, int N, int H, int W, int T,
+                  hipStream_t s) {
+  if (!c->ok_visual) return fail(AVSEP_ENOWEIGHT, "visual_encoder weights are incomplete");
+  if (N <= 0 || H <= 0 || W <= 0) return fail(AVSEP_EINVAL, "N, H, W must be positive");
+  if (N > c->pe_len_v) return fail(AVSEP_EINVAL, "frame count exceeds PositionalEncoding max_len");
+  const int d = c->d, Mv = B * N;
+  const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2),
+            W3 = conv_out(W2);
+  RCK(profiled(c, "conv1_c1_kernel", 2.0 * Mv * H1 * W1 * 32 * 9, 4.0 * Mv * (H * W + H1 * W1 * 32), s,
+               [&] { return launch_conv1_c1(lips, c->c1_w, c->c1_b, w.act1, Mv, H, W, H1, W1, s); }));
+  RCK(record_tap(c, w, "v_conv0", w.act1, (size_t)Mv * H1 * W1 * 32, s));
+  GemmParams p{};
+  p.A = w.act1; p.W = c->c2_w; p.ldw = 9 * 32; p.bias = c->c2_b; p.C = w.act2; p.ldc = 64;
+  p.M = Mv * H2 * W2; p.N = 64; p.K = 9 * 32; p.amode = AMODE_CONV2D; p.Kt = 32;
+  p.Hin = H1; p.Win = W1; p.Hout = H2; p.Wout = W2; p.act = ACT_RELU;
+  RCK(run_gemm(c, p, s));
+  RCK(record_tap(c, w, "v_conv1", w.act2, (size_t)Mv * H2 * W2 * 64, s));
+  GemmParams p3{};
+  p3.A = w.act2; p3.W = c->c3_w; p3.ldw = 9 * 64; p3.bias = c->c3_b; p3.C = w.act3; p3.ldc = 128;
+  p3.M = Mv * H3 * W3; p3.N = 128; p3.K = 9 * 64; p3.amode = AMODE_CONV2D; p3.Kt = 64;
+  p3.Hin = H2; p3.Win = W2; p3.Hout = H3; p3.Wout = W3; p3.act = ACT_RELU;
+  RCK(run_gemm(c, p3, s));
+  RCK(record_tap(c, w, "v_conv2", w.act3, (size_t)Mv * H3 * W3 * 128, s));
+  RCK(profiled(c, "avgpool_kernel", 1.0 * Mv * H3 * W3 * 128, 4.0 * Mv * 128 * (H3 * W3 + 1), s,
+               [&] { return launch_avgpool(w.act3, w.pool, Mv, H3 * W3, 128, s); }));
+  RCK(record_tap(c, w, "v_pool", w.pool, (size_t)Mv * 128, s));
+  GemmParams pf = linear_params(w.pool, 128, c->fp_w, 128, c->fp_b, w.v_x, d, Mv, d, ACT_NONE);
+  pf.R = c->v_pe; pf.ldr = d; pf.rperiod = N;   // PE indexed by frame position
+  RCK(run_gemm(c, pf, s));
+  for (int i = 0; i < c->Le; ++i) {
+    RCK(encoder_layer(c, c->v_layers[i], w.v_x, w.v_ln, w.v_qkv, w.v_att, w.v_ffn, B, N, s));
+    RCK(record_tap(c, w, ("v_enc" + std::to_string(i)).c_str(), w.v_x, (size_t)Mv * d, s));
+  }
+  RCK(profiled(c, "interp_linear_kernel", 3.0 * B * T * d, 4.0 * B * d * (N + T), s,
+               [&] { return launch_interp_linear(w.v_x, w.v_up, B, N, T, d, s); }));
+  RCK(record_tap(c, w, "v_interp", w.v_up, (size_t)B * T * d, s));
+  return AVSEP_OK;
+}
+
+// K/V projections of the (layer-invariant) visual stream for ALL fusion layers in one GEMM.
+int fusion_kv(avsep_ctx* c, const Workspace& w, const float* visual, int B, int T, hipStream_t s) {
+  if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
+  if (c->Lf == 0) return AVSEP_OK;
+  const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
+  RCK(run_gemm(c, linear_params(visual, d, c->wkv_all, d, c->bkv_all, w.kv_all, nkv, M, nkv, ACT_NONE), s));
+  return AVSEP_OK;
+}
+
+// CrossModalFusion.forward (model.py:145-149) in place on x; final LayerNorm written to w.ln.
+int fusion_layers(avsep_ctx* c, const Workspace& w, float* x, int B, int T, hipStream_t s) {
+  if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
+  const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
+  for (int i = 0; i < c->Lf; ++i) {
+    const FusLayerW& L = c->f_layers[i];
+    RCK(run_layernorm(c, x, L.g1, L.be1, w.ln, M, d, s));
+    RCK(run_gemm(c, linear_params(w.ln, d, L.wq, d, L.bq, w.f_q, d, M, d, ACT_NONE), s));
+    const float* kk = w.kv_all + (size_t)i * 2 * d;
+    RCK(run_attention(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, d, B, T, T, s));
+    GemmParams po = linear_params(w.att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
+    po.R = x; po.ldr = d;
+    RCK(run_gemm(c, po, s));
+    RCK(run_layernorm(c, x, L.g2, L.be2, w.ln, M, d, s));
+    RCK(run_gemm(c, linear_params(w.ln, d, L.w1, d, L.b1, w.ffn, 4 * d, M, 4 * d, ACT_GELU), s));
+    GemmParams p2 = linear_params(w.ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
+    p2.R = x; p2.ldr = d;
+    RCK(run_gemm(c, p2, s));
+    RCK(record_tap(c, w, ("f_layer" + std::to_string(i)).c_str(), x, (size_t)M * d, s));
+  }
+  RCK(run_layernorm(c, x, c->fn_g, c->fn_b, w.ln, M, d, s));
+  RCK(record_tap(c, w, "f_norm", w.ln, (size_t)M * d, s));
+  return AVSEP_OK;
+}
+
+// SeparationDecoder.forward + .separate (model.py:201-220): masks = sigmoid(W2 gelu(W1 x)), output
+// channel n = s*F + f, written as (B,T,S,F); separated = masks * mixed (xt holds mixed^T) in the epilogue.
+int decoder_stage(avsep_ctx* c, const Workspace& w, const float* fused, float* masks, float* sep, int B, int T,
+                  hipStream_t s) {
+  if (!c->ok_decoder) return fail(AVSEP_ENOWEIGHT, "decoder weights are incomplete");
+  const int d = c->d, M = B * T, SF = c->S * c->F;
+  RCK(run_gemm(c, linear_params(fused, d, c->d_w1, d, c->d_b1, w.ffn, 2 * d, M, 2 * d, ACT_GELU), s));
+  GemmParams p = linear_params(w.ffn, 2 * d, c->d_w2, 2 * d, c->d_b2, masks, SF, M, SF, ACT_SIGMOID);
+  if (sep) {
+    p.C2 = sep; p.X = w.xt; p.ldx = c->Fp; p.F = c->F;
+  }
+  RCK(run_gemm(c, p, s));
+  return AVSEP_OK;
+}
+
+int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
+                 size_t ws_bytes, int B, int T, int N, int H, int W, hipStream_t s) {
+  RCK(check_common(c, B, T));
+  if (!mixed || !lips || !masks || !sep || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
+  Workspace w;
+  const size_t need = carve(c, &w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float);
+  if (ws_bytes < need) return fail(AVSEP_ENOMEM, "workspace too small: see avsep_workspace_bytes()");
+  c->taps.clear();
+  c->tap_cursor = 0;
+  // fork: visual encoder (+ the fusion K/V projection that depends only on it) on the side stream
+  HCK(hipEventRecord(c->ev_fork, s));
+  HCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  int rv = visual_branch(c, w, lips, B, N, H, W, T, c->side);
+  if (rv == AVSEP_OK) rv = fusion_kv(c, w, w.v_up, B, T, c->side);
+  // always join, even on error, so a capture in progress is not left forked
+  hipError_t ej = hipEventRecord(c->ev_join, c->side);
+  int ra = audio_branch(c, w, mixed, B, T, s);
+  hipError_t ew = hipStreamWaitEvent(s, c->ev_join, 0);
+  if (rv != AVSEP_OK) return rv;
+  if (ra != AVSEP_OK) return ra;
+  HCK(ej);
+  HCK(ew);
+  RCK(fusion_layers(c, w, w.a_x, B, T, s));
+  RCK(decoder_stage(c, w, w.ln, masks, sep, B, T, s));
+  return AVSEP_OK;
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+int avsep_abi_version(void) { return AVSEP_ABI_VERSION; }
+const char* avsep_last_error(void) { return g_err.c_str(); }
+
+int avsep_create(const avsep_config* cfg, avsep_ctx** out) {
+  if (!cfg || !out) return fail(AVSEP_EINVAL, "null argument");
+  *out = nullptr;
+  if (cfg->freq_bins <= 0 || cfg->d_model <= 0 || cfg->nhead <= 0 || cfg->num_encoder_layers < 0 ||
+      cfg->num_fusion_layers < 0 || cfg->num_speakers <= 0)
+    return fail(AVSEP_EINVAL, "non-positive model dimension");
+  if (cfg->d_model % 32) return fail(AVSEP_EINVAL, "d_model must be a multiple of 32 (K chunks of the fp32 MFMA GEMM)");
+  if (cfg->d_model % cfg->nhead) return fail(AVSEP_EINVAL, "embed_dim must be divisible by num_heads");
+  const int dh = cfg->d_model / cfg->nhead;
+  if ((dh & 3) || dh > 128)
+    return fail(AVSEP_EINVAL, "head dim d_model/nhead must be a multiple of 4 and <= 128");
+  avsep_ctx* c = new (std::nothrow) avsep_ctx();
+  if (!c) return fail(AVSEP_ENOMEM, "host allocation failed");
+  c->cfg = *cfg;
+  c->F = cfg->freq_bins; c->Fp = (int)align_up(cfg->freq_bins, 32); c->d = cfg->d_model; c->h = cfg->nhead;
+  c->dh = dh; c->Le = cfg->num_encoder_layers; c->Lf = cfg->num_fusion_layers; c->S = cfg->num_speakers;
+  size_t off = 0;
+  layout_arena(c, [&](size_t n) { off += align_up(n ? n : 1, 64); return (float*)nullptr; });
+  c->arena_floats = off;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->arena), off * sizeof(float));
+  if (e != hipSuccess) { delete c; return fail_hip(e, "hipMalloc(weight arena)"); }
+  off = 0;
+  layout_arena(c, [&](size_t n) { float* p = c->arena + off; off += align_up(n ? n : 1, 64); return p; });
+  bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_gin, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_gout, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { avsep_destroy(c); return fail(AVSEP_EHIP, "stream/event creation failed"); }
+  *out = c;
+  return AVSEP_OK;
+}
+
+void avsep_destroy(avsep_ctx* c) {
+  if (!c) return;
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+  for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_gin) (void)hipEventDestroy(c->ev_gin);
+  if (c->ev_gout) (void)hipEventDestroy(c->ev_gout);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->gstream) (void)hipStreamDestroy(c->gstream);
+  if (c->arena) (void)hipFree(c->arena);
+  delete c;
+}
+
+int avsep_profile_begin(avsep_ctx* c) {
+  if (!c) return fail(AVSEP_EINVAL, "null context");
+  for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  c->prof.clear();
+  c->prof_on = true;
+  return AVSEP_OK;
+}
+
+// Stops profiling, waits for the recorded events and writes one JSON array, aggregated per kernel name in
+// first-launch order: [{"name":..,"calls":n,"ms":total,"flops":total,"bytes":total}, ...].
+// Returns the number of bytes written (excluding the NUL) or a negative error.
+int64_t avsep_profile_end(avsep_ctx* c, char* json, size_t cap) {
+  if (!c || !json || cap < 3) return fail(AVSEP_EINVAL, "bad argument");
+  c->prof_on = false;
+  struct Agg { std::string name; long calls; double ms, flops, bytes; };
+  std::vector<Agg> agg;
+  int rc = AVSEP_OK;
+  for (auto& r : c->prof) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(r.e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
+    if (e != hipSuccess && rc == AVSEP_OK) rc = fail_hip(e, "hipEventElapsedTime");
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    Agg* a = nullptr;
+    for (auto& x : agg) if (x.name == r.name) a = &x;
+    if (!a) { agg.push_back({r.name, 0, 0, 0, 0}); a = &agg.back(); }
+    a->calls++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
+  }
+  c->prof.clear();
+  if (rc != AVSEP_OK) return rc;
+  std::string out = "[";
+  char line[384];
+  for (size_t i = 0; i < agg.size(); ++i) {
+    snprintf(line, sizeof line, "%s{\"name\":\"%s\",\"calls\":%ld,\"ms\":%.6f,\"flops\":%.0f,\"bytes\":%.0f}",
+             i ? "," : "", agg[i].name.c_str(), agg[i].calls, agg[i].ms, agg[i].flops, agg[i].bytes);
+    out += line;
+  }
+  out += "]";
+  if (out.size() + 1 > cap) return fail(AVSEP_ENOMEM, "profile buffer too small");
+  memcpy(json, out.c_str(), out.size() + 1);
+  return (int64_t)out.size();
+}
+
+int avsep_set_debug_taps(avsep_ctx* c, int on) {
+  if (!c) return fail(AVSEP_EINVAL, "null context");
+  c->keep_taps = on != 0;
+  return AVSEP_OK;
+}
+
+int avsep_set_weight(avsep_ctx* c, const char* key, const float* dev_ptr, const int64_t* shape, int ndim) {
+  if (!c || !key || !dev_ptr || ndim < 0 || ndim > 4 || (ndim > 0 && !shape)) return fail(AVSEP_EINVAL, "bad argument");
+  RawW w;
+  w.ptr = dev_ptr;
+  w.shape.assign(shape, shape + ndim);
+  c->raw[key] = std::move(w);
+  c->finalized = false;
+  return AVSEP_OK;
+}
+
+int avsep_finalize_weights(avsep_ctx* c, void* stream) {
+  if (!c) return fail(AVSEP_EINVAL, "null context");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int d = c->d, F = c->F, S = c->S;
+  // replayed graphs bake in nothing about weights (the arena address is stable), so they stay valid
+  {  // ---- audio encoder
+    Packer P{c, s};
+    if (const float* w = P.need("audio_encoder.input_proj.0.weight", {d, F, 3}))
+      P.keep(launch_pack_conv1d(w, c->a_w1, d, F, c->Fp, s));
+    P.copy("audio_encoder.input_proj.0.bias", c->a_b1, d);
+    if (const float* w = P.need("audio_encoder.input_proj.2.weight", {d, d, 3}))
+      P.keep(launch_pack_conv1d(w, c->a_w2, d, d, d, s));
+    P.copy("audio_encoder.input_proj.2.bias", c->a_b2, d);
+    RCK(pack_pe(P, "audio_encoder.pos_enc.pe", c->a_pe, &c->pe_len_a));
+    pack_encoder(P, "audio_encoder.", c->a_layers);
+    HCK(P.err);
+    c->ok_audio = !P.missing;
+  }
+  {  // ---- visual encoder
+    Packer P{c, s};
+    const int chans[4] = {1, 32, 64, 128};
+    float* wp[3] = {c->c1_w, c->c2_w, c->c3_w};
+    float* bp[3] = {c->c1_b, c->c2_b, c->c3_b};
+    for (int i = 0; i < 3; ++i) {
+      const std::string cv = "visual_encoder.conv." + std::to_string(3 * i) + ".";
+      const std::string bn = "visual_encoder.conv." + std::to_string(3 * i + 1) + ".";
+      const int co = chans[i + 1], ci = chans[i];
+      const float* w = P.need(cv + "weight", {co, ci, 3, 3});
+      const float* b = P.need(cv + "bias", {co});
+      const float* g = P.need(bn + "weight", {co});
+      const float* be = P.need(bn + "bias", {co});
+      const float* mu = P.need(bn + "running_mean", {co});
+      const float* var = P.need(bn + "running_var", {co});
+      if (w && b && g && be && mu && var)
+        P.keep(launch_pack_conv2d_bn(w, b, g, be, mu, var, wp[i], bp[i], co, ci, 1e-5f, s));
+    }
+    P.rows("visual_encoder.frame_proj.weight", c->fp_w, d, 128);
+    P.copy("visual_encoder.frame_proj.bias", c->fp_b, d);
+    RCK(pack_pe(P, "visual_encoder.pos_enc.pe", c->v_pe, &c->pe_len_v));
+    pack_encoder(P, "visual_encoder.", c->v_layers);
+    HCK(P.err);
+    c->ok_visual = !P.missing;
+  }
+  {  // ---- fusion
+    Packer P{c, s};
+    const float qs = 1.0f / std::sqrt((float)c->dh);
+    for (int i = 0; i < c->Lf; ++i) {
+      const std::string p = "fusion.layers." + std::to_string(i) + ".";
+      FusLayerW& L = c->f_layers[i];
+      if (const float* w = P.need(p + "cross_attn.in_proj_weight", {3 * d, d})) {
+        P.keep(launch_pack_rows(w, L.wq, d, d, d, qs, d, s));                                  // Wq * 1/sqrt(dh)
+        P.keep(launch_pack_rows(w + (size_t)d * d, c->wkv_all + (size_t)i * 2 * d * d, 2 * d, d, d, 1.0f, 0, s));
+      }
+      if (const float* b = P.need(p + "cross_attn.in_proj_bias", {3 * d})) {
+        P.keep(launch_scale_copy(b, L.bq, d, qs, d, s));
+        P.keep(launch_scale_copy(b + d, c->bkv_all + (size_t)i * 2 * d, 2 * d, 1.0f, 0, s));
+      }
+      P.rows(p + "cross_attn.out_proj.weight", L.wo, d, d);
+      P.copy(p + "cross_attn.out_proj.bias", L.bo, d);
+      P.rows(p + "ff.0.weight", L.w1, 4 * d, d);
+      P.copy(p + "ff.0.bias", L.b1, 4 * d);
+      P.rows(p + "ff.3.weight", L.w2, d, 4 * d);
+      P.copy(p + "ff.3.bias", L.b2, d);
+      P.copy(p + "norm1.weight", L.g1, d);
+      P.copy(p + "norm1.bias", L.be1, d);
+      P.copy(p + "norm2.weight", L.g2, d);
+      P.copy(p + "norm2.bias", L.be2, d);
+    }
+    P.copy("fusion.norm.weight", c->fn_g, d);
+    P.copy("fusion.norm.bias", c->fn_b, d);
+    HCK(P.err);
+    c->ok_fusion = !P.missing;
+  }
+  {  // ---- decoder
+    Packer P{c, s};
+    P.rows("decoder.decoder.0.weight", c->d_w1, 2 * d, d);
+    P.copy("decoder.decoder.0.bias", c->d_b1, 2 * d);
+    P.rows("decoder.decoder.3.weight", c->d_w2, (int64_t)S * F, 2 * d);
+    P.copy("decoder.decoder.3.bias", c->d_b2, (int64_t)S * F);
+    HCK(P.err);
+    c->ok_decoder = !P.missing;
+  }
+  if (!(c->ok_audio || c->ok_visual || c->ok_fusion || c->ok_decoder))
+    return fail(AVSEP_ENOWEIGHT, "no stage has a complete set of weights");
+  c->finalized = true;
+  return AVSEP_OK;
+}
+
+size_t avsep_workspace_bytes(const avsep_ctx* c, int B, int T, int N, int H, int W) {
+  if (!c || B <= 0 || T <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+  return carve(c, nullptr, nullptr, B, T, N, H, W) * sizeof(float);
+}
+
+int avsep_forward(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
+                  size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) {
+  return forward_impl(c, mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, reinterpret_cast<hipStream_t>(stream));
+}
+
+int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
+                        size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) {
+  RCK(check_common(c, B, T));
+  if (c->keep_taps || c->prof_on) return fail(AVSEP_EINVAL, "debug taps / profiler are not available under graph replay");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GraphEntry* hit = nullptr;
+  for (auto& g : c->graphs)
+    if (g.mixed == mixed && g.lips == lips && g.masks == masks && g.sep == sep && g.ws == ws &&
+        g.ws_bytes == ws_bytes && g.B == B && g.T == T && g.N == N && g.H == H && g.W == W)
+      hit = &g;
+  if (!hit) {
+    // capture on the context's own stream (the caller's may be the legacy stream, which cannot capture)
+    hipGraph_t graph = nullptr;
+    HCK(hipStreamBeginCapture(c->gstream, hipStreamCaptureModeThreadLocal));
+    int r = forward_impl(c, mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, c->gstream);
+    hipError_t e = hipStreamEndCapture(c->gstream, &graph);
+    if (r != AVSEP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+    HCK(e);
+    GraphEntry g{mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, nullptr};
+    e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HCK(e);
+    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    c->graphs.push_back(g);
+    hit = &c->graphs.back();
+  }
+  HCK(hipEventRecord(c->ev_gin, s));
+  HCK(hipStreamWaitEvent(c->gstream, c->ev_gin, 0));
+  HCK(hipGraphLaunch(hit->exec, c->gstream));
+  HCK(hipEventRecord(c->ev_gout, c->gstream));
+  HCK(hipStreamWaitEvent(s, c->ev_gout, 0));
+  return AVSEP_OK;
+}
+
+int avsep_audio_encoder(avsep_ctx* c, const float* mixed, float* out, void* ws, size_t ws_bytes, int B, int T,
+                        void* stream) {
+  RCK(check_common(c, B, T));
+  if (!mixed || !out || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Workspace w;
+  if (ws_bytes < carve(c, &w, reinterpret_cast<float*>(ws), B, T, 1, 1, 1) * sizeof(float))
+    return fail(AVSEP_ENOMEM, "workspace too small");
+  c->taps.clear(); c->tap_cursor = 0;
+  RCK(audio_branch(c, w, mixed, B, T, s));
+  HCK(hipMemcpyAsync(out, w.a_x, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return AVSEP_OK;
+}
+
+int avsep_visual_encoder(avsep_ctx* c, const float* lips, float* out, void* ws, size_t ws_bytes, int B, int N, int H,
+                         int W, int T, void* stream) {
+  RCK(check_common(c, B, T));
+  if (!lips || !out || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Workspace w;
+  if (ws_bytes < carve(c, &w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float))
+    return fail(AVSEP_ENOMEM, "workspace too small");
+  c->taps.clear(); c->tap_cursor = 0;
+  RCK(visual_branch(c, w, lips, B, N, H, W, T, s));
+  HCK(hipMemcpyAsync(out, w.v_up, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return AVSEP_OK;
+}
+
+int avsep_fusion(avsep_ctx* c, const float* audio, const float* visual, float* out, void* ws, size_t ws_bytes, int B,
+                 int T, void* stream) {
+  RCK(check_common(c, B, T));
+  if (!audio || !visual || !out || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Workspace w;
+  if (ws_bytes < carve(c, &w, reinterpret_cast<float*>(ws), B, T, 1, 1, 1) * sizeof(float))
+    return fail(AVSEP_ENOMEM, "workspace too small");
+  c->taps.clear(); c->tap_cursor = 0;
+  HCK(hipMemcpyAsync(w.a_x, audio, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RCK(fusion_kv(c, w, visual, B, T, s));
+  RCK(fusion_layers(c, w, w.a_x, B, T, s));
+  HCK(hipMemcpyAsync(out, w.ln, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return AVSEP_OK;
+}
+
+int avsep_decoder(avsep_ctx* c, const float* fused, const float* mixed, float* masks, float* sep, void* ws,
+                  size_t ws_bytes, int B, int T, void* stream) {
+  RCK(check_common(c, B, T));
+  if (!fused || !masks || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
+  if ((mixed == nullptr) != (sep == nullptr)) return fail(AVSEP_EINVAL, "mixed and separated must be given together");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Workspace w;
+  if (ws_bytes < carve(c, &w, reinterpret_cast<float*>(ws), B, T, 1, 1, 1) * sizeof(float))
+    return fail(AVSEP_ENOMEM, "workspace too small");
+  if (mixed) HCK(launch_transpose_pad(mixed, w.xt, B, c->F, T, c->Fp, s));
+  RCK(decoder_stage(c, w, fused, masks, sep, B, T, s));
+  return AVSEP_OK;
+}
+
+int64_t avsep_read_tap(avsep_ctx* c, const char* name, float* dst, int64_t max_floats, void* ws, int B, int T,
+                          int N, int H, int W, void* stream) {
+  if (!c || !name || !dst || !ws) return fail(AVSEP_EINVAL, "bad argument");
+  if (!c->keep_taps) return fail(AVSEP_ESTATE, "debug taps are off (avsep_set_debug_taps)");
+  Workspace w;
+  carve(c, &w, reinterpret_cast<float*>(ws), B, T, N, H, W);
+  for (const auto& t : c->taps)
+    if (t.name == name) {
+      if ((int64_t)t.n > max_floats) return fail(AVSEP_ENOMEM, "destination too small for tap");
+      hipError_t e = hipMemcpyAsync(dst, w.taps + t.off, t.n * sizeof(float), hipMemcpyDeviceToDevice,
+                                    reinterpret_cast<hipStream_t>(stream));
+      if (e != hipSuccess) return fail_hip(e, "hipMemcpyAsync(tap)");
+      return (int64_t)t.n;
+    }
+  return fail(AVSEP_EINVAL, std::string("unknown tap: ") + name);
+}
+
+// ---------------------------------------------------------------------------------- single-kernel entry points
+int avsep_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int N,
+                    int K, int act, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32) return fail(AVSEP_EINVAL, "K must be a multiple of 32");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  GemmParams p = linear_params(x, K, w, K, bias, y, N, M, N, act);
+  if (residual) { p.R = residual; p.ldr = N; }
+  HCK(launch_gemm(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps,
+                       void* stream) {
+  if (!x || !gamma || !beta || !y) return fail(AVSEP_EINVAL, "null pointer");
+  HCK(launch_layernorm(x, gamma, beta, y, M, d, eps, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
+                       int B, int nhead, int dh, int Lq, int Lk, void* stream) {
+  if (!q || !k || !v || !out) return fail(AVSEP_EINVAL, "null pointer");
+  HCK(launch_attention(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream) {
+  if (!x || !y || B <= 0 || N <= 0 || T <= 0 || d <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  HCK(launch_interp_linear(x, y, B, N, T, d, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// kernels.h -- internal launcher declarations shared by the HIP translation units of libavsep_hip.so.
+// Everything here is gfx950 (CDNA4) only: 64-wide wavefronts, v_mfma_f32_16x16x4_f32, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
+enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2 };
+
+// C[M,N] = epilogue( A'[M,K] * W[N,K]^T ), fp32 in / fp32 accumulate on the matrix cores.
+// A' is A itself (PLAIN), a 3-tap shifted view of a (B,T,Kt) sequence tensor (TAPS3: Conv1d k=3 p=1 as one
+// GEMM with K = 3*Kt, model.py:38,40), or an on-the-fly im2col gather of a channels-last image tensor
+// (CONV2D: Conv2d k=3 s=2 p=1, K = 9*Cin, model.py:85,88).
+struct GemmParams {
+  const float* A;
+  const float* W;      // [N][K] row-major, K contiguous (== nn.Linear.weight layout), K % 32 == 0
+  const float* bias;   // [N] or nullptr
+  float* C;            // [M][ldc]
+  int M, N, K;
+  int lda, ldw, ldc;
+  int amode;
+  int T;               // TAPS3: sequence length (rows per batch element)
+  int Kt;              // TAPS3: per-tap K;  CONV2D: Cin
+  int Hin, Win, Hout, Wout;  // CONV2D
+  int act;             // ACT_*
+  const float* R;      // residual / positional-encoding rows, or nullptr:  C += R[(m % rperiod)][n]
+  int ldr, rperiod;    // rperiod <= 0: plain residual (row m)
+  float* C2;           // mask mode (SeparationDecoder.separate, model.py:220): C2 = C * X[m][n % F]
+  const float* X;
+  int ldx, F;
+};
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+const char* gemm_instance_name(const GemmParams& p);   // template instance launch_gemm() will pick
+
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int d, float eps,
+                            hipStream_t s);
+hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                            float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s);
+// (B,F,T) -> (B,T,Fp) zero padded
+hipError_t launch_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, hipStream_t s);
+// first visual conv (Cin=1) + folded BN + ReLU: frames (M,H,W) -> act (M,Ho,Wo,32) channels-last
+hipError_t launch_conv1_c1(const float* frames, const float* w9x32, const float* bias32, float* out, int M,
+                           int H, int W, int Ho, int Wo, hipStream_t s);
+// mean over P positions: x (M,P,C) -> y (M,C)
+hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s);
+hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);
+
+// weight packing (device -> device)
+hipError_t launch_pack_rows(const float* src, float* dst, int rows, int K, int Kp, float scale, int scale_rows,
+                            hipStream_t s);  // dst[r][k] = src[r][k] * (r < scale_rows ? scale : 1), zero pad to Kp
+hipError_t launch_pack_conv1d(const float* w, float* dst, int Co, int Ci, int Cip, hipStream_t s);  // (Co,Ci,3)->[Co][3][Cip]
+// (Co,Ci,3,3) + BN(gamma,beta,mean,var) -> wp [Co][9][Ci] (or [9][Co] when Ci==1), bp [Co]
+hipError_t launch_pack_conv2d_bn(const float* w, const float* b, const float* gamma, const float* beta,
+                                 const float* mean, const float* var, float* wp, float* bp, int Co, int Ci,
+                                 float eps, hipStream_t s);
+hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, int scale_n, hipStream_t s);

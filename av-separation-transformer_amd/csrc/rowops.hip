@@ -1,0 +1,268 @@
+// rowops.hip -- the HBM-bound kernels of the forward path (wavefront reductions and layout passes) and
+// the one-off weight packers.  None of these has arithmetic intensity worth the matrix cores; they are
+// written for coalesced 16-byte accesses along the contiguous axis and 64-lane wavefront reductions.
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// nn.LayerNorm (model.py:143,162-163 and the norm1/norm2 of TransformerEncoderLayer): one wavefront per
+// row, the row held in registers (VEC float4 per lane), two-pass mean / biased variance like ATen.
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gam,
+                                                        const float* __restrict__ bet, float* __restrict__ y,
+                                                        int M, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * d;
+  f32x4 v[VEC];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int col = (lane + 64 * i) * 4;
+    v[i] = col < d ? *reinterpret_cast<const f32x4*>(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float sq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int col = (lane + 64 * i) * 4;
+    if (col < d) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c = v[i][e] - mean;
+        sq += c * c;
+      }
+    }
+  }
+  const float var = wave_sum(sq) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  float* yr = y + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int col = (lane + 64 * i) * 4;
+    if (col < d) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam + col);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bet + col);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+      *reinterpret_cast<f32x4*>(yr + col) = o;
+    }
+  }
+}
+
+// mixed_spec (B,F,T) -> (B,T,Fp): makes the frequency axis contiguous so Conv1d becomes a K-contiguous
+// GEMM and the mask epilogue reads mixed along n; 32x32 LDS tile transpose, both sides coalesced.
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int F, int T, int Fp) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* xb = x + (size_t)b * F * T;
+  float* yb = y + (size_t)b * T * Fp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = f0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (f < F && t < T) ? xb[(size_t)f * T + t] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, f = f0 + tx;
+    if (t < T && f < Fp) yb[(size_t)t * Fp + f] = tile[tx][ty + 8 * i];
+  }
+}
+
+// First visual conv: Conv2d(1->32,k3,s2,p1)+BatchNorm2d(eval)+ReLU (model.py:82-84) with BN folded into
+// w/b by the packer.  Cin = 1 means 9 MACs per output: VALU work, output written channels-last
+// (M,Ho,Wo,32) so the next conv's implicit-GEMM gather reads 128-byte channel rows.
+__global__ __launch_bounds__(256) void conv1_c1_kernel(const float* __restrict__ frames, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       int total_px, int H, int W, int Ho, int Wo) {
+  const int cq = threadIdx.x & 7;             // channel quad: channels 4cq..4cq+3
+  const int px = blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (px >= total_px) return;
+  const int hw = Ho * Wo;
+  const int img = px / hw;
+  const int rem = px - img * hw;
+  const int y = rem / Wo, x = rem - y * Wo;
+  const float* f = frames + (size_t)img * H * W;
+  f32x4 a = *reinterpret_cast<const f32x4*>(bias + 4 * cq);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * y - 1 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * x - 1 + kx;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float p = ok ? f[iy * W + ix] : 0.0f;
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + (ky * 3 + kx) * 32 + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = fmaf(p, w4[e], a[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.0f);
+  *reinterpret_cast<f32x4*>(out + (size_t)px * 32 + 4 * cq) = a;
+}
+
+// AdaptiveAvgPool2d(1) (model.py:91): x (M,P,C) channels-last -> y (M,C)
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int M,
+                                                      int P, int C) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int cq = C >> 2;
+  if (idx >= M * cq) return;
+  const int m = idx / cq, c4 = idx - m * cq;
+  const float* src = x + (size_t)m * P * C + 4 * c4;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < P; ++p) s += *reinterpret_cast<const f32x4*>(src + (size_t)p * C);
+  const float inv = 1.0f / (float)P;
+  *reinterpret_cast<f32x4*>(y + (size_t)m * C + 4 * c4) = s * inv;
+}
+
+// F.interpolate(mode='linear', align_corners=False) along time (model.py:114-116); index arithmetic in
+// fp32 exactly as ATen's area_pixel_compute_source_index.
+__global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int B, int N, int T, int d) {
+  const int dq = d >> 2;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)B * T * dq) return;
+  const int c4 = (int)(idx % dq);
+  const size_t bt = idx / dq;
+  const int t = (int)(bt % T);
+  const int b = (int)(bt / T);
+  const float scale = (float)N / (float)T;
+  float src = scale * ((float)t + 0.5f) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  int i0 = (int)src;
+  i0 = i0 < N - 1 ? i0 : N - 1;
+  const int i1 = i0 + 1 < N ? i0 + 1 : N - 1;
+  const float w1 = src - (float)i0;
+  const float w0 = 1.0f - w1;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(x + ((size_t)b * N + i0) * d + 4 * c4);
+  const f32x4 c = *reinterpret_cast<const f32x4*>(x + ((size_t)b * N + i1) * d + 4 * c4);
+  *reinterpret_cast<f32x4*>(y + bt * d + 4 * c4) = w0 * a + w1 * c;
+}
+
+// ------------------------------------------------------------------------------------ weight packers
+__global__ void pack_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int K, int Kp,
+                                 float scale, int scale_rows) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)rows * Kp) return;
+  const int r = (int)(idx / Kp), k = (int)(idx - (size_t)r * Kp);
+  float v = k < K ? src[(size_t)r * K + k] : 0.0f;
+  if (r < scale_rows) v *= scale;
+  dst[idx] = v;
+}
+
+__global__ void pack_conv1d_kernel(const float* __restrict__ w, float* __restrict__ dst, int Co, int Ci, int Cip) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Co * 3 * Cip) return;
+  const int ci = (int)(idx % Cip);
+  const int tap = (int)((idx / Cip) % 3);
+  const int co = (int)(idx / ((size_t)3 * Cip));
+  dst[idx] = ci < Ci ? w[((size_t)co * Ci + ci) * 3 + tap] : 0.0f;
+}
+
+// BN(eval) folding: y = (conv(x)+b - mean) * gamma / sqrt(var+eps) + beta  (model.py:82-90)
+__global__ void pack_conv2d_bn_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                      float* __restrict__ wp, float* __restrict__ bp, int Co, int Ci, float eps) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Co * 9 * Ci) return;
+  const int ci = idx % Ci;
+  const int tap = (idx / Ci) % 9;
+  const int co = idx / (9 * Ci);
+  const float sc = gamma[co] / sqrtf(var[co] + eps);
+  const float v = w[((size_t)co * Ci + ci) * 9 + tap] * sc;
+  if (Ci == 1) wp[tap * Co + co] = v;            // [9][Co] for the VALU kernel
+  else wp[((size_t)co * 9 + tap) * Ci + ci] = v;  // [Co][9][Ci] for the implicit GEMM
+  if (ci == 0 && tap == 0) bp[co] = (b[co] - mean[co]) * sc + beta[co];
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float scale,
+                                  int scale_n) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < n) dst[idx] = idx < scale_n ? src[idx] * scale : src[idx];
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int d, float eps,
+                            hipStream_t s) {
+  if (M <= 0 || d <= 0 || (d & 3) || d > 2048) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+  const int vec = (d + 255) / 256;
+  if (vec <= 1) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, x, g, b, y, M, d, eps);
+  else if (vec <= 2) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, s, x, g, b, y, M, d, eps);
+  else if (vec <= 4) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, g, b, y, M, d, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, g, b, y, M, d, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, hipStream_t s) {
+  const dim3 grid((T + 31) / 32, (Fp + 31) / 32, B), block(256);
+  hipLaunchKernelGGL(transpose_pad_kernel, grid, block, 0, s, x, y, F, T, Fp);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv1_c1(const float* frames, const float* w9x32, const float* bias32, float* out, int M, int H,
+                           int W, int Ho, int Wo, hipStream_t s) {
+  const long total = (long)M * Ho * Wo;
+  if (total <= 0 || total > 0x7fffffffL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv1_c1_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, frames, w9x32, bias32,
+                     out, (int)total, H, W, Ho, Wo);
+  return hipGetLastError();
+}
+
+hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s) {
+  if (C & 3) return hipErrorInvalidValue;
+  const int n = M * (C / 4);
+  hipLaunchKernelGGL(avgpool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, M, P, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s) {
+  if (d & 3) return hipErrorInvalidValue;
+  const size_t n = (size_t)B * T * (d / 4);
+  hipLaunchKernelGGL(interp_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, B, N, T, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_rows(const float* src, float* dst, int rows, int K, int Kp, float scale, int scale_rows,
+                            hipStream_t s) {
+  const size_t n = (size_t)rows * Kp;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, K, Kp,
+                     scale, scale_rows);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_conv1d(const float* w, float* dst, int Co, int Ci, int Cip, hipStream_t s) {
+  const size_t n = (size_t)Co * 3 * Cip;
+  hipLaunchKernelGGL(pack_conv1d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, dst, Co, Ci, Cip);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_conv2d_bn(const float* w, const float* b, const float* gamma, const float* beta,
+                                 const float* mean, const float* var, float* wp, float* bp, int Co, int Ci,
+                                 float eps, hipStream_t s) {
+  const int n = Co * 9 * Ci;
+  hipLaunchKernelGGL(pack_conv2d_bn_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, b, gamma, beta, mean, var,
+                     wp, bp, Co, Ci, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, int scale_n, hipStream_t s) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, scale, scale_n);
+  return hipGetLastError();
+}

@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native AVSeparationTransformer forward path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): SyntheticAVDataset 2-speaker clips, 1 s @ 8 kHz (F=257, T=63,
+N=50 lip frames of 32x32), d_model=256, nhead=4, 2 encoder + 2 fusion layers, batch 32 PER GPU, forward
+only, fp32.  A "step" is one forward over one resident batch: inputs are in HBM before the timed region,
+outputs stay in HBM.  Clips are independent in eval mode, so N GPUs = N independent
+shards of the clip stream, no data-path collective; scaling is weak.
+
+One JSON line on rank 0:
+  value          whole-job clips/s (all ranks' clips / max-over-ranks wall time of the K timed steps)
+  roofline       dominant kernel of the path, priced live with HIP events on its own stream
+                 (avsep_profile_begin/end, include/avsep.h) against the fp32 matrix peak
+  cpu_baseline   the reference's CPU path (oracle/torch_cpu.py port, bit-identical to the reference here)
+                 timed on this box's host cores, rank 0, N=1 only, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "av-separation-transformer_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (spec)
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: model kwargs, dataset kwargs, per-GPU batch          
+    "cfg2": dict(model=dict(freq_bins=257, d_model=256, nhead=4, num_encoder_layers=2, num_fusion_layers=2,
+                            num_speakers=2),
+                 data=dict(sample_rate=8000, duration=1.0, num_frames=25, frame_h=32, frame_w=32,
+                           speaker_freqs=(220.0, 440.0)), batch=32),
+    "cfg3": dict(model=dict(freq_bins=257, d_model=512, nhead=8, num_encoder_layers=6, num_fusion_layers=4,
+                            num_speakers=2),
+                 data=dict(sample_rate=16000, duration=2.0, num_frames=25, frame_h=32, frame_w=32,
+                           speaker_freqs=(220.0, 440.0)), batch=64),
+    "cfg5": dict(model=dict(freq_bins=257, d_model=512, nhead=8, num_encoder_layers=6, num_fusion_layers=8,
+                            num_speakers=2),
+                 data=dict(sample_rate=16000, duration=4.0, num_frames=25, frame_h=48, frame_w=48,
+                           speaker_freqs=(220.0, 440.0)), batch=32),
+}
+
+
+def flops_per_clip(F, T, N, H, W, d, Le, Lf, S):
+    """Algorithmic forward FLOPs per clip (1 MAC = 2 FLOP, elementwise work excluded)."""
+    def layer(L):
+        return 24 * L * d * d + 4 * L * L * d
+    co = lambda x: (x - 1) // 2 + 1  # noqa: E731
+    h1, w1 = co(H), co(W)
+    h2, w2 = co(h1), co(w1)
+    h3, w3 = co(h2), co(w2)
+    conv = 2 * N * (h1 * w1 * 32 * 9 + h2 * w2 * 64 * 32 * 9 + h3 * w3 * 128 * 64 * 9) + 2 * N * 128 * d
+    return (2 * T * F * d * 3 + 2 * T * d * d * 3 + Le * layer(T) + conv + Le * layer(N) + Lf * layer(T)
+            + 2 * T * d * 2 * d + 2 * T * 2 * d * F * S)
+
+
+def shard_range(rank, world, batch):
+    """Clip indices of this rank: shard r owns clips [r*batch, (r+1)*batch) of the synthetic stream."""
+    return range(rank * batch, (rank + 1) * batch)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import av_separation as av
+    wl = WORKLOADS[a.workload]
+    B = a.batch or wl["batch"]
+    mk, dk = wl["model"], wl["data"]
+    torch.manual_seed(0)                       # same random-init weights on every rank (replicated model)
+    model = av.AVSeparationTransformer(dropout=0.0, **mk).to(dev).eval()
+    ds = av.SyntheticAVDataset(num_samples=world * B, **dk)
+    items = [ds[i] for i in shard_range(rank, world, B)]
+    mixed = torch.stack([it["mixed_spec"] for it in items]).to(dev).contiguous()
+    lips = torch.stack([it["lip_frames"] for it in items]).to(dev).contiguous()
+    _, F, T = mixed.shape
+    _, N, H, W = lips.shape
+    S = mk["num_speakers"]
+    masks = torch.empty(B, T, S, F, device=dev)
+    sep = torch.empty(B, T, S, F, device=dev)
+    graph = not a.no_graph
+
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream), torch.no_grad():
+        for _ in range(max(1, a.warmup)):
+            model.run_static(mixed, lips, masks, sep, graph=graph)
+        stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            model.run_static(mixed, lips, masks, sep, graph=graph)
+        stream.synchronize()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if dist is not None:
+            dist.barrier()
+        elapsed = t1 - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- per-kernel roofline, live: eager forwards with every launch bracketed by HIP events
+        prof_iters = 10
+        model.run_static(mixed, lips, masks, sep, graph=False)
+        stream.synchronize()
+        model.profile_begin()
+        for _ in range(prof_iters):
+            model.run_static(mixed, lips, masks, sep, graph=False)
+        stream.synchronize()
+        kernels = model.profile_end()
+
+    gflop_clip = flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
+    value = world * B * a.steps / elapsed
+    ms_step = elapsed / a.steps * 1e3
+    for k in kernels:
+        k["avg_us"] = k["ms"] / k["calls"] * 1e3
+        k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+    dom = max(kernels, key=lambda k: k["ms"])
+    launches_per_fwd = dom["calls"] / prof_iters
+    roofline = {
+        "bound": "mfma", "kernel": dom["name"],
+        "achieved": round(dom["tflops"], 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(dom["tflops"] / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+        "avg_launch_us": round(dom["avg_us"], 3), "launches_per_step": launches_per_fwd,
+        "algorithmic_gflop_per_launch": round(dom["flops"] / dom["calls"] / 1e9, 4),
+        "share_of_kernel_time": round(dom["ms"] / sum(k["ms"] for k in kernels), 4),
+        # whole path: clips/s x GFLOP/clip vs the fp32 matrix peak of ONE GPU
+        "path_tflops_per_gpu": round(value / world * gflop_clip / 1e3, 3),
+        "path_frac": round(value / world * gflop_clip / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
+    }
+
+    out = {
+        "metric": "separated clips/sec (2-spk, 1s@8kHz, d=256) forward, fp32",
+        "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.workload}: SyntheticAVDataset {S}-speaker, F={F}, T={T}, N={N}, {H}x{W} lips, "
+                               f"d_model={mk['d_model']}, nhead={mk['nhead']}, {mk['num_encoder_layers']}+"
+                               f"{mk['num_fusion_layers']} layers, forward-only",
+                   "batch_per_gpu": B, "global_batch": world * B, "gflop_per_clip": round(gflop_clip, 4),
+                   "launch": "hipGraph replay" if graph else "eager", "parallelism": f"replica x{world} (clip shards)"},
+        "roofline": roofline,
+        "kernels": [{"name": k["name"], "calls_per_step": k["calls"] / prof_iters, "avg_us": round(k["avg_us"], 2),
+                     "tflops": round(k["tflops"], 2), "gbs": round(k["gbs"], 1)} for k in kernels],
+    }
+
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(model, mixed, lips, masks, mk, B, a.cpu_seconds)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(model, mixed, lips, masks_gpu, mk, B, budget_s):
+    """Reference CPU path (port) on this box's host cores + the parity of this run's GPU masks against it."""
+    import numpy as np
+    from oracle import torch_cpu
+    threads = torch.get_num_threads()
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    mx, lp = mixed.cpu(), lips.cpu()
+    torch_cpu.forward(state, mx, lp, mk["nhead"], mk["num_speakers"])        # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 200:
+        t0 = time.perf_counter()
+        ref_sep, ref_masks = torch_cpu.forward(state, mx, lp, mk["nhead"], mk["num_speakers"])
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    got = masks_gpu.permute(0, 2, 3, 1).cpu()
+    return {"value": round(B / med, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} forwards of the same {B}-clip batch, median {med * 1e3:.1f} ms "
+                      f"(torch {torch.__version__} CPU, eval/no_grad/fp32, fused encoder fast path)",
+            "gpu_masks_max_abs_err_vs_cpu": float((got - ref_masks).abs().max())}
+
+
+if __name__ == "__main__":
+    main()

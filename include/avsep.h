@@ -1,0 +1,133 @@
+/*
+ * avsep.h -- C ABI of the MI355X-native AV-Separation-Transformer forward path (libavsep_hip.so).
+ *
+ * This is the drop-in boundary of DESIGN.md §(b): plain pointers and sizes, no torch types.  The
+ * reference has NO native/FFI layer (8 pure-Python files); its "interface" for this
+ * path is the set of torch.nn module calls in /root/reference/src/av_separation/model.py.  Each entry
+ * point below names the reference call it replaces.  The Python host mirror
+ * (av-separation-transformer_amd/av_separation/) binds these with ctypes; INTEGRATION.md shows the stub
+ * a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 unless noted; tensors are dense row-major
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises the host
+ *   - functions return 0 on success, a negative AVSEP_E* code otherwise, and never throw;
+ *     avsep_last_error() gives a thread-local message for the last failure
+ *   - inputs are borrowed and never written; outputs/workspace are caller-owned
+ */
+#ifndef AVSEP_H_
+#define AVSEP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVSEP_ABI_VERSION 1
+
+enum {
+  AVSEP_OK = 0,
+  AVSEP_EINVAL = -1,     /* bad argument / unsupported shape            */
+  AVSEP_ENOWEIGHT = -2,  /* a weight needed by the called stage is unset */
+  AVSEP_EHIP = -3,       /* a HIP runtime call failed                   */
+  AVSEP_ENOMEM = -4,     /* workspace too small / allocation failed     */
+  AVSEP_ESTATE = -5      /* weights not finalized                       */
+};
+
+/* Constructor arguments of AVSeparationTransformer (model.py:240-249).  dropout is not part of the
+ * inference path (identity in eval, model.py:301). */
+typedef struct avsep_config {
+  int32_t freq_bins;           /* F   */
+  int32_t d_model;             /* d   (multiple of 32) */
+  int32_t nhead;               /* h   (d/h a multiple of 4, <= 128) */
+  int32_t num_encoder_layers;  /* Le  */
+  int32_t num_fusion_layers;   /* Lf  */
+  int32_t num_speakers;        /* S   */
+} avsep_config;
+
+typedef struct avsep_ctx avsep_ctx;
+
+int avsep_abi_version(void);
+const char* avsep_last_error(void);
+
+/* One context per device & model.  Allocates (hipMalloc) the packed-weight arena. */
+int avsep_create(const avsep_config* cfg, avsep_ctx** out);
+void avsep_destroy(avsep_ctx* ctx);
+
+/* The weight ABI is the reference's state_dict: `key` is a reference state_dict key
+ * ("audio_encoder.input_proj.0.weight", ...), `dev_ptr` a float32 device tensor of `shape`.
+ * The pointer is only recorded; avsep_finalize_weights() reads all recorded tensors on `stream` and
+ * re-packs them (BN folding model.py:83-89, q-scale folding, conv tap-major layouts, K padding) into
+ * the context's arena, after which the caller's tensors are no longer referenced.
+ * `*.pe` buffers (model.py:297) are accepted; `*.num_batches_tracked` is ignored. */
+int avsep_set_weight(avsep_ctx* ctx, const char* key, const float* dev_ptr, const int64_t* shape, int ndim);
+int avsep_finalize_weights(avsep_ctx* ctx, void* stream);
+
+/* Bytes of scratch avsep_forward()/stage calls need for these sizes (pure host arithmetic). */
+size_t avsep_workspace_bytes(const avsep_ctx* ctx, int B, int T, int N, int H, int W);
+
+/* AVSeparationTransformer.forward (model.py:268-276).
+ *   mixed   (B,F,T)      lips (B,N,H,W)
+ *   masks_btsf, separated_btsf: (B,T,S,F) row-major -- the memory order of the reference's outputs,
+ *   whose logical (B,S,F,T) tensors are views with strides (S*F*T, F, 1, S*F).
+ * The audio and visual encoders run concurrently on `stream` and one context-owned side stream. */
+int avsep_forward(avsep_ctx* ctx, const float* mixed, const float* lips, float* masks_btsf,
+                  float* separated_btsf, void* workspace, size_t workspace_bytes, int B, int T, int N,
+                  int H, int W, void* stream);
+
+/* Same call, replayed from a hipGraph captured on first use for this exact argument tuple
+ * (launch-bound at small batch: DESIGN.md "graphs").  Pointers must stay valid between calls. */
+int avsep_forward_graph(avsep_ctx* ctx, const float* mixed, const float* lips, float* masks_btsf,
+                        float* separated_btsf, void* workspace, size_t workspace_bytes, int B, int T,
+                        int N, int H, int W, void* stream);
+
+/* Stage entry points = the reference's sub-modules, usable stand-alone like in its tests.
+ *   AudioEncoder.forward      model.py:54-60     mixed (B,F,T)            -> out (B,T,d)
+ *   VisualEncoder.forward     model.py:103-117   lips (B,N,H,W), T        -> out (B,T,d)
+ *   CrossModalFusion.forward  model.py:145-149   audio,visual (B,T,d)     -> out (B,T,d)
+ *   SeparationDecoder.forward+separate  model.py:201-220  fused (B,T,d), mixed (B,F,T) (may be NULL,
+ *                             then separated_btsf must be NULL too)        -> masks/separated (B,T,S,F) */
+int avsep_audio_encoder(avsep_ctx* ctx, const float* mixed, float* out, void* ws, size_t ws_bytes, int B,
+                        int T, void* stream);
+int avsep_visual_encoder(avsep_ctx* ctx, const float* lips, float* out, void* ws, size_t ws_bytes, int B,
+                         int N, int H, int W, int T, void* stream);
+int avsep_fusion(avsep_ctx* ctx, const float* audio, const float* visual, float* out, void* ws,
+                 size_t ws_bytes, int B, int T, void* stream);
+int avsep_decoder(avsep_ctx* ctx, const float* fused, const float* mixed, float* masks_btsf,
+                  float* separated_btsf, void* ws, size_t ws_bytes, int B, int T, void* stream);
+
+/* Debug/parity taps.  After avsep_set_debug_taps(ctx, 1), avsep_workspace_bytes() reserves a tap area and
+ * every eager forward/stage call copies its stage-boundary activations there; avsep_read_tap() copies one
+ * of them (names follow oracle/numpy_forward.py: "a_conv1","a_pe","a_enc0","v_conv0".."v_conv2" (channels-
+ * last), "v_pool","v_enc0","v_interp","f_layer0","f_norm") from the same workspace/sizes into `dst`.
+ * Returns the number of floats written, or a negative error.  Not available under graph replay. */
+int avsep_set_debug_taps(avsep_ctx* ctx, int on);
+int64_t avsep_read_tap(avsep_ctx* ctx, const char* name, float* dst, int64_t max_floats, void* workspace, int B,
+                       int T, int N, int H, int W, void* stream);
+
+/* Live per-kernel profile: between avsep_profile_begin() and avsep_profile_end() every kernel the EAGER
+ * entry points launch is bracketed by two HIP events on the stream it runs on.  avsep_profile_end() waits
+ * for them and writes a JSON array aggregated per kernel (template instance) in first-launch order:
+ *   [{"name":"gemm_kernel<64, 32, 0>","calls":n,"ms":total,"flops":algorithmic,"bytes":algorithmic},...]
+ * Returns the JSON length or a negative error.  bench.py prices its roofline from this. */
+int avsep_profile_begin(avsep_ctx* ctx);
+int64_t avsep_profile_end(avsep_ctx* ctx, char* json, size_t capacity);
+
+/* Single-kernel entry points (parity tests drive every kernel through the ABI).
+ * y = act(LN?(x) W^T + b) (+ residual); act: 0 none, 1 relu, 2 gelu(erf), 3 sigmoid. */
+int avsep_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
+                    int N, int K, int act, void* stream);
+int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d,
+                       float eps, void* stream);
+/* softmax(q k^T) v per (batch, head); q is expected pre-scaled.  q (B,Lq,ldq) etc. with head h at
+ * column offset h*dh; out (B,Lq,ldo). */
+int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
+                       int ldo, int B, int nhead, int dh, int Lq, int Lk, void* stream);
+int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVSEP_H_ */

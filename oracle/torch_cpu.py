@@ -1,0 +1,123 @@
+"""CPU baseline: the reference's PyTorch CPU forward restated with torch functional ops.
+
+TEST INFRASTRUCTURE (see oracle/numpy_forward.py header) -- used only by bench.py's `cpu_baseline` leg
+(kind "port") and by tests as a second checker.  /root/reference does not exist on the GPU box, so the
+reference's CPU path (eval, no_grad, fp32, torch's fused encoder fast path) is timed
+there through this restatement, which issues the same ATen kernels the reference's nn.Modules dispatch
+to: mkldnn convolution, addmm, native_layer_norm, native_batch_norm,
+_transformer_encoder_layer_fwd (the eval fast path of nn.TransformerEncoderLayer, torch
+nn/modules/transformer.py:842-921), the explicit bmm/softmax/bmm cross-attention of
+F.multi_head_attention_forward with need_weights=True (torch nn/functional.py:6576-6594), exact-erf GELU,
+upsample_linear1d, sigmoid.  Pinned against tests/golden/ in tests/test_oracle.py.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _to_torch(state, dtype=torch.float32):
+    out = {}
+    for k, v in state.items():
+        t = v if isinstance(v, torch.Tensor) else torch.from_numpy(__import__("numpy").ascontiguousarray(v))
+        out[k] = t.to(dtype) if t.is_floating_point() else t
+    return out
+
+
+def _count(state, prefix):
+    n = 0
+    while f"{prefix}{n}.norm1.weight" in state:
+        n += 1
+    return n
+
+
+def _encoder_layer(x, W, p, nhead, fast):
+    """pre-norm TransformerEncoderLayer, relu, ff=4d  (model.py:48-52)."""
+    if fast and hasattr(torch, "_transformer_encoder_layer_fwd") and x.dtype == torch.float32:
+        return torch._transformer_encoder_layer_fwd(
+            x, x.shape[-1], nhead, W[p + "self_attn.in_proj_weight"], W[p + "self_attn.in_proj_bias"],
+            W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"], False, True, 1e-5,
+            W[p + "norm1.weight"], W[p + "norm1.bias"], W[p + "norm2.weight"], W[p + "norm2.bias"],
+            W[p + "linear1.weight"], W[p + "linear1.bias"], W[p + "linear2.weight"], W[p + "linear2.bias"],
+            None, None)
+    d = x.shape[-1]
+    n = F.layer_norm(x, (d,), W[p + "norm1.weight"], W[p + "norm1.bias"], 1e-5)
+    a = _mha(n, n, W[p + "self_attn.in_proj_weight"], W[p + "self_attn.in_proj_bias"],
+             W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"], nhead)
+    x = x + a
+    n = F.layer_norm(x, (d,), W[p + "norm2.weight"], W[p + "norm2.bias"], 1e-5)
+    return x + F.linear(F.relu(F.linear(n, W[p + "linear1.weight"], W[p + "linear1.bias"])),
+                        W[p + "linear2.weight"], W[p + "linear2.bias"])
+
+
+def _mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead):
+    B, Lq, d = q_in.shape
+    Lk = kv_in.shape[1]
+    dh = d // nhead
+    q = F.linear(q_in, w_in[:d], b_in[:d]) * (1.0 / math.sqrt(dh))
+    k = F.linear(kv_in, w_in[d:2 * d], b_in[d:2 * d])
+    v = F.linear(kv_in, w_in[2 * d:], b_in[2 * d:])
+    q = q.view(B, Lq, nhead, dh).transpose(1, 2).reshape(B * nhead, Lq, dh)
+    k = k.view(B, Lk, nhead, dh).transpose(1, 2).reshape(B * nhead, Lk, dh)
+    v = v.view(B, Lk, nhead, dh).transpose(1, 2).reshape(B * nhead, Lk, dh)
+    p = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
+    o = torch.bmm(p, v).view(B, nhead, Lq, dh).transpose(1, 2).reshape(B, Lq, d)
+    return F.linear(o, w_out, b_out)
+
+
+@torch.no_grad()
+def forward(state, mixed, lips, nhead, num_speakers, fast=True):
+    """(separated, masks), logical (B,S,F,T) like AVSeparationTransformer.forward (model.py:268-276).
+    `state`: reference state_dict (torch tensors or numpy arrays); pe buffers optional."""
+    W = state if all(isinstance(v, torch.Tensor) for v in state.values()) else _to_torch(state, mixed.dtype)
+    B, Fq, T = mixed.shape
+    # ---- AudioEncoder (model.py:54-60)
+    h = F.relu(F.conv1d(mixed, W["audio_encoder.input_proj.0.weight"], W["audio_encoder.input_proj.0.bias"], padding=1))
+    h = F.relu(F.conv1d(h, W["audio_encoder.input_proj.2.weight"], W["audio_encoder.input_proj.2.bias"], padding=1))
+    a = h.permute(0, 2, 1)
+    d = a.shape[-1]
+    a = a + _pe(W, "audio_encoder.pos_enc.pe", T, d, a.dtype)
+    for i in range(_count(W, "audio_encoder.transformer.layers.")):
+        a = _encoder_layer(a, W, f"audio_encoder.transformer.layers.{i}.", nhead, fast)
+    # ---- VisualEncoder (model.py:103-117)
+    _, N, H, Wd = lips.shape
+    x = lips.reshape(B * N, 1, H, Wd)
+    for ci, bi in ((0, 1), (3, 4), (6, 7)):
+        c, b = f"visual_encoder.conv.{ci}.", f"visual_encoder.conv.{bi}."
+        x = F.conv2d(x, W[c + "weight"], W[c + "bias"], stride=2, padding=1)
+        x = F.batch_norm(x, W[b + "running_mean"], W[b + "running_var"], W[b + "weight"], W[b + "bias"], False, 0.1, 1e-5)
+        x = F.relu(x)
+    v = F.adaptive_avg_pool2d(x, 1).flatten(1)
+    v = F.linear(v, W["visual_encoder.frame_proj.weight"], W["visual_encoder.frame_proj.bias"]).view(B, N, d)
+    v = v + _pe(W, "visual_encoder.pos_enc.pe", N, d, v.dtype)
+    for i in range(_count(W, "visual_encoder.transformer.layers.")):
+        v = _encoder_layer(v, W, f"visual_encoder.transformer.layers.{i}.", nhead, fast)
+    v = F.interpolate(v.permute(0, 2, 1), size=T, mode="linear", align_corners=False).permute(0, 2, 1)
+    # ---- CrossModalFusion (model.py:145-173)
+    for i in range(_count(W, "fusion.layers.")):
+        p = f"fusion.layers.{i}."
+        n = F.layer_norm(a, (d,), W[p + "norm1.weight"], W[p + "norm1.bias"], 1e-5)
+        a = a + _mha(n, v, W[p + "cross_attn.in_proj_weight"], W[p + "cross_attn.in_proj_bias"],
+                     W[p + "cross_attn.out_proj.weight"], W[p + "cross_attn.out_proj.bias"], nhead)
+        n = F.layer_norm(a, (d,), W[p + "norm2.weight"], W[p + "norm2.bias"], 1e-5)
+        a = a + F.linear(F.gelu(F.linear(n, W[p + "ff.0.weight"], W[p + "ff.0.bias"])),
+                         W[p + "ff.3.weight"], W[p + "ff.3.bias"])
+    a = F.layer_norm(a, (d,), W["fusion.norm.weight"], W["fusion.norm.bias"], 1e-5)
+    # ---- SeparationDecoder (model.py:201-220)
+    z = F.linear(F.gelu(F.linear(a, W["decoder.decoder.0.weight"], W["decoder.decoder.0.bias"])),
+                 W["decoder.decoder.3.weight"], W["decoder.decoder.3.bias"])
+    masks = torch.sigmoid(z.view(B, T, num_speakers, Fq).permute(0, 2, 3, 1))
+    return masks * mixed.unsqueeze(1), masks
+
+
+def _pe(W, key, L, d, dtype):
+    if key in W:
+        return W[key][:, :L].to(dtype)
+    pos = torch.arange(0, L).unsqueeze(1).float()
+    div = torch.exp(torch.arange(0, d, 2).float() * (-math.log(10000.0) / d))
+    pe = torch.zeros(L, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(0).to(dtype)
