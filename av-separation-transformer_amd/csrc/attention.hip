@@ -20,6 +20,19 @@
 
 namespace {
 
+// exp(x) for x <= 0 with a compensated argument: x*log2(e) is split into its rounded product and the exact
+// rounding error (fma) plus the low part of log2(e), so the relative error stays ~1 ulp even for |x| ~ 100
+// (plain exp2(x*log2e) loses |x|*6e-8).  One v_exp_f32 + 5 VALU.
+__device__ __forceinline__ float exp_neg(float x) {
+  const float L2E_HI = 1.44269502162933349609f, L2E_LO = 1.92596299112661746e-08f;
+  x = fmaxf(x, -120.0f);          // exp2(-173) is exactly 0 on v_exp_f32; keeps -inf (masked keys, first tile) finite
+  const float t = x * L2E_HI;
+  float r = fmaf(x, L2E_HI, -t);
+  r = fmaf(x, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.69314718055994530942f, e);
+}
+
 // NB = ceil(dh / 16).  REG = (dh == 16*NB): the fast path with unpredicated vector loads; otherwise the head
 // is zero-extended to 16*NB (k >= dh contributes 0 to S, rows dv >= dh of O^T are never stored).
 template <int NB, bool REG>
@@ -118,12 +131,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float mnew = fmaxf(mrun, tmax);          // finite: tile 0 always holds key 0
-    const float alpha = __expf(mrun - mnew);       // 0 on the first tile (mrun = -inf)
+    const float alpha = exp_neg(mrun - mnew);       // 0 on the first tile (mrun = -inf)
     float psum = 0.0f;
     float pr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      pr[r] = __expf(st[r] - mnew);
+      pr[r] = exp_neg(st[r] - mnew);
       psum += pr[r];
     }
     lrun = lrun * alpha + psum;                    // per-lane partial (own 4 keys per tile); reduced at the end

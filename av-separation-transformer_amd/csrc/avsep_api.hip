@@ -296,6 +296,12 @@ int record_tap(avsep_ctx* c, const Workspace& w, const char* name, const float* 
 // launches; with it on, each launch is bracketed by two HIP events recorded on the stream it runs on, and
 // carries its ALGORITHMIC flops/bytes (DESIGN.md "roofline accounting"), so bench.py can price every kernel
 // live, on hardware, without an external profiler.
+// HIP event records cost several microseconds each on this stack, so a launch is not timed alone: with the
+// profiler on it is issued PROF_REPS times back to back between ONE pair of events and the record keeps the
+// mean.  (In-place residual updates are applied PROF_REPS times, so a profiled forward's OUTPUT is
+// meaningless -- it is a timing run only.)
+constexpr int PROF_REPS = 20;
+
 template <typename L>
 int profiled(avsep_ctx* c, const char* name, double flops, double bytes, hipStream_t s, L&& launch) {
   if (!c->prof_on) {
@@ -306,7 +312,8 @@ int profiled(avsep_ctx* c, const char* name, double flops, double bytes, hipStre
   HCK(hipEventCreate(&r.e0));
   HCK(hipEventCreate(&r.e1));
   HCK(hipEventRecord(r.e0, s));
-  hipError_t e = launch();
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < PROF_REPS && e == hipSuccess; ++i) e = launch();
   HCK(hipEventRecord(r.e1, s));
   c->prof.push_back(r);
   HCK(e);
@@ -498,6 +505,8 @@ int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* mas
   if (ws_bytes < need) return fail(AVSEP_ENOMEM, "workspace too small: see avsep_workspace_bytes()");
   c->taps.clear();
   c->tap_cursor = 0;
+  // profiling: park the stream so the launches below are already queued when the GPU reaches them
+  if (c->prof_on) HCK(launch_delay(5000, s));
   // fork: visual encoder (+ the fusion K/V projection that depends only on it) on the side stream
   HCK(hipEventRecord(c->ev_fork, s));
   HCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -599,7 +608,7 @@ int64_t avsep_profile_end(avsep_ctx* c, char* json, size_t cap) {
     Agg* a = nullptr;
     for (auto& x : agg) if (x.name == r.name) a = &x;
     if (!a) { agg.push_back({r.name, 0, 0, 0, 0}); a = &agg.back(); }
-    a->calls++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
+    a->calls++; a->ms += ms / PROF_REPS; a->flops += r.flops; a->bytes += r.bytes;
   }
   c->prof.clear();
   if (rc != AVSEP_OK) return rc;

@@ -22,6 +22,7 @@
 //     in the reference's (B,T,S,F) memory order.
 #include "kernels.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -36,6 +37,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 template <int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int D = (BM + BN >= 256) ? 2 : 4;   // prefetch ring depth (even); the biggest tile keeps VGPRs < 256
   constexpr int WBM = BM / 32;   // 16-row MFMA blocks per wave
   constexpr int WBN = BN / 32;   // 16-col MFMA blocks per wave
   constexpr int APASS = BM / 32; // staging passes of 32 rows (256 threads x float4 = 32 rows x 128 B)
@@ -93,40 +95,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   const int nk = p.K >> 5;
   const int cpt = (AMODE == AMODE_PLAIN) ? nk : (p.Kt >> 5);   // chunks per tap
-  int tap = 0, sub = 0;                                        // running (tap, chunk-in-tap) of the chunk being loaded
+  int tap = 0, sub = 0;                                        // (tap, chunk-in-tap) of the NEXT chunk to load
+  int kload = 0;                                               // index of the next chunk to load (saturates at nk-1)
 
-  f32x4 ra[APASS], rb[BPASS];
-  auto load_chunk = [&](int kc) {
+  // D-deep register ring: the global loads of chunk kc+D are issued while chunk kc is being multiplied, so
+  // D-1 chunks of MFMA time cover one L2 / Infinity-Cache / HBM round trip (measured ~2k cycles per chunk
+  // exposed with a 1-deep prefetch at one workgroup per CU: profiles/r01_*).  fp32 MFMA leaves the VGPR file
+  // nearly empty, so the ring is free.  Loads are unconditional (the chunk index saturates) to keep the
+  // compiler's counted vmcnt waits exact; the ring is statically indexed after unrolling.
+  f32x4 ra[D][APASS], rb[D][BPASS];
+  auto load_chunk = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       if (AMODE == AMODE_PLAIN) {
-        ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (kc << 5));
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + (kload << 5));
       } else if (AMODE == AMODE_TAPS3) {
         const int t = a_aux0[i] + tap - 1;
         const bool ok = (t >= 0) && (t < p.T);
         const float* src = a_src[i] + (ptrdiff_t)(tap - 1) * p.lda + (sub << 5);
-        ra[i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int iy = a_aux0[i] + ky, ix = a_aux1[i] + kx;
         const bool ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
         const float* src = a_src[i] + ((size_t)(ok ? iy : 0) * p.Win + (ok ? ix : 0)) * p.Kt + (sub << 5);
-        ra[i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + (kc << 5));
-    if (AMODE != AMODE_PLAIN) {
-      if (++sub == cpt) { sub = 0; ++tap; }
+    for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + (kload << 5));
+    if (kload < nk - 1) {
+      ++kload;
+      if (AMODE != AMODE_PLAIN) {
+        if (++sub == cpt) { sub = 0; ++tap; }
+      }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int slot, int buf) {
     float* a = As + buf * BM * 32 + st_off;
     float* b = Bs + buf * BN * 32 + st_off;
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + i * 32 * 32) = ra[i];
+    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + i * 32 * 32) = ra[slot][i];
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + i * 32 * 32) = rb[i];
+    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + i * 32 * 32) = rb[slot][i];
   };
 
   // ---- fragment read coordinates ----------------------------------------------------------------
@@ -152,34 +163,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_chunk(0);
-  store_chunk(0);
+#pragma unroll
+  for (int j = 0; j < D; ++j) load_chunk(j);
+  store_chunk(0, 0);
   __syncthreads();
 
-  for (int kc = 0; kc < nk; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nk) load_chunk(kc + 1);   // global loads in flight under this chunk's MFMAs
-    const float* a = As + cur * BM * 32;
-    const float* b = Bs + cur * BN * 32;
+  for (int kc0 = 0; kc0 < nk; kc0 += D) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 fa[WBM], fb[WBN];
+    for (int j = 0; j < D; ++j) {
+      const int kc = kc0 + j;
+      if (kc < nk) {                       // block-uniform
+        load_chunk(j);                     // slot j (chunk kc) went to LDS one iteration ago: refill with chunk kc+D
+        const float* a = As + (j & 1) * BM * 32;   // D is even: (kc & 1) == (j & 1)
+        const float* b = Bs + (j & 1) * BN * 32;
 #pragma unroll
-      for (int i = 0; i < WBM; ++i)
-        fa[i] = *reinterpret_cast<const f32x4*>(a + a_off[i] + (((4 * s + fq) ^ a_swz[i]) << 2));
+        for (int s = 0; s < 2; ++s) {
+          f32x4 fa[WBM], fb[WBN];
 #pragma unroll
-      for (int j = 0; j < WBN; ++j)
-        fb[j] = *reinterpret_cast<const f32x4*>(b + b_off[j] + (((4 * s + fq) ^ b_swz[j]) << 2));
+          for (int i = 0; i < WBM; ++i)
+            fa[i] = *reinterpret_cast<const f32x4*>(a + a_off[i] + (((4 * s + fq) ^ a_swz[i]) << 2));
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+          for (int jn = 0; jn < WBN; ++jn)
+            fb[jn] = *reinterpret_cast<const f32x4*>(b + b_off[jn] + (((4 * s + fq) ^ b_swz[jn]) << 2));
 #pragma unroll
-        for (int i = 0; i < WBM; ++i)
+          for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int j = 0; j < WBN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[j][c], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < WBM; ++i)
+#pragma unroll
+              for (int jn = 0; jn < WBN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[jn][c], acc[i][jn], 0, 0, 0);
+        }
+        // chunk kc+1 (ring slot j+1, loaded D-1 iterations ago) -> the other LDS buffer
+        if (kc + 1 < nk) store_chunk((j + 1) % D, (j + 1) & 1);
+        __syncthreads();
+      }
     }
-    if (kc + 1 < nk) store_chunk(cur ^ 1);
-    __syncthreads();
   }
 
   // ---- epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg -----------------
@@ -222,18 +240,21 @@ struct Tile { int bm, bn; };
 // At the small M of batch-32 inference (M = B*T = 2016) the big tiles leave most CUs idle, so the
 // choice matters more than the inner loop (DESIGN.md "tile selection").
 Tile pick_tile(int M, int N, int amode) {
-  static const Tile cands[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {64, 32}, {32, 64}, {32, 32}};
-  double best = 1e300;
-  Tile bt{64, 64};
-  for (const Tile& t : cands) {
-    if (amode != AMODE_PLAIN && (t.bm < 64 && t.bn > 32)) continue;   // not instantiated
-    const long blocks = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
-    const long rounds = (blocks + 255) / 256;
-    const double reuse = 1.0 + 16.0 / t.bm + 16.0 / t.bn;
-    const double cost = (double)rounds * t.bm * t.bn * reuse;
-    if (cost < best) { best = cost; bt = t; }
+  // developer override for hardware sweeps (tools/gemm_sweep.py): AVSEP_GEMM_TILE=BMxBN
+  if (const char* e = getenv("AVSEP_GEMM_TILE")) {
+    Tile t{0, 0};
+    if (sscanf(e, "%dx%d", &t.bm, &t.bn) == 2) return t;
   }
-  return bt;
+  // Measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt): with fp32 MFMA the inner loop is
+  // cheap to feed, so what decides the time at M ~ 2k is how many workgroups are resident to hide the
+  // staging latency.  Take the largest tile that still gives >= 4 workgroups per CU, else >= 2, else the
+  // smallest tile.
+  static const Tile cands[] = {{128, 64}, {64, 64}, {64, 32}, {32, 32}};
+  auto blocks = [&](const Tile& t) { return (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn); };
+  for (long need : {1024L, 512L})
+    for (const Tile& t : cands)
+      if (blocks(t) >= need) return t;
+  return Tile{32, 32};
 }
 
 }  // namespace

@@ -48,6 +48,8 @@ hipError_t launch_conv1_c1(const float* frames, const float* w9x32, const float*
 hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);
 
+hipError_t launch_delay(unsigned us, hipStream_t s);   // profiling aid, see rowops.hip
+
 // weight packing (device -> device)
 hipError_t launch_pack_rows(const float* src, float* dst, int rows, int K, int Kp, float scale, int scale_rows,
                             hipStream_t s);  // dst[r][k] = src[r][k] * (r < scale_rows ? scale : 1), zero pad to Kp

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 // F.interpolate(mode='linear', align_corners=False) along time (model.py:114-116); index arithmetic in
 // fp32 exactly as ATen's area_pixel_compute_source_index.
 __global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                            int B, int N, int T, int d) {
+                                                            int B, int N, int T, int d, float scale) {
   const int dq = d >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)B * T * dq) return;
@@ -140,8 +140,10 @@ __global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restr
   const size_t bt = idx / dq;
   const int t = (int)(bt % T);
   const int b = (int)(bt / T);
-  const float scale = (float)N / (float)T;
-  float src = scale * ((float)t + 0.5f) - 0.5f;
+  // scale = (float)N / (float)T comes from the host (one IEEE rounding).  ATen's CPU kernel evaluates
+  // scale*(i+0.5)-0.5 as ONE fused multiply-add (measured: tests/test_oracle.py::test_interp_index_is_fma),
+  // and a 1-ulp difference in src moves the lerp weight by ~4e-6, so the fma is part of the contract.
+  float src = fmaf(scale, (float)t + 0.5f, -0.5f);
   src = src < 0.0f ? 0.0f : src;
   int i0 = (int)src;
   i0 = i0 < N - 1 ? i0 : N - 1;
@@ -151,6 +153,13 @@ __global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restr
   const f32x4 a = *reinterpret_cast<const f32x4*>(x + ((size_t)b * N + i0) * d + 4 * c4);
   const f32x4 c = *reinterpret_cast<const f32x4*>(x + ((size_t)b * N + i1) * d + 4 * c4);
   *reinterpret_cast<f32x4*>(y + bt * d + 4 * c4) = w0 * a + w1 * c;
+}
+
+// Profiling aid: keeps the stream busy for `us` microseconds so the host can queue a whole forward behind
+// it; the per-kernel HIP events of avsep_profile_* then see back-to-back kernels instead of launch gaps.
+__global__ void delay_kernel(unsigned us) {
+  const unsigned long long t0 = wall_clock64();          // 100 MHz constant clock
+  while (wall_clock64() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
 }
 
 // ------------------------------------------------------------------------------------ weight packers
@@ -198,6 +207,11 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, float* __restri
 
 }  // namespace
 
+hipError_t launch_delay(unsigned us, hipStream_t s) {
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, us);
+  return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int d, float eps,
                             hipStream_t s) {
   if (M <= 0 || d <= 0 || (d & 3) || d > 2048) return hipErrorInvalidValue;
@@ -235,7 +249,8 @@ hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStre
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s) {
   if (d & 3) return hipErrorInvalidValue;
   const size_t n = (size_t)B * T * (d / 4);
-  hipLaunchKernelGGL(interp_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, B, N, T, d);
+  hipLaunchKernelGGL(interp_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, B, N, T, d,
+                     (float)N / (float)T);
   return hipGetLastError();
 }
 

@@ -108,8 +108,10 @@ int64_t avsep_read_tap(avsep_ctx* ctx, const char* name, float* dst, int64_t max
                        int T, int N, int H, int W, void* stream);
 
 /* Live per-kernel profile: between avsep_profile_begin() and avsep_profile_end() every kernel the EAGER
- * entry points launch is bracketed by two HIP events on the stream it runs on.  avsep_profile_end() waits
- * for them and writes a JSON array aggregated per kernel (template instance) in first-launch order:
+ * entry points launch is issued 20x back to back between one pair of HIP events on the stream it runs on
+ * (an event record costs microseconds here, a kernel may take less) and its MEAN duration is kept; outputs
+ * of a profiled call are therefore meaningless (residual updates applied 20x).  avsep_profile_end() waits
+ * for the events and writes a JSON array aggregated per kernel (template instance) in first-launch order:
  *   [{"name":"gemm_kernel<64, 32, 0>","calls":n,"ms":total,"flops":algorithmic,"bytes":algorithmic},...]
  * Returns the JSON length or a negative error.  bench.py prices its roofline from this. */
 int avsep_profile_begin(avsep_ctx* ctx);

@@ -107,12 +107,14 @@ def batchnorm2d(x, g, b, mean, var, eps=BN_EPS, train=False):
 def interp_linear(x, out_len):
     """F.interpolate(mode='linear', align_corners=False) along axis 1 of (B,N,d)  (model.py:114-116).
     Index arithmetic in the tensor dtype (float32 on the product path) like ATen's area_pixel_compute_source_index:
-    src = (N/T)*(i+0.5)-0.5 clamped at 0; i0=floor(src); i1=min(i0+1,N-1); w=src-i0."""
+    src = fma(N/T, i+0.5, -0.5) clamped at 0; i0=floor(src); i1=min(i0+1,N-1); w=src-i0.
+    The multiply-add is FUSED in ATen's compiled CPU kernel (one rounding): emulated here in float64, where the
+    float32 x float32 product is exact.  Pinned by tests/test_oracle.py::test_interp_index_is_fma."""
     B, N, d = x.shape
     ft = x.dtype.type                      # ATen does the index arithmetic in the tensor's opmath type
     scale = ft(N) / ft(out_len)
     i = np.arange(out_len).astype(x.dtype)
-    src = scale * (i + ft(0.5)) - ft(0.5)
+    src = (scale.astype(np.float64) * (i + ft(0.5)).astype(np.float64) - 0.5).astype(x.dtype)
     src = np.maximum(src, ft(0.0))
     i0 = np.floor(src).astype(np.int64)
     i0 = np.minimum(i0, N - 1)

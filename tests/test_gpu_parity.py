@@ -263,8 +263,12 @@ def test_op_attention(lib, dev, B, h, dh, Lq, Lk):
     q64 = q.astype(np.float64).reshape(B, Lq, h, dh).transpose(0, 2, 1, 3)
     k64 = k.astype(np.float64).reshape(B, Lk, h, dh).transpose(0, 2, 1, 3)
     v64 = v.astype(np.float64).reshape(B, Lk, h, dh).transpose(0, 2, 1, 3)
-    ref = (onp.softmax_last(q64 @ k64.transpose(0, 1, 3, 2)) @ v64).transpose(0, 2, 1, 3).reshape(B, Lq, d)
-    assert maxabs(o.cpu().numpy(), ref) < 5e-6
+    scores = q64 @ k64.transpose(0, 1, 3, 2)
+    ref = (onp.softmax_last(scores) @ v64).transpose(0, 2, 1, 3).reshape(B, Lq, d)
+    # an fp32 score carries ~eps*|s|*sqrt(dh) of rounding, which softmax turns into the same RELATIVE error
+    # on p: the bound scales with the largest score (the spiked key makes it ~50)
+    tol = 2e-6 + 6e-8 * float(np.abs(scores).max()) * math.sqrt(dh) * 4.0
+    assert maxabs(o.cpu().numpy(), ref) < tol
 
 
 @pytest.mark.parametrize("B,N,T,d", [(2, 10, 32, 64), (2, 50, 63, 256), (1, 12, 5, 32), (3, 1, 7, 64),
@@ -276,7 +280,7 @@ def test_op_interp_linear(lib, dev, B, N, T, d):
     xd = t(x, dev)
     check(lib.avsep_op_interp_linear(xd.data_ptr(), y.data_ptr(), B, N, T, d, _stream()))
     ref = onp.interp_linear(x, T)
-    assert maxabs(y.cpu().numpy(), ref) < 1e-6
+    assert maxabs(y.cpu().numpy(), ref) < 1e-6     # |x| <= 3: a couple of fp32 ulps
     # cross-check the oracle's index formula against torch's own F.interpolate on the host
     tref = torch.nn.functional.interpolate(torch.from_numpy(x).permute(0, 2, 1), size=T, mode="linear",
                                            align_corners=False).permute(0, 2, 1).numpy()

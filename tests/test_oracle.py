@@ -84,3 +84,14 @@ def test_interp_matches_definition():
     x = np.array([[[0.0], [1.0]]], dtype=np.float32)
     y = onp.interp_linear(x, 4)[0, :, 0]
     np.testing.assert_allclose(y, [0.0, 0.25, 0.75, 1.0], atol=1e-7)
+
+
+@pytest.mark.parametrize("N,T", [(50, 63), (50, 501), (75, 251), (10, 32), (12, 5)])
+def test_interp_index_is_fma(N, T):
+    """torch's F.interpolate (the reference's model.py:115) rounds scale*(i+0.5)-0.5 once (fused); with two
+    roundings a few output rows move by ~4e-6.  The oracle must agree with torch on the host to 1 ulp."""
+    import torch
+    x = seeded.tensor(4, "x", (2, N, 16), -3, 3)
+    want = torch.nn.functional.interpolate(torch.from_numpy(x).permute(0, 2, 1), size=T, mode="linear",
+                                           align_corners=False).permute(0, 2, 1).numpy()
+    assert maxabs(onp.interp_linear(x, T), want) < 5e-7
