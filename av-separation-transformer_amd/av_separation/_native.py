@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libavsep_hip.so")
+LIB_PATH = os.environ.get("AVSEP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libavsep_hip.so")
 
 # every symbol include/avsep.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (

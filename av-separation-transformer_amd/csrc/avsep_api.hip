@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -84,8 +85,14 @@ struct avsep_ctx {
   std::vector<FusLayerW> f_layers;
   float *fn_g, *fn_b, *d_w1, *d_b1, *d_w2, *d_b2;
   // streams / events for the audio || visual fork-join and graph replay
+  static constexpr int MAX_SPLIT = 4;
+  int split = 1;                                   // batch shards per forward (measured: >1 is slower) (avsep_set_option "split")
   hipStream_t side = nullptr, gstream = nullptr;
+  hipStream_t pstream[2 * MAX_SPLIT] = {};         // [2p], [2p+1]: audio / visual stream of shard p >= 1
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gin = nullptr, ev_gout = nullptr;
+  hipEvent_t ev_vdone[MAX_SPLIT] = {}, ev_pdone[MAX_SPLIT] = {}, ev_adone[MAX_SPLIT] = {}, ev_tdone[MAX_SPLIT] = {};
+  bool no_fused_conv = false;                      // developer A/B switch (AVSEP_NO_FUSED_CONV)
+  bool tail_split = true;                          // fusion+decoder: half the batch per stream after the join
   std::vector<GraphEntry> graphs;
   // live per-kernel profiler (HIP events around every launch, on the launch's own stream)
   struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
@@ -344,6 +351,28 @@ int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk
                   [&] { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, s); });
 }
 
+// y = act( LayerNorm(x) W^T + b ).  At small M the LayerNorm is fused into the GEMM's A staging (one launch
+// less per LayerNorm, 13 per forward); once the problem is big enough for 64x64 tiles to fill the chip the
+// fused kernel's 32x32 tiles would sit at the L2 feed limit, so the stand-alone LayerNorm + big-tile GEMM wins.
+int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be, float* ln_buf, const float* W,
+                  const float* bias, float* y, int M, int N, int act, hipStream_t s) {
+  const int d = c->d;
+  GemmParams p{};
+  p.A = x; p.W = W; p.bias = bias; p.C = y;
+  p.M = M; p.N = N; p.K = d;
+  p.lda = d; p.ldw = d; p.ldc = N;
+  p.amode = AMODE_PLAIN;
+  p.act = act;
+  const long big_tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+  if (gemm_ln_supported(d) && big_tiles < 1024) {
+    p.ln_gamma = g; p.ln_beta = be; p.ln_eps = 1e-5f;
+    return run_gemm(c, p, s);
+  }
+  RCK(run_layernorm(c, x, g, be, ln_buf, M, d, s));
+  p.A = ln_buf;
+  return run_gemm(c, p, s);
+}
+
 // ------------------------------------------------------------------------------------------ building blocks
 GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
                          int M, int N, int act) {
@@ -360,14 +389,12 @@ GemmParams linear_params(const float* A, int lda, const float* W, int K, const f
 int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
                   int Lseq, hipStream_t s) {
   const int d = c->d, M = B * Lseq;
-  RCK(run_layernorm(c, x, L.g1, L.be1, ln, M, d, s));
-  RCK(run_gemm(c, linear_params(ln, d, L.wqkv, d, L.bqkv, qkv, 3 * d, M, 3 * d, ACT_NONE), s));
+  RCK(run_ln_linear(c, x, L.g1, L.be1, ln, L.wqkv, L.bqkv, qkv, M, 3 * d, ACT_NONE, s));   // norm1 -> in_proj
   RCK(run_attention(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, d, B, Lseq, Lseq, s));
   GemmParams po = linear_params(att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
   po.R = x; po.ldr = d; po.rperiod = 0;
   RCK(run_gemm(c, po, s));
-  RCK(run_layernorm(c, x, L.g2, L.be2, ln, M, d, s));
-  RCK(run_gemm(c, linear_params(ln, d, L.w1, d, L.b1, ffn, 4 * d, M, 4 * d, ACT_RELU), s));
+  RCK(run_ln_linear(c, x, L.g2, L.be2, ln, L.w1, L.b1, ffn, M, 4 * d, ACT_RELU, s));        // norm2 -> linear1
   GemmParams p2 = linear_params(ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
   p2.R = x; p2.ldr = d; p2.rperiod = 0;
   RCK(run_gemm(c, p2, s));
@@ -416,23 +443,38 @@ int visual_branch(avsep_ctx* c, const Workspace& w, const float* lips, int B, in
   const int d = c->d, Mv = B * N;
   const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2),
             W3 = conv_out(W2);
-  RCK(profiled(c, "conv1_c1_kernel", 2.0 * Mv * H1 * W1 * 32 * 9, 4.0 * Mv * (H * W + H1 * W1 * 32), s,
-               [&] { return launch_conv1_c1(lips, c->c1_w, c->c1_b, w.act1, Mv, H, W, H1, W1, s); }));
-  RCK(record_tap(c, w, "v_conv0", w.act1, (size_t)Mv * H1 * W1 * 32, s));
-  GemmParams p{};
-  p.A = w.act1; p.W = c->c2_w; p.ldw = 9 * 32; p.bias = c->c2_b; p.C = w.act2; p.ldc = 64;
-  p.M = Mv * H2 * W2; p.N = 64; p.K = 9 * 32; p.amode = AMODE_CONV2D; p.Kt = 32;
-  p.Hin = H1; p.Win = W1; p.Hout = H2; p.Wout = W2; p.act = ACT_RELU;
-  RCK(run_gemm(c, p, s));
-  RCK(record_tap(c, w, "v_conv1", w.act2, (size_t)Mv * H2 * W2 * 64, s));
-  GemmParams p3{};
-  p3.A = w.act2; p3.W = c->c3_w; p3.ldw = 9 * 64; p3.bias = c->c3_b; p3.C = w.act3; p3.ldc = 128;
-  p3.M = Mv * H3 * W3; p3.N = 128; p3.K = 9 * 64; p3.amode = AMODE_CONV2D; p3.Kt = 64;
-  p3.Hin = H2; p3.Win = W2; p3.Hout = H3; p3.Wout = W3; p3.act = ACT_RELU;
-  RCK(run_gemm(c, p3, s));
-  RCK(record_tap(c, w, "v_conv2", w.act3, (size_t)Mv * H3 * W3 * 128, s));
-  RCK(profiled(c, "avgpool_kernel", 1.0 * Mv * H3 * W3 * 128, 4.0 * Mv * 128 * (H3 * W3 + 1), s,
-               [&] { return launch_avgpool(w.act3, w.pool, Mv, H3 * W3, 128, s); }));
+  // fused LDS-resident conv stack (conv_stack.hip) unless debug taps want the intermediate activations or the
+  // frame size does not fit it
+  bool fused = !c->keep_taps && !c->no_fused_conv;
+  if (fused) {
+    const double fl = 2.0 * Mv * ((double)H1 * W1 * 32 * 9 + (double)H2 * W2 * 64 * 288 + (double)H3 * W3 * 128 * 576);
+    hipError_t e = hipSuccess;
+    int r = profiled(c, "conv_stack_kernel", fl, 4.0 * Mv * ((double)H * W + 128), s, [&] {
+      e = launch_conv_stack(lips, c->c1_w, c->c1_b, c->c2_w, c->c2_b, c->c3_w, c->c3_b, w.pool, Mv, H, W, s);
+      return e == hipErrorNotSupported ? hipSuccess : e;
+    });
+    RCK(r);
+    if (e == hipErrorNotSupported) fused = false;
+  }
+  if (!fused) {
+    RCK(profiled(c, "conv1_c1_kernel", 2.0 * Mv * H1 * W1 * 32 * 9, 4.0 * Mv * (H * W + H1 * W1 * 32), s,
+                 [&] { return launch_conv1_c1(lips, c->c1_w, c->c1_b, w.act1, Mv, H, W, H1, W1, s); }));
+    RCK(record_tap(c, w, "v_conv0", w.act1, (size_t)Mv * H1 * W1 * 32, s));
+    GemmParams p{};
+    p.A = w.act1; p.W = c->c2_w; p.ldw = 9 * 32; p.bias = c->c2_b; p.C = w.act2; p.ldc = 64;
+    p.M = Mv * H2 * W2; p.N = 64; p.K = 9 * 32; p.amode = AMODE_CONV2D; p.Kt = 32;
+    p.Hin = H1; p.Win = W1; p.Hout = H2; p.Wout = W2; p.act = ACT_RELU;
+    RCK(run_gemm(c, p, s));
+    RCK(record_tap(c, w, "v_conv1", w.act2, (size_t)Mv * H2 * W2 * 64, s));
+    GemmParams p3{};
+    p3.A = w.act2; p3.W = c->c3_w; p3.ldw = 9 * 64; p3.bias = c->c3_b; p3.C = w.act3; p3.ldc = 128;
+    p3.M = Mv * H3 * W3; p3.N = 128; p3.K = 9 * 64; p3.amode = AMODE_CONV2D; p3.Kt = 64;
+    p3.Hin = H2; p3.Win = W2; p3.Hout = H3; p3.Wout = W3; p3.act = ACT_RELU;
+    RCK(run_gemm(c, p3, s));
+    RCK(record_tap(c, w, "v_conv2", w.act3, (size_t)Mv * H3 * W3 * 128, s));
+    RCK(profiled(c, "avgpool_kernel", 1.0 * Mv * H3 * W3 * 128, 4.0 * Mv * 128 * (H3 * W3 + 1), s,
+                 [&] { return launch_avgpool(w.act3, w.pool, Mv, H3 * W3, 128, s); }));
+  }
   RCK(record_tap(c, w, "v_pool", w.pool, (size_t)Mv * 128, s));
   GemmParams pf = linear_params(w.pool, 128, c->fp_w, 128, c->fp_b, w.v_x, d, Mv, d, ACT_NONE);
   pf.R = c->v_pe; pf.ldr = d; pf.rperiod = N;   // PE indexed by frame position
@@ -457,37 +499,44 @@ int fusion_kv(avsep_ctx* c, const Workspace& w, const float* visual, int B, int 
 }
 
 // CrossModalFusion.forward (model.py:145-149) in place on x; final LayerNorm written to w.ln.
-int fusion_layers(avsep_ctx* c, const Workspace& w, float* x, int B, int T, hipStream_t s) {
+int fusion_layers(avsep_ctx* c, const Workspace& w, float* x, int B, int T, hipStream_t s, bool final_norm) {
   if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
   const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
   for (int i = 0; i < c->Lf; ++i) {
     const FusLayerW& L = c->f_layers[i];
-    RCK(run_layernorm(c, x, L.g1, L.be1, w.ln, M, d, s));
-    RCK(run_gemm(c, linear_params(w.ln, d, L.wq, d, L.bq, w.f_q, d, M, d, ACT_NONE), s));
+    RCK(run_ln_linear(c, x, L.g1, L.be1, w.ln, L.wq, L.bq, w.f_q, M, d, ACT_NONE, s));       // norm1 -> q proj
     const float* kk = w.kv_all + (size_t)i * 2 * d;
     RCK(run_attention(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, d, B, T, T, s));
     GemmParams po = linear_params(w.att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
     po.R = x; po.ldr = d;
     RCK(run_gemm(c, po, s));
-    RCK(run_layernorm(c, x, L.g2, L.be2, w.ln, M, d, s));
-    RCK(run_gemm(c, linear_params(w.ln, d, L.w1, d, L.b1, w.ffn, 4 * d, M, 4 * d, ACT_GELU), s));
+    RCK(run_ln_linear(c, x, L.g2, L.be2, w.ln, L.w1, L.b1, w.ffn, M, 4 * d, ACT_GELU, s));   // norm2 -> ff.0
     GemmParams p2 = linear_params(w.ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
     p2.R = x; p2.ldr = d;
     RCK(run_gemm(c, p2, s));
     RCK(record_tap(c, w, ("f_layer" + std::to_string(i)).c_str(), x, (size_t)M * d, s));
   }
-  RCK(run_layernorm(c, x, c->fn_g, c->fn_b, w.ln, M, d, s));
-  RCK(record_tap(c, w, "f_norm", w.ln, (size_t)M * d, s));
+  if (final_norm) {   // stand-alone CrossModalFusion: materialise fusion.norm; the full forward fuses it into the decoder
+    RCK(run_layernorm(c, x, c->fn_g, c->fn_b, w.ln, M, d, s));
+    RCK(record_tap(c, w, "f_norm", w.ln, (size_t)M * d, s));
+  }
   return AVSEP_OK;
 }
 
 // SeparationDecoder.forward + .separate (model.py:201-220): masks = sigmoid(W2 gelu(W1 x)), output
 // channel n = s*F + f, written as (B,T,S,F); separated = masks * mixed (xt holds mixed^T) in the epilogue.
+// `fuse_norm`: `fused` is the un-normalised fusion output and fusion.norm (model.py:149) is applied as the
+// LayerNorm prologue of the first decoder GEMM.
 int decoder_stage(avsep_ctx* c, const Workspace& w, const float* fused, float* masks, float* sep, int B, int T,
-                  hipStream_t s) {
+                  hipStream_t s, bool fuse_norm) {
   if (!c->ok_decoder) return fail(AVSEP_ENOWEIGHT, "decoder weights are incomplete");
   const int d = c->d, M = B * T, SF = c->S * c->F;
-  RCK(run_gemm(c, linear_params(fused, d, c->d_w1, d, c->d_b1, w.ffn, 2 * d, M, 2 * d, ACT_GELU), s));
+  if (fuse_norm) {
+    if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
+    RCK(run_ln_linear(c, fused, c->fn_g, c->fn_b, w.ln, c->d_w1, c->d_b1, w.ffn, M, 2 * d, ACT_GELU, s));
+  } else {
+    RCK(run_gemm(c, linear_params(fused, d, c->d_w1, d, c->d_b1, w.ffn, 2 * d, M, 2 * d, ACT_GELU), s));
+  }
   GemmParams p = linear_params(w.ffn, 2 * d, c->d_w2, 2 * d, c->d_b2, masks, SF, M, SF, ACT_SIGMOID);
   if (sep) {
     p.C2 = sep; p.X = w.xt; p.ldx = c->Fp; p.F = c->F;
@@ -496,33 +545,123 @@ int decoder_stage(avsep_ctx* c, const Workspace& w, const float* fused, float* m
   return AVSEP_OK;
 }
 
+// Workspace view of the clips [b0, B) for the row-local stages after the audio/visual join.
+Workspace shift_rows(const avsep_ctx* c, const Workspace& w, int b0, int T) {
+  Workspace v = w;
+  const size_t rows = (size_t)b0 * T, d = c->d;
+  v.xt += rows * c->Fp;
+  v.a_x += rows * d;
+  v.ln += rows * d;
+  v.f_q += rows * d;
+  v.att += rows * d;
+  v.ffn += rows * 4 * d;
+  v.kv_all += rows * (size_t)c->Lf * 2 * d;
+  return v;
+}
+
+// One shard of the batch: audio encoder on `sa`, visual encoder (+ fusion K/V projection) on `sv`, join, then
+// fusion + decoder.  Clips are independent in eval mode, so shards never exchange data.
+// After the join the visual stream would idle while fusion + decoder run on the audio stream (measured: one
+// hardware queue 84 % busy, the other 40 %, profiles/r01c_*), so the tail is cut in two halves of the batch,
+// one per stream -- same kernels, half the rows each, running concurrently.
+int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const float* lips, float* masks, float* sep,
+                 int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv, int p) {
+  int rv = visual_branch(c, w, lips, B, N, H, W, T, sv);
+  if (rv == AVSEP_OK) rv = fusion_kv(c, w, w.v_up, B, T, sv);
+  // always join, even on error, so a capture in progress is not left forked
+  hipError_t ej = hipEventRecord(c->ev_vdone[p], sv);
+  int ra = audio_branch(c, w, mixed, B, T, sa);
+  hipError_t ew = hipStreamWaitEvent(sa, c->ev_vdone[p], 0);
+  const bool tail_split = c->tail_split && B >= 2 && !c->keep_taps && !c->prof_on;
+  hipError_t ea = hipSuccess, eb = hipSuccess;
+  if (tail_split) {
+    ea = hipEventRecord(c->ev_adone[p], sa);
+    eb = hipStreamWaitEvent(sv, c->ev_adone[p], 0);
+  }
+  if (rv != AVSEP_OK) return rv;
+  if (ra != AVSEP_OK) return ra;
+  HCK(ej);
+  HCK(ew);
+  HCK(ea);
+  HCK(eb);
+  const size_t SF = (size_t)c->S * c->F;
+  if (!tail_split) {
+    RCK(fusion_layers(c, w, w.a_x, B, T, sa, /*final_norm=*/c->keep_taps));
+    RCK(decoder_stage(c, w, w.a_x, masks, sep, B, T, sa, /*fuse_norm=*/true));
+    return AVSEP_OK;
+  }
+  const int b1 = (B + 1) / 2;   // clips [0,b1) on sa, [b1,B) on sv
+  int r0 = fusion_layers(c, w, w.a_x, b1, T, sa, false);
+  if (r0 == AVSEP_OK) r0 = decoder_stage(c, w, w.a_x, masks, sep, b1, T, sa, true);
+  const Workspace w1 = shift_rows(c, w, b1, T);
+  int r1 = fusion_layers(c, w1, w1.a_x, B - b1, T, sv, false);
+  if (r1 == AVSEP_OK)
+    r1 = decoder_stage(c, w1, w1.a_x, masks + (size_t)b1 * T * SF, sep + (size_t)b1 * T * SF, B - b1, T, sv, true);
+  hipError_t et = hipEventRecord(c->ev_tdone[p], sv);
+  hipError_t eu = hipStreamWaitEvent(sa, c->ev_tdone[p], 0);
+  if (r0 != AVSEP_OK) return r0;
+  if (r1 != AVSEP_OK) return r1;
+  HCK(et);
+  HCK(eu);
+  return AVSEP_OK;
+}
+
+// Number of independent batch shards run on their own stream pairs.  At small batch every kernel is a few
+// microseconds of MFMA work wrapped in a fixed prologue/epilogue; running several shards' kernels
+// concurrently fills those bubbles (DESIGN.md "batch shards").
+int pick_split(const avsep_ctx* c, int B) {
+  if (c->keep_taps || c->prof_on) return 1;
+  int p = c->split;
+  if (p <= 0) p = 1;
+  if (p > avsep_ctx::MAX_SPLIT) p = avsep_ctx::MAX_SPLIT;
+  if (p > B) p = B;
+  return p;
+}
+
+size_t carve_all(const avsep_ctx* c, int P, Workspace* parts, float* base, int B, int T, int N, int H, int W) {
+  size_t off = 0;
+  for (int p = 0; p < P; ++p) {
+    const int b0 = (int)((long)B * p / P), b1 = (int)((long)B * (p + 1) / P);
+    off += carve(c, parts ? &parts[p] : nullptr, base ? base + off : nullptr, b1 - b0, T, N, H, W);
+  }
+  return off;
+}
+
 int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
                  size_t ws_bytes, int B, int T, int N, int H, int W, hipStream_t s) {
   RCK(check_common(c, B, T));
   if (!mixed || !lips || !masks || !sep || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
-  Workspace w;
-  const size_t need = carve(c, &w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float);
+  const int P = pick_split(c, B);
+  Workspace w[avsep_ctx::MAX_SPLIT];
+  const size_t need = carve_all(c, P, w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float);
   if (ws_bytes < need) return fail(AVSEP_ENOMEM, "workspace too small: see avsep_workspace_bytes()");
   c->taps.clear();
   c->tap_cursor = 0;
   // profiling: park the stream so the launches below are already queued when the GPU reaches them
   if (c->prof_on) HCK(launch_delay(5000, s));
-  // fork: visual encoder (+ the fusion K/V projection that depends only on it) on the side stream
+  // fork every shard's streams off the caller's stream
   HCK(hipEventRecord(c->ev_fork, s));
-  HCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-  int rv = visual_branch(c, w, lips, B, N, H, W, T, c->side);
-  if (rv == AVSEP_OK) rv = fusion_kv(c, w, w.v_up, B, T, c->side);
-  // always join, even on error, so a capture in progress is not left forked
-  hipError_t ej = hipEventRecord(c->ev_join, c->side);
-  int ra = audio_branch(c, w, mixed, B, T, s);
-  hipError_t ew = hipStreamWaitEvent(s, c->ev_join, 0);
-  if (rv != AVSEP_OK) return rv;
-  if (ra != AVSEP_OK) return ra;
-  HCK(ej);
-  HCK(ew);
-  RCK(fusion_layers(c, w, w.a_x, B, T, s));
-  RCK(decoder_stage(c, w, w.ln, masks, sep, B, T, s));
-  return AVSEP_OK;
+  int rc = AVSEP_OK;
+  const size_t SF = (size_t)c->S * c->F;
+  for (int p = 0; p < P; ++p) {
+    const int b0 = (int)((long)B * p / P), b1 = (int)((long)B * (p + 1) / P);
+    hipStream_t sa = p == 0 ? s : c->pstream[2 * p];
+    hipStream_t sv = p == 0 ? c->side : c->pstream[2 * p + 1];
+    static const bool serial = getenv("AVSEP_SERIAL") != nullptr;   // developer A/B: everything on one stream
+    if (serial) sv = sa;
+    if (p) HCK(hipStreamWaitEvent(sa, c->ev_fork, 0));
+    HCK(hipStreamWaitEvent(sv, c->ev_fork, 0));
+    const int r = forward_part(c, w[p], mixed + (size_t)b0 * c->F * T, lips + (size_t)b0 * N * H * W,
+                               masks + (size_t)b0 * T * SF, sep + (size_t)b0 * T * SF, b1 - b0, T, N, H, W, sa, sv, p);
+    if (r != AVSEP_OK && rc == AVSEP_OK) rc = r;
+    if (p) {   // join the shard back into the caller's stream
+      hipError_t e1 = hipEventRecord(c->ev_pdone[p], sa);
+      hipError_t e2 = hipStreamWaitEvent(s, c->ev_pdone[p], 0);
+      if (rc == AVSEP_OK && e1 != hipSuccess) rc = fail_hip(e1, "hipEventRecord(shard done)");
+      if (rc == AVSEP_OK && e2 != hipSuccess) rc = fail_hip(e2, "hipStreamWaitEvent(shard done)");
+    }
+  }
+  return rc;
 }
 
 }  // namespace
@@ -562,6 +701,18 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) {
             hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_gin, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_gout, hipEventDisableTiming) == hipSuccess;
+  for (int p = 0; p < avsep_ctx::MAX_SPLIT && ok; ++p) {
+    ok = hipEventCreateWithFlags(&c->ev_vdone[p], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_pdone[p], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_adone[p], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_tdone[p], hipEventDisableTiming) == hipSuccess;
+    if (p && ok)
+      ok = hipStreamCreateWithFlags(&c->pstream[2 * p], hipStreamNonBlocking) == hipSuccess &&
+           hipStreamCreateWithFlags(&c->pstream[2 * p + 1], hipStreamNonBlocking) == hipSuccess;
+  }
+  if (const char* e = getenv("AVSEP_SPLIT")) c->split = atoi(e);
+  if (const char* e = getenv("AVSEP_TAIL_SPLIT")) c->tail_split = atoi(e) != 0;
+  c->no_fused_conv = getenv("AVSEP_NO_FUSED_CONV") != nullptr;
   if (!ok) { avsep_destroy(c); return fail(AVSEP_EHIP, "stream/event creation failed"); }
   *out = c;
   return AVSEP_OK;
@@ -575,6 +726,14 @@ void avsep_destroy(avsep_ctx* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_gin) (void)hipEventDestroy(c->ev_gin);
   if (c->ev_gout) (void)hipEventDestroy(c->ev_gout);
+  for (int p = 0; p < avsep_ctx::MAX_SPLIT; ++p) {
+    if (c->ev_vdone[p]) (void)hipEventDestroy(c->ev_vdone[p]);
+    if (c->ev_pdone[p]) (void)hipEventDestroy(c->ev_pdone[p]);
+    if (c->ev_adone[p]) (void)hipEventDestroy(c->ev_adone[p]);
+    if (c->ev_tdone[p]) (void)hipEventDestroy(c->ev_tdone[p]);
+    if (c->pstream[2 * p]) (void)hipStreamDestroy(c->pstream[2 * p]);
+    if (c->pstream[2 * p + 1]) (void)hipStreamDestroy(c->pstream[2 * p + 1]);
+  }
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->gstream) (void)hipStreamDestroy(c->gstream);
   if (c->arena) (void)hipFree(c->arena);
@@ -731,7 +890,12 @@ int avsep_finalize_weights(avsep_ctx* c, void* stream) {
 
 size_t avsep_workspace_bytes(const avsep_ctx* c, int B, int T, int N, int H, int W) {
   if (!c || B <= 0 || T <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
-  return carve(c, nullptr, nullptr, B, T, N, H, W) * sizeof(float);
+  size_t need = carve(c, nullptr, nullptr, B, T, N, H, W);          // unsplit layout (taps / profiler / stages)
+  for (int P = 2; P <= avsep_ctx::MAX_SPLIT; ++P) {
+    const size_t n = carve_all(c, P < B ? P : B, nullptr, nullptr, B, T, N, H, W);
+    if (n > need) need = n;
+  }
+  return need * sizeof(float);
 }
 
 int avsep_forward(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
@@ -812,7 +976,7 @@ int avsep_fusion(avsep_ctx* c, const float* audio, const float* visual, float* o
   c->taps.clear(); c->tap_cursor = 0;
   HCK(hipMemcpyAsync(w.a_x, audio, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
   RCK(fusion_kv(c, w, visual, B, T, s));
-  RCK(fusion_layers(c, w, w.a_x, B, T, s));
+  RCK(fusion_layers(c, w, w.a_x, B, T, s, /*final_norm=*/true));
   HCK(hipMemcpyAsync(out, w.ln, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
   return AVSEP_OK;
 }
@@ -827,7 +991,7 @@ int avsep_decoder(avsep_ctx* c, const float* fused, const float* mixed, float* m
   if (ws_bytes < carve(c, &w, reinterpret_cast<float*>(ws), B, T, 1, 1, 1) * sizeof(float))
     return fail(AVSEP_ENOMEM, "workspace too small");
   if (mixed) HCK(launch_transpose_pad(mixed, w.xt, B, c->F, T, c->Fp, s));
-  RCK(decoder_stage(c, w, fused, masks, sep, B, T, s));
+  RCK(decoder_stage(c, w, fused, masks, sep, B, T, s, /*fuse_norm=*/false));
   return AVSEP_OK;
 }
 

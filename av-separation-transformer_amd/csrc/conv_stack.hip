@@ -1,0 +1,290 @@
+// conv_stack.hip -- the visual front-end fused into one kernel:
+//   3 x [Conv2d(k3,s2,p1) -> BatchNorm2d(eval) -> ReLU]  (1->32->64->128 channels)  -> AdaptiveAvgPool2d(1)
+// (VisualEncoder.conv, model.py:81-92) for G lip frames per workgroup pass, with every intermediate
+// activation kept in LDS: the only HBM traffic is the frames in (H*W*4 B each) and 128 floats out per frame,
+// instead of writing and re-reading act1 (52 MB) / act2 (26 MB) / act3 (13 MB) per 32-clip batch.
+//
+//   phase 1  conv1 (Cin = 1: 9 MACs per output) on the VALU, channels-last into a zero-haloed LDS image
+//   phase 2  conv2 as an implicit GEMM on the fp32 matrix cores: rows = output positions of the G frames,
+//            K = 9 taps x 32 ch; A fragments are ds_read_b128 gathers from the haloed image (no predication),
+//            W fragments stream from L2 (each wave owns 16 of the 64 output channels, so a workgroup reads
+//            the 73 KB of conv2 weights once per pass); bias+ReLU -> second haloed LDS image
+//   phase 3  conv3 the same way (K = 9 x 64, each wave owns 32 of the 128 channels), then the epilogue
+//            averages the valid positions of each frame in registers/shuffles and stores 128 floats.
+//
+// BatchNorm is folded into the conv weights/bias by the packer (avsep_api.hip).  Pixel stride in LDS is
+// C+4 floats so neighbouring positions fall on different banks for the b128 gathers.
+#include "kernels.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int C1 = 32, C2 = 64, C3 = 128;
+constexpr int C1P = C1 + 4, C2P = C2 + 4;   // padded pixel strides (floats)
+
+struct ConvStackParams {
+  const float* frames;   // (Mv, H, W)
+  const float* w1;       // [9][32]
+  const float* b1;       // [32]
+  const float* w2;       // [64][9][32]
+  const float* b2;       // [64]
+  const float* w3;       // [128][9][64]
+  const float* b3;       // [128]
+  float* pooled;         // (Mv, 128)
+  int Mv, H, W, H1, W1, H2, W2, H3, W3;
+  int a1_frame, a2_frame;   // floats per frame image incl. halo
+};
+
+// RB2 / RB3: 16-row MFMA blocks of the conv2 / conv3 output rows, COMPILE-TIME so the accumulator arrays stay in
+// registers with no per-block predication (a runtime "if (i < rb)" around each MFMA made hipcc shuffle the whole
+// accumulator file through v_accvgpr moves: 300k VALU instructions per wave, 10x slower).  Rows past the valid
+// range read row 0's window and are simply not stored.
+// NW = wavefronts per workgroup (4 or 8).  With 8, two waves share each SIMD so one wave's LDS gathers / weight
+// loads / barriers hide behind the other's MFMAs: conv2 rows are split in two halves (waves 0-3 / 4-7, each wave
+// still owning 16 output channels), conv3 gives every wave 16 of the 128 channels.
+template <int G, int RB2, int RB3MAX, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackParams p) {
+  constexpr int NT = 64 * NW;
+  constexpr int RSPLIT = NW / 4;                       // conv2 row halves
+  constexpr int RB2MAX = (RB2 + RSPLIT - 1) / RSPLIT;  // conv2 row blocks per wave
+  constexpr int CB3 = 8 / NW;                          // conv3 16-channel blocks per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* a1 = lds;                         // G x (H1+2) x (W1+2) x C1P
+  float* a2 = lds + G * p.a1_frame;        // G x (H2+2) x (W2+2) x C2P
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 15;
+  const int q = lane >> 4;
+  const int P1 = p.H1 * p.W1, P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
+  const int s1w = p.W1 + 2, s2w = p.W2 + 2;
+
+  // zero both images once: the halo is never written again
+  for (int i = tid * 4; i < G * (p.a1_frame + p.a2_frame); i += 4 * NT)
+    *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ngroups = (p.Mv + G - 1) / G;
+
+  // per-lane LDS base offsets of the 3x3 window origin of each output row (row = 16*rb + c)
+  const int cb2 = wave & 3;                 // conv2 column block of this wave
+  const int rb2_0 = (wave >> 2) * RB2MAX;   // first conv2 row block of this wave
+  int base2[RB2MAX], base3[RB3MAX];
+#pragma unroll
+  for (int i = 0; i < RB2MAX; ++i) {
+    int m = 16 * (rb2_0 + i) + c;
+    m = m < G * P2 ? m : 0;
+    const int g = m / P2, pos = m - g * P2;
+    const int y = pos / p.W2, x = pos - y * p.W2;
+    base2[i] = g * p.a1_frame + ((2 * y) * s1w + 2 * x) * C1P + 4 * q;
+  }
+#pragma unroll
+  for (int i = 0; i < RB3MAX; ++i) {
+    int m = 16 * i + c;
+    m = m < G * P3 ? m : 0;
+    const int g = m / P3, pos = m - g * P3;
+    const int y = pos / p.W3, x = pos - y * p.W3;
+    base3[i] = g * p.a2_frame + ((2 * y) * s2w + 2 * x) * C2P + 4 * q;
+  }
+  // weights of this wave's output channels: conv2 col-block cb2, conv3 col-blocks CB3*wave .. CB3*wave+CB3-1
+  const float* w2l = p.w2 + (size_t)(16 * cb2 + c) * 9 * C1 + 4 * q;
+  const int ch3 = 16 * CB3 * wave + c;      // first conv3 channel of this lane
+  const float* w3l0 = p.w3 + (size_t)ch3 * 9 * C2 + 4 * q;
+  const float* w3l1 = w3l0 + (size_t)(CB3 > 1 ? 16 : 0) * 9 * C2;
+  const float bias2 = p.b2[16 * cb2 + c];
+  const float bias3_0 = p.b3[ch3], bias3_1 = p.b3[ch3 + (CB3 > 1 ? 16 : 0)];
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int f0 = grp * G;
+    __syncthreads();   // previous pass done with a1/a2 (and the zero fill on the first pass)
+
+    // ---------------- phase 1: conv1 + BN + ReLU on the VALU -> a1 interior ----------------------------
+    for (int idx = tid; idx < G * P1 * 8; idx += NT) {
+      const int cq = idx & 7;
+      const int px = idx >> 3;
+      const int g = px / P1, pos = px - g * P1;
+      const int y = pos / p.W1, x = pos - y * p.W1;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(p.b1 + 4 * cq);
+      if (f0 + g < p.Mv) {
+        const float* fr = p.frames + (size_t)(f0 + g) * p.H * p.W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = 2 * y - 1 + ky;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * x - 1 + kx;
+            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float v = ok ? fr[iy * p.W + ix] : 0.0f;
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w1 + (ky * 3 + kx) * C1 + 4 * cq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, w4[e], acc[e]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.0f);
+      } else {
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      *reinterpret_cast<f32x4*>(a1 + g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * cq) = acc;
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: conv2 implicit GEMM, wave owns output channels [16*wave, 16*wave+16) -----
+    {
+      f32x4 acc[RB2MAX];
+#pragma unroll
+      for (int i = 0; i < RB2MAX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 bw = *reinterpret_cast<const f32x4*>(w2l);
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int toff = (ky * s1w + kx) * C1P;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const f32x4 b = bw;
+          const int nxt = tap * 2 + s + 1;
+          if (nxt < 18) bw = *reinterpret_cast<const f32x4*>(w2l + (nxt >> 1) * C1 + (nxt & 1) * 16);
+          f32x4 fa[RB2MAX];
+#pragma unroll
+          for (int i = 0; i < RB2MAX; ++i)
+            fa[i] = *reinterpret_cast<const f32x4*>(a1 + base2[i] + toff + 16 * s);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < RB2MAX; ++i)
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], b[e], acc[i], 0, 0, 0);
+        }
+      }
+      // bias + ReLU -> a2 interior (C/D: col = c -> channel 16*wave+c, row = 4q + r -> position)
+#pragma unroll
+      for (int i = 0; i < RB2MAX; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * (rb2_0 + i) + 4 * q + r;
+          if (m < G * P2) {
+            const int g = m / P2, pos = m - g * P2;
+            const int y = pos / p.W2, x = pos - y * p.W2;
+            a2[g * p.a2_frame + ((y + 1) * s2w + (x + 1)) * C2P + 16 * cb2 + c] = fmaxf(acc[i][r] + bias2, 0.0f);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: conv3 implicit GEMM + average pool, wave owns 32 output channels -------
+    {
+      f32x4 acc0[RB3MAX], acc1[RB3MAX];
+#pragma unroll
+      for (int i = 0; i < RB3MAX; ++i) acc0[i] = acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 bw0 = *reinterpret_cast<const f32x4*>(w3l0);
+      f32x4 bw1 = *reinterpret_cast<const f32x4*>(w3l1);
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int toff = (ky * s2w + kx) * C2P;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const f32x4 b0 = bw0, b1 = bw1;
+          const int nxt = tap * 4 + s + 1;
+          if (nxt < 36) {
+            bw0 = *reinterpret_cast<const f32x4*>(w3l0 + (nxt >> 2) * C2 + (nxt & 3) * 16);
+            if constexpr (CB3 > 1) bw1 = *reinterpret_cast<const f32x4*>(w3l1 + (nxt >> 2) * C2 + (nxt & 3) * 16);
+          }
+          f32x4 fa[RB3MAX];
+#pragma unroll
+          for (int i = 0; i < RB3MAX; ++i)
+            fa[i] = *reinterpret_cast<const f32x4*>(a2 + base3[i] + toff + 16 * s);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < RB3MAX; ++i) {
+              acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], b0[e], acc0[i], 0, 0, 0);
+              if constexpr (CB3 > 1) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], b1[e], acc1[i], 0, 0, 0);
+            }
+        }
+      }
+      // bias + ReLU, then the mean over each frame's P3 positions (rows g*P3 .. (g+1)*P3-1)
+      const float invp = 1.0f / (float)P3;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < RB3MAX; ++i) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * i + 4 * q + r;
+            const bool in = (m >= g * P3) && (m < (g + 1) * P3);
+            s0 += in ? fmaxf(acc0[i][r] + bias3_0, 0.0f) : 0.0f;
+            s1 += in ? fmaxf(acc1[i][r] + bias3_1, 0.0f) : 0.0f;
+          }
+        }
+        s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        if (q == 0 && f0 + g < p.Mv) {
+          p.pooled[(size_t)(f0 + g) * C3 + ch3] = s0 * invp;
+          if constexpr (CB3 > 1) p.pooled[(size_t)(f0 + g) * C3 + ch3 + 16] = s1 * invp;
+        }
+      }
+    }
+  }
+}
+
+inline int conv_out(int x) { return (x - 1) / 2 + 1; }
+
+template <int G, int RB2, int RB3, int NW>
+hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) {
+  auto kern = conv_stack_kernel<G, RB2, RB3, NW>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  const int ngroups = (p.Mv + G - 1) / G;
+  const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;
+  int grid = 256 * (per_cu > 2 ? 2 : per_cu);
+  if (grid > ngroups) grid = ngroups;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, s, p);
+  return hipGetLastError();
+}
+
+template <int G, int RB2, int RB3>
+hipError_t launch_cs(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) {
+  static const bool four = getenv("AVSEP_CONV_NW4") != nullptr;   // developer A/B switch
+  if (four) return launch_cs_nw<G, RB2, RB3, 4>(p, lds_bytes, s);
+  return launch_cs_nw<G, RB2, RB3, 8>(p, lds_bytes, s);
+}
+
+}  // namespace
+
+// Returns hipErrorNotSupported when the frame size does not fit the fused kernel's LDS / register tiling
+// (the caller then takes the unfused conv1 + implicit-GEMM path).
+hipError_t launch_conv_stack(const float* frames, const float* w1, const float* b1, const float* w2,
+                             const float* b2, const float* w3, const float* b3, float* pooled, int Mv, int H,
+                             int W, hipStream_t s) {
+  if (Mv <= 0 || H <= 0 || W <= 0) return hipErrorInvalidValue;
+  ConvStackParams p{};
+  p.frames = frames; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.pooled = pooled;
+  p.Mv = Mv; p.H = H; p.W = W;
+  p.H1 = conv_out(H); p.W1 = conv_out(W);
+  p.H2 = conv_out(p.H1); p.W2 = conv_out(p.W1);
+  p.H3 = conv_out(p.H2); p.W3 = conv_out(p.W2);
+  p.a1_frame = (p.H1 + 2) * (p.W1 + 2) * C1P;
+  p.a2_frame = (p.H2 + 2) * (p.W2 + 2) * C2P;
+  const int P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
+  const size_t frame_bytes = (size_t)(p.a1_frame + p.a2_frame) * sizeof(float);
+  const size_t LDS_MAX = 160 * 1024;
+  static const bool force_g1 = getenv("AVSEP_CONV_G1") != nullptr;   // developer A/B switch
+  // Instantiations (G frames per pass, conv2 row blocks, conv3 row blocks); the smallest one that covers the
+  // frame size is used -- surplus row blocks recompute row 0 and are discarded.  Two frames per pass halve the
+  // weight traffic per frame.
+  const int r2g2 = (2 * P2 + 15) / 16, r3g2 = (2 * P3 + 15) / 16, r2 = (P2 + 15) / 16, r3 = (P3 + 15) / 16;
+  if (!force_g1 && 2 * frame_bytes <= LDS_MAX && Mv > 1) {
+    if (r2g2 <= 1 && r3g2 <= 1) return launch_cs<2, 1, 1>(p, 2 * frame_bytes, s);
+    if (r2g2 <= 2 && r3g2 <= 1) return launch_cs<2, 2, 1>(p, 2 * frame_bytes, s);
+    if (r2g2 <= 4 && r3g2 <= 1) return launch_cs<2, 4, 1>(p, 2 * frame_bytes, s);
+    if (r2g2 <= 8 && r3g2 <= 2) return launch_cs<2, 8, 2>(p, 2 * frame_bytes, s);
+  }
+  if (frame_bytes > LDS_MAX) return hipErrorNotSupported;
+  if (r2 <= 1 && r3 <= 1) return launch_cs<1, 1, 1>(p, frame_bytes, s);
+  if (r2 <= 4 && r3 <= 1) return launch_cs<1, 4, 1>(p, frame_bytes, s);
+  if (r2 <= 9 && r3 <= 3) return launch_cs<1, 9, 3>(p, frame_bytes, s);
+  if (r2 <= 12 && r3 <= 4) return launch_cs<1, 12, 4>(p, frame_bytes, s);
+  return hipErrorNotSupported;
+}

@@ -4,19 +4,22 @@
 //   nn.Linear           model.py:93,155-161,195,198 and the in/out projections of MultiheadAttention
 //   nn.Conv1d k3 p1     model.py:38,40   as ONE GEMM with K = 3*Cin over a 3-tap shifted A view
 //   nn.Conv2d k3 s2 p1  model.py:85,88   as an implicit GEMM (im2col gather done by the staging loads)
+//   nn.LayerNorm        fused as an A-operand prologue of the Linear it feeds (gemm_ln_kernel)
 //
 // Design (CDNA4):
 //   * v_mfma_f32_16x16x4_f32: exact fp32 FMA chain at 256 FLOP/clk/CU -- the only matrix path that keeps
 //     masks within 1e-4 of the fp32 reference (bf16/fp16 miss it, SURVEY.md §7 "Precision").
 //   * 256 threads = 4 wavefronts in a 2x2 grid; wave tile (BM/2)x(BN/2) made of 16x16 MFMA blocks.
-//   * K is walked in chunks of 32 floats.  A and W chunks are staged global -> registers -> LDS with
-//     128-byte-row coalesced float4 loads (issued one chunk ahead of the MFMAs that hide them) and a
+//   * K is walked in chunks of BK floats.  A and W chunks are staged global -> registers -> LDS with
+//     full-row coalesced float4 loads (a small register ring issued ahead of the MFMAs) and a
 //     double-buffered LDS image, one barrier per chunk.
-//   * LDS image [row][32] with the 16-byte slot index XOR-swizzled by (row>>1)&7, which makes both the
-//     ds_write_b128 of the staging pass and the ds_read_b128 fragment reads bank-conflict free.
+//   * LDS image [row][BK] with the 16-byte slot index XOR-swizzled by the row, which makes both the
+//     ds_write_b128 of the staging pass and the ds_read_b128 fragment reads bank-conflict free
+//     (SQ_LDS_BANK_CONFLICT = 0 measured).
 //   * k-permutation trick: lane (r=l&15, q=l>>4) reads ONE float4 = k {16s+4q .. 16s+4q+3} of its row and
 //     feeds component j to MFMA j; A and W use the same permutation so the contraction is unchanged and
 //     every fragment read is a single ds_read_b128.
+//   * XCD-aware tile order (each of the 8 XCDs has a private L2): XCD x owns a contiguous range of A rows.
 //   * Epilogue fused: bias, ReLU / erf-GELU / sigmoid, residual or positional-encoding add, and the
 //     sigmoid-mask * mixed product of SeparationDecoder (model.py:207,220) with both outputs written
 //     in the reference's (B,T,S,F) memory order.
@@ -35,172 +38,23 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int BM, int BN, int AMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-  constexpr int D = (BM + BN >= 256) ? 2 : 4;   // prefetch ring depth (even); the biggest tile keeps VGPRs < 256
-  constexpr int WBM = BM / 32;   // 16-row MFMA blocks per wave
-  constexpr int WBN = BN / 32;   // 16-col MFMA blocks per wave
-  constexpr int APASS = BM / 32; // staging passes of 32 rows (256 threads x float4 = 32 rows x 128 B)
-  constexpr int BPASS = BN / 32;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * 32];
-  float* As = lds;
-  float* Bs = lds + 2 * BM * 32;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nbn = (p.N + BN - 1) / BN;
-  const int bm = blockIdx.x / nbn;
-  const int bn = blockIdx.x - bm * nbn;
-  const int m0 = bm * BM, n0 = bn * BN;
-
-  // ---- staging coordinates: thread -> (row srow + 32*pass, 16-byte slot schunk) -------------------
-  const int srow = tid >> 3;
-  const int schunk = tid & 7;
-  const float* a_src[APASS];
-  int a_aux0[APASS], a_aux1[APASS];   // TAPS3: t index;  CONV2D: iy0, ix0
-#pragma unroll
-  for (int i = 0; i < APASS; ++i) {
-    int m = m0 + srow + 32 * i;
-    m = m < p.M ? m : p.M - 1;
-    if (AMODE == AMODE_PLAIN) {
-      a_src[i] = p.A + (size_t)m * p.lda + 4 * schunk;
-      a_aux0[i] = a_aux1[i] = 0;
-    } else if (AMODE == AMODE_TAPS3) {
-      a_src[i] = p.A + (size_t)m * p.lda + 4 * schunk;
-      a_aux0[i] = m % p.T;
-      a_aux1[i] = 0;
-    } else {
-      const int hw = p.Hout * p.Wout;
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int y = rem / p.Wout;
-      const int x = rem - y * p.Wout;
-      a_src[i] = p.A + (size_t)img * p.Hin * p.Win * p.Kt + 4 * schunk;
-      a_aux0[i] = 2 * y - 1;
-      a_aux1[i] = 2 * x - 1;
-    }
+// Workgroups are dealt round-robin over the 8 XCDs, each with a private L2, so in launch order every XCD
+// would touch every A row block and pull its own copy through the fabric.  Remap (bijective for any grid
+// size) so XCD x owns a contiguous range of tiles = a contiguous range of A rows: A crosses the fabric once
+// instead of 8 times; only W is shared by all XCDs.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_tile(const GemmParams& p) {
+  int tile = blockIdx.x;
+  if (!p.no_xcd_remap) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
   }
-  const float* b_src[BPASS];
-#pragma unroll
-  for (int i = 0; i < BPASS; ++i) {
-    int n = n0 + srow + 32 * i;
-    n = n < p.N ? n : p.N - 1;
-    b_src[i] = p.W + (size_t)n * p.ldw + 4 * schunk;
-  }
-  // swizzled LDS float offset of this thread's staging slot (same for every pass up to +32 rows: the
-  // swizzle uses (row>>1)&7 and 32 rows keep it unchanged)
-  const int st_off = srow * 32 + ((schunk ^ ((srow >> 1) & 7)) << 2);
+  return tile;
+}
 
-  const int nk = p.K >> 5;
-  const int cpt = (AMODE == AMODE_PLAIN) ? nk : (p.Kt >> 5);   // chunks per tap
-  int tap = 0, sub = 0;                                        // (tap, chunk-in-tap) of the NEXT chunk to load
-  int kload = 0;                                               // index of the next chunk to load (saturates at nk-1)
-
-  // D-deep register ring: the global loads of chunk kc+D are issued while chunk kc is being multiplied, so
-  // D-1 chunks of MFMA time cover one L2 / Infinity-Cache / HBM round trip (measured ~2k cycles per chunk
-  // exposed with a 1-deep prefetch at one workgroup per CU: profiles/r01_*).  fp32 MFMA leaves the VGPR file
-  // nearly empty, so the ring is free.  Loads are unconditional (the chunk index saturates) to keep the
-  // compiler's counted vmcnt waits exact; the ring is statically indexed after unrolling.
-  f32x4 ra[D][APASS], rb[D][BPASS];
-  auto load_chunk = [&](int slot) {
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      if (AMODE == AMODE_PLAIN) {
-        ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + (kload << 5));
-      } else if (AMODE == AMODE_TAPS3) {
-        const int t = a_aux0[i] + tap - 1;
-        const bool ok = (t >= 0) && (t < p.T);
-        const float* src = a_src[i] + (ptrdiff_t)(tap - 1) * p.lda + (sub << 5);
-        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-      } else {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const int iy = a_aux0[i] + ky, ix = a_aux1[i] + kx;
-        const bool ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
-        const float* src = a_src[i] + ((size_t)(ok ? iy : 0) * p.Win + (ok ? ix : 0)) * p.Kt + (sub << 5);
-        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + (kload << 5));
-    if (kload < nk - 1) {
-      ++kload;
-      if (AMODE != AMODE_PLAIN) {
-        if (++sub == cpt) { sub = 0; ++tap; }
-      }
-    }
-  };
-  auto store_chunk = [&](int slot, int buf) {
-    float* a = As + buf * BM * 32 + st_off;
-    float* b = Bs + buf * BN * 32 + st_off;
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + i * 32 * 32) = ra[slot][i];
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + i * 32 * 32) = rb[slot][i];
-  };
-
-  // ---- fragment read coordinates ----------------------------------------------------------------
-  const int fr = lane & 15;   // row inside a 16-row block (A: m, W: n)
-  const int fq = lane >> 4;   // k quarter
-  int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
-#pragma unroll
-  for (int i = 0; i < WBM; ++i) {
-    const int r = wm * (BM / 2) + 16 * i + fr;
-    a_off[i] = r * 32;
-    a_swz[i] = (r >> 1) & 7;
-  }
-#pragma unroll
-  for (int j = 0; j < WBN; ++j) {
-    const int r = wn * (BN / 2) + 16 * j + fr;
-    b_off[j] = r * 32;
-    b_swz[j] = (r >> 1) & 7;
-  }
-
-  f32x4 acc[WBM][WBN];
-#pragma unroll
-  for (int i = 0; i < WBM; ++i)
-#pragma unroll
-    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int j = 0; j < D; ++j) load_chunk(j);
-  store_chunk(0, 0);
-  __syncthreads();
-
-  for (int kc0 = 0; kc0 < nk; kc0 += D) {
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int kc = kc0 + j;
-      if (kc < nk) {                       // block-uniform
-        load_chunk(j);                     // slot j (chunk kc) went to LDS one iteration ago: refill with chunk kc+D
-        const float* a = As + (j & 1) * BM * 32;   // D is even: (kc & 1) == (j & 1)
-        const float* b = Bs + (j & 1) * BN * 32;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          f32x4 fa[WBM], fb[WBN];
-#pragma unroll
-          for (int i = 0; i < WBM; ++i)
-            fa[i] = *reinterpret_cast<const f32x4*>(a + a_off[i] + (((4 * s + fq) ^ a_swz[i]) << 2));
-#pragma unroll
-          for (int jn = 0; jn < WBN; ++jn)
-            fb[jn] = *reinterpret_cast<const f32x4*>(b + b_off[jn] + (((4 * s + fq) ^ b_swz[jn]) << 2));
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 0; i < WBM; ++i)
-#pragma unroll
-              for (int jn = 0; jn < WBN; ++jn)
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[jn][c], acc[i][jn], 0, 0, 0);
-        }
-        // chunk kc+1 (ring slot j+1, loaded D-1 iterations ago) -> the other LDS buffer
-        if (kc + 1 < nk) store_chunk((j + 1) % D, (j + 1) & 1);
-        __syncthreads();
-      }
-    }
-  }
-
-  // ---- epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg -----------------
+// Fused epilogue shared by the GEMM kernels.  C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+reg.
+template <int BM, int BN, int WBM, int WBN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], int m0, int n0,
+                                              int wm, int wn, int fr, int fq) {
 #pragma unroll
   for (int j = 0; j < WBN; ++j) {
     const int n = n0 + wn * (BN / 2) + 16 * j + fr;
@@ -227,69 +81,472 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <int BM, int BN, int AMODE>
+// One K-chunk of MFMAs from the LDS image (shared by both kernels).
+template <int BK, int WBM, int WBN>
+__device__ __forceinline__ void mfma_chunk(const float* a, const float* b, const int (&a_off)[WBM],
+                                           const int (&a_swz)[WBM], const int (&b_off)[WBN], const int (&b_swz)[WBN],
+                                           int fq, f32x4 (&acc)[WBM][WBN]) {
+#pragma unroll
+  for (int s = 0; s < BK / 16; ++s) {
+    f32x4 fa[WBM], fb[WBN];
+#pragma unroll
+    for (int i = 0; i < WBM; ++i)
+      fa[i] = *reinterpret_cast<const f32x4*>(a + a_off[i] + (((4 * s + fq) ^ a_swz[i]) << 2));
+#pragma unroll
+    for (int jn = 0; jn < WBN; ++jn)
+      fb[jn] = *reinterpret_cast<const f32x4*>(b + b_off[jn] + (((4 * s + fq) ^ b_swz[jn]) << 2));
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < WBM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < WBN; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][c], fb[jn][c], acc[i][jn], 0, 0, 0);
+  }
+}
+
+// 16-byte-slot XOR swizzle: conflict-free ds_write_b128 (8 consecutive lanes = 8 slots of one row) and
+// ds_read_b128 (16-lane groups = 16 rows x one logical slot) for 128-, 256- and 512-byte rows.
+template <int SLOTS>
+__device__ __forceinline__ int swz(int row) {
+  return SLOTS == 8 ? ((row >> 1) & 7) : (row & 15);
+}
+
+template <int BM, int BN, int BK, int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int SLOTS = BK / 4;            // 16-byte slots per LDS row
+  constexpr int RPP = 256 / SLOTS;         // rows staged per pass (256 threads x float4)
+  constexpr int APASS = BM / RPP;
+  constexpr int BPASS = BN / RPP;
+  constexpr int WBM = BM / 32;             // 16-row MFMA blocks per wave
+  constexpr int WBN = BN / 32;             // 16-col MFMA blocks per wave
+  // Register prefetch ring (even depth).  Measured on MI355X (profiles/r01b_*): neither a deeper ring nor a
+  // larger BK moves the M ~ 2k shapes -- small tiles sit at the L2 -> CU feed limit (8-11 flop per byte),
+  // big tiles lack workgroups -- so the ring stays shallow and cheap in registers.
+  constexpr int D = (APASS + BPASS <= 4) ? 4 : 2;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * BK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + BN - 1) / BN;
+  const int tile = xcd_tile(p);
+  const int bm = tile / nbn;
+  const int bn = tile - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // ---- staging coordinates: thread -> (row srow + RPP*pass, 16-byte slot sslot) -------------------
+  const int srow = tid / SLOTS;
+  const int sslot = tid % SLOTS;
+  const float* a_src[APASS];
+  int a_aux0[APASS], a_aux1[APASS];   // TAPS3: t index;  CONV2D: iy0, ix0
+  int a_st[APASS], b_st[BPASS];       // swizzled LDS float offsets of this thread's staging slots
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int r = srow + RPP * i;
+    a_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    int m = m0 + r;
+    m = m < p.M ? m : p.M - 1;
+    if (AMODE == AMODE_PLAIN) {
+      a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;
+      a_aux0[i] = a_aux1[i] = 0;
+    } else if (AMODE == AMODE_TAPS3) {
+      a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;
+      a_aux0[i] = m % p.T;
+      a_aux1[i] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int y = rem / p.Wout;
+      const int x = rem - y * p.Wout;
+      a_src[i] = p.A + (size_t)img * p.Hin * p.Win * p.Kt + 4 * sslot;
+      a_aux0[i] = 2 * y - 1;
+      a_aux1[i] = 2 * x - 1;
+    }
+  }
+  const float* b_src[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int r = srow + RPP * i;
+    b_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    b_src[i] = p.W + (size_t)n * p.ldw + 4 * sslot;
+  }
+
+  const int nk = p.K / BK;
+  const int cpt = (AMODE == AMODE_PLAIN) ? nk : (p.Kt / BK);   // chunks per tap
+  int tap = 0, sub = 0;                                        // (tap, chunk-in-tap) of the NEXT chunk to load
+  int kload = 0;                                               // index of the next chunk to load
+
+  // the ring is statically indexed after unrolling; loads past the last chunk are skipped (block-uniform)
+  f32x4 ra[D][APASS], rb[D][BPASS];
+  auto load_chunk = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      if (AMODE == AMODE_PLAIN) {
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + kload * BK);
+      } else if (AMODE == AMODE_TAPS3) {
+        const int t = a_aux0[i] + tap - 1;
+        const bool ok = (t >= 0) && (t < p.T);
+        const float* src = a_src[i] + (ptrdiff_t)(tap - 1) * p.lda + sub * BK;
+        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int iy = a_aux0[i] + ky, ix = a_aux1[i] + kx;
+        const bool ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+        const float* src = a_src[i] + ((size_t)(ok ? iy : 0) * p.Win + (ok ? ix : 0)) * p.Kt + sub * BK;
+        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + kload * BK);
+    ++kload;
+    if (AMODE != AMODE_PLAIN) {
+      if (++sub == cpt) { sub = 0; ++tap; }
+    }
+  };
+  auto store_chunk = [&](int slot, int buf) {
+    float* a = As + buf * BM * BK;
+    float* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + a_st[i]) = ra[slot][i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + b_st[i]) = rb[slot][i];
+  };
+
+  // ---- fragment read coordinates ----------------------------------------------------------------
+  const int fr = lane & 15;   // row inside a 16-row block (A: m, W: n)
+  const int fq = lane >> 4;   // k quarter
+  int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    const int r = wm * (BM / 2) + 16 * i + fr;
+    a_off[i] = r * BK;
+    a_swz[i] = swz<SLOTS>(r);
+  }
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int r = wn * (BN / 2) + 16 * j + fr;
+    b_off[j] = r * BK;
+    b_swz[j] = swz<SLOTS>(r);
+  }
+
+  f32x4 acc[WBM][WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (j < nk) load_chunk(j);
+  store_chunk(0, 0);
+  __syncthreads();
+
+  for (int kc0 = 0; kc0 < nk; kc0 += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const int kc = kc0 + j;
+      if (kc < nk) {                       // block-uniform
+        if (kc + D < nk) load_chunk(j);    // slot j (chunk kc) went to LDS one iteration ago: refill with chunk kc+D
+        // D is even: (kc & 1) == (j & 1)
+        mfma_chunk<BK, WBM, WBN>(As + (j & 1) * BM * BK, Bs + (j & 1) * BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+        // chunk kc+1 (ring slot j+1, loaded D-1 iterations ago) -> the other LDS buffer
+        if (kc + 1 < nk) store_chunk((j + 1) % D, (j + 1) & 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm-fused GEMM:  C = epilogue( LN(A) W^T )  for K = normalised width <= NKMAX*BK.
+// Every LayerNorm of the model feeds exactly one Linear (norm1 -> in_proj / q-proj, norm2 -> linear1 / ff.0,
+// fusion.norm -> decoder.0; model.py:149,168-172 and nn.TransformerEncoderLayer norm_first), so the
+// normalisation is applied to the A operand on its way to LDS and the stand-alone LayerNorm launches (13 per
+// forward, ~4.5 us each at their launch floor) disappear.  K is short (d_model), so the whole A row-slice and W
+// slice of the tile are loaded into registers up front (all loads in flight at once = one memory round trip),
+// the row statistics are computed from those registers (no second pass over A), and the chunks are then fed
+// through the same swizzled 2-buffer LDS image / MFMA loop as gemm_kernel.
+// Row statistics: shifted one-pass sums (relative to the row's first element), combined across the SLOTS
+// lanes that own the row with in-wave shuffles; biased variance, eps inside the sqrt like nn.LayerNorm.
+template <int BM, int BN, int BK, int NKMAX>
+__global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
+  constexpr int SLOTS = BK / 4;
+  constexpr int RPP = 256 / SLOTS;
+  constexpr int APASS = BM / RPP;
+  constexpr int BPASS = BN / RPP;
+  constexpr int WBM = BM / 32;
+  constexpr int WBN = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * BK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + BN - 1) / BN;
+  const int tile = xcd_tile(p);
+  const int bm = tile / nbn;
+  const int bn = tile - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int nk = p.K / BK;
+
+  const int srow = tid / SLOTS;
+  const int sslot = tid % SLOTS;
+  f32x4 ra[NKMAX][APASS], rb[NKMAX][BPASS], rg[NKMAX], rbe[NKMAX];
+  int a_st[APASS], b_st[BPASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int r = srow + RPP * i;
+    a_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    int m = m0 + r;
+    m = m < p.M ? m : p.M - 1;
+    const float* src = p.A + (size_t)m * p.lda + 4 * sslot;
+#pragma unroll
+    for (int kc = 0; kc < NKMAX; ++kc)
+      if (kc < nk) ra[kc][i] = *reinterpret_cast<const f32x4*>(src + kc * BK);
+  }
+#pragma unroll
+  for (int kc = 0; kc < NKMAX; ++kc)
+    if (kc < nk) {
+      rg[kc] = *reinterpret_cast<const f32x4*>(p.ln_gamma + kc * BK + 4 * sslot);
+      rbe[kc] = *reinterpret_cast<const f32x4*>(p.ln_beta + kc * BK + 4 * sslot);
+    }
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int r = srow + RPP * i;
+    b_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    const float* src = p.W + (size_t)n * p.ldw + 4 * sslot;
+#pragma unroll
+    for (int kc = 0; kc < NKMAX; ++kc)
+      if (kc < nk) rb[kc][i] = *reinterpret_cast<const f32x4*>(src + kc * BK);
+  }
+
+  // ---- row statistics from the registers, then normalise in place -----------------------------------
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const float c = __shfl(ra[0][i][0], lane & ~(SLOTS - 1));   // the row's first element (its sslot-0 lane)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < NKMAX; ++kc)
+      if (kc < nk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dlt = ra[kc][i][e] - c;
+          s1 += dlt;
+          s2 = fmaf(dlt, dlt, s2);
+        }
+      }
+#pragma unroll
+    for (int off = SLOTS / 2; off >= 1; off >>= 1) {
+      s1 += __shfl_xor(s1, off);
+      s2 += __shfl_xor(s2, off);
+    }
+    const float inv = 1.0f / (float)p.K;
+    const float m1 = s1 * inv;
+    const float var = fmaxf(s2 * inv - m1 * m1, 0.0f);
+    const float mu = c + m1;
+    const float rs = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+    for (int kc = 0; kc < NKMAX; ++kc)
+      if (kc < nk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[kc][i][e] = (ra[kc][i][e] - mu) * rs * rg[kc][e] + rbe[kc][e];
+      }
+  }
+
+  auto store_chunk = [&](int kc, int buf) {
+    float* a = As + buf * BM * BK;
+    float* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + a_st[i]) = ra[kc][i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + b_st[i]) = rb[kc][i];
+  };
+
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    const int r = wm * (BM / 2) + 16 * i + fr;
+    a_off[i] = r * BK;
+    a_swz[i] = swz<SLOTS>(r);
+  }
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int r = wn * (BN / 2) + 16 * j + fr;
+    b_off[j] = r * BK;
+    b_swz[j] = swz<SLOTS>(r);
+  }
+  f32x4 acc[WBM][WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  store_chunk(0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int kc = 0; kc < NKMAX; ++kc) {
+    if (kc < nk) {   // block-uniform
+      mfma_chunk<BK, WBM, WBN>(As + (kc & 1) * BM * BK, Bs + (kc & 1) * BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+      if (kc + 1 < NKMAX) {
+        if (kc + 1 < nk) store_chunk(kc + 1, (kc + 1) & 1);
+      }
+      __syncthreads();
+    }
+  }
+
+  gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+}
+
+template <int BM, int BN, int BK, int AMODE>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, AMODE>), dim3(nbm * nbn), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE>), dim3(nbm * nbn), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
-struct Tile { int bm, bn; };
+struct Tile { int bm, bn, bk; };
 
-// Pick the block tile that minimises (rounds over 256 CUs) x (tile work) x (operand-reuse penalty).
-// At the small M of batch-32 inference (M = B*T = 2016) the big tiles leave most CUs idle, so the
-// choice matters more than the inner loop (DESIGN.md "tile selection").
-Tile pick_tile(int M, int N, int amode) {
-  // developer override for hardware sweeps (tools/gemm_sweep.py): AVSEP_GEMM_TILE=BMxBN
+// Block tile and K-chunk for one launch.
+//  * (BM,BN): measured on MI355X (tools/gemm_sweep.py, profiles/r01a_gemm_tile_sweep.txt): what decides the
+//    time at M ~ 2k is how many workgroups are resident.  Take the largest tile that still gives >= 4
+//    workgroups per CU, else >= 2, else the smallest tile.
+//  * BK: 64 where it divides K (and the per-tap K of the conv modes) and the tile is small, else 32
+//    (profiles/r01b_gemm_tile_sweep.txt: BK changes little; 64 halves the barriers of the small tiles).
+Tile pick_tile(const GemmParams& p) {
+  // developer override for hardware sweeps (tools/gemm_sweep.py): AVSEP_GEMM_TILE=BMxBNxBK
   if (const char* e = getenv("AVSEP_GEMM_TILE")) {
-    Tile t{0, 0};
-    if (sscanf(e, "%dx%d", &t.bm, &t.bn) == 2) return t;
+    Tile t{0, 0, 32};
+    if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
   }
-  // Measured on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt): with fp32 MFMA the inner loop is
-  // cheap to feed, so what decides the time at M ~ 2k is how many workgroups are resident to hide the
-  // staging latency.  Take the largest tile that still gives >= 4 workgroups per CU, else >= 2, else the
-  // smallest tile.
-  static const Tile cands[] = {{128, 64}, {64, 64}, {64, 32}, {32, 32}};
-  auto blocks = [&](const Tile& t) { return (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn); };
+  if (p.amode == AMODE_CONV2D) {
+    if (const char* e = getenv("AVSEP_CONV_TILE")) {   // developer override: AVSEP_CONV_TILE=BMxBNxBK
+      Tile t{0, 0, 32};
+      if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
+    }
+  }
+  static const Tile cands[] = {{128, 64, 32}, {64, 64, 32}, {64, 32, 32}, {32, 32, 32}};
+  auto blocks = [&](const Tile& t) { return (long)((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn); };
+  Tile pick{32, 32, 32};
+  bool found = false;
   for (long need : {1024L, 512L})
     for (const Tile& t : cands)
-      if (blocks(t) >= need) return t;
-  return Tile{32, 32};
+      if (!found && blocks(t) >= need) { pick = t; found = true; }
+  const int kunit = p.amode == AMODE_PLAIN ? p.K : p.Kt;   // a chunk must not straddle a tap
+  if (pick.bm + pick.bn <= 96 && kunit % 64 == 0) pick.bk = 64;
+  return pick;
+}
+
+// LN-fused launch.  BK = 64 (or 32 when d % 64 != 0) and the whole K (<= 8 chunks) in registers; the 64-row /
+// 64-column tiles are only instantiated for <= 4 chunks (d_model <= 256), where they fit the register file.
+bool ln_fusable(const GemmParams& p) {
+  if (!p.ln_gamma || !p.ln_beta || p.amode != AMODE_PLAIN) return false;
+  const int bk = (p.K % 64 == 0) ? 64 : 32;
+  return p.K / bk <= 8;
+}
+
+Tile pick_ln_tile(const GemmParams& p) {
+  const int bk = (p.K % 64 == 0) ? 64 : 32;
+  if (const char* e = getenv("AVSEP_LN_TILE")) {   // developer override: AVSEP_LN_TILE=BMxBN
+    Tile t{32, 32, bk};
+    if (sscanf(e, "%dx%d", &t.bm, &t.bn) == 2) return t;
+  }
+  Tile pick{32, 32, bk};
+  if (bk == 64 && p.K / bk <= 4) {
+    static const Tile cands[] = {{64, 64, 64}, {64, 32, 64}};
+    auto blocks = [&](const Tile& t) { return (long)((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn); };
+    bool found = false;
+    for (long need : {1024L, 512L})
+      for (const Tile& t : cands)
+        if (!found && blocks(t) >= need) { pick = t; found = true; }
+  }
+  return pick;
+}
+
+template <int BM, int BN, int BK, int NKMAX>
+hipError_t launch_ln_t(const GemmParams& p, hipStream_t s) {
+  const int nb = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, BK, NKMAX>), dim3(nb), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
+  const Tile t = pick_ln_tile(p);
+  const int nk = p.K / t.bk;
+  if (t.bk == 64) {
+    if (t.bm == 64 && t.bn == 64 && nk <= 4) return launch_ln_t<64, 64, 64, 4>(p, s);
+    if (t.bm == 64 && t.bn == 32 && nk <= 4) return launch_ln_t<64, 32, 64, 4>(p, s);
+    if (nk <= 4) return launch_ln_t<32, 32, 64, 4>(p, s);
+    return launch_ln_t<32, 32, 64, 8>(p, s);
+  }
+  if (nk <= 4) return launch_ln_t<32, 32, 32, 4>(p, s);
+  return launch_ln_t<32, 32, 32, 8>(p, s);
 }
 
 }  // namespace
 
+bool gemm_ln_supported(int K) {
+  static const float dummy = 0.f;
+  GemmParams p{};
+  p.K = K;
+  p.amode = AMODE_PLAIN;
+  p.ln_gamma = p.ln_beta = &dummy;
+  return ln_fusable(p);
+}
+
 const char* gemm_instance_name(const GemmParams& p) {
   static thread_local char buf[64];
-  const Tile t = pick_tile(p.M, p.N, p.amode);
-  snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d>", t.bm, t.bn, p.amode);
+  if (p.ln_gamma) {
+    const Tile t = pick_ln_tile(p);
+    snprintf(buf, sizeof buf, "gemm_ln_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.K / t.bk <= 4 ? 4 : 8);
+    return buf;
+  }
+  const Tile t = pick_tile(p);
+  snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.amode);
   return buf;
 }
 
-hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
+hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
+  GemmParams p = p_in;
+  static const bool no_remap = getenv("AVSEP_NO_XCD_REMAP") != nullptr;   // developer A/B switch
+  p.no_xcd_remap = no_remap ? 1 : 0;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 31)) return hipErrorInvalidValue;
-  const Tile t = pick_tile(p.M, p.N, p.amode);
-#define AVSEP_CASE(BM_, BN_, AM_) \
-  if (t.bm == BM_ && t.bn == BN_ && p.amode == AM_) return launch_t<BM_, BN_, AM_>(p, s);
-  AVSEP_CASE(128, 128, AMODE_PLAIN)
-  AVSEP_CASE(128, 64, AMODE_PLAIN)
-  AVSEP_CASE(64, 128, AMODE_PLAIN)
-  AVSEP_CASE(64, 64, AMODE_PLAIN)
-  AVSEP_CASE(64, 32, AMODE_PLAIN)
-  AVSEP_CASE(32, 64, AMODE_PLAIN)
-  AVSEP_CASE(32, 32, AMODE_PLAIN)
-  AVSEP_CASE(128, 128, AMODE_TAPS3)
-  AVSEP_CASE(128, 64, AMODE_TAPS3)
-  AVSEP_CASE(64, 128, AMODE_TAPS3)
-  AVSEP_CASE(64, 64, AMODE_TAPS3)
-  AVSEP_CASE(64, 32, AMODE_TAPS3)
-  AVSEP_CASE(32, 32, AMODE_TAPS3)
-  AVSEP_CASE(128, 128, AMODE_CONV2D)
-  AVSEP_CASE(128, 64, AMODE_CONV2D)
-  AVSEP_CASE(64, 128, AMODE_CONV2D)
-  AVSEP_CASE(64, 64, AMODE_CONV2D)
-  AVSEP_CASE(64, 32, AMODE_CONV2D)
-  AVSEP_CASE(32, 32, AMODE_CONV2D)
+  if (p.amode != AMODE_PLAIN && (p.Kt <= 0 || (p.Kt & 31))) return hipErrorInvalidValue;
+  if (p.ln_gamma) {
+    if (!ln_fusable(p)) return hipErrorInvalidValue;   // callers check gemm_ln_supported() first
+    return launch_gemm_ln(p, s);
+  }
+  const Tile t = pick_tile(p);
+  if (p.K % t.bk) return hipErrorInvalidValue;
+#define AVSEP_CASE(BM_, BN_, BK_, AM_) \
+  if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
+#define AVSEP_MODES(BM_, BN_, BK_) \
+  AVSEP_CASE(BM_, BN_, BK_, AMODE_PLAIN) AVSEP_CASE(BM_, BN_, BK_, AMODE_TAPS3) AVSEP_CASE(BM_, BN_, BK_, AMODE_CONV2D)
+  AVSEP_MODES(128, 64, 32)
+  AVSEP_MODES(64, 64, 32)
+  AVSEP_MODES(64, 64, 64)
+  AVSEP_MODES(64, 32, 32)
+  AVSEP_MODES(64, 32, 64)
+  AVSEP_MODES(32, 32, 32)
+  AVSEP_MODES(32, 32, 64)
+  AVSEP_CASE(32, 32, 128, AMODE_PLAIN)
+  AVSEP_CASE(32, 32, 128, AMODE_TAPS3)
+#undef AVSEP_MODES
 #undef AVSEP_CASE
   return hipErrorInvalidValue;
 }

@@ -30,10 +30,17 @@ struct GemmParams {
   float* C2;           // mask mode (SeparationDecoder.separate, model.py:220): C2 = C * X[m][n % F]
   const float* X;
   int ldx, F;
+  int no_xcd_remap;    // developer switch: 1 = launch-order tiles (A/B measurements)
+  // Fused LayerNorm prologue (PLAIN mode, K == normalised width): A' = (A - mean_row) * rstd_row * gamma + beta,
+  // row statistics computed in-kernel by a pre-pass over the block's rows (nn.LayerNorm, eps ln_eps).
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
-const char* gemm_instance_name(const GemmParams& p);   // template instance launch_gemm() will pick
+const char* gemm_instance_name(const GemmParams& p);
+bool gemm_ln_supported(int K);                          // can launch_gemm() fuse a LayerNorm over K columns?   // template instance launch_gemm() will pick
 
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int d, float eps,
                             hipStream_t s);
@@ -44,6 +51,11 @@ hipError_t launch_transpose_pad(const float* x, float* y, int B, int F, int T, i
 // first visual conv (Cin=1) + folded BN + ReLU: frames (M,H,W) -> act (M,Ho,Wo,32) channels-last
 hipError_t launch_conv1_c1(const float* frames, const float* w9x32, const float* bias32, float* out, int M,
                            int H, int W, int Ho, int Wo, hipStream_t s);
+// whole visual conv front-end (3 x conv+BN+ReLU + average pool) in one LDS-resident kernel; returns
+// hipErrorNotSupported when the frame size does not fit (callers fall back to the three launches above/below)
+hipError_t launch_conv_stack(const float* frames, const float* w1, const float* b1, const float* w2,
+                             const float* b2, const float* w3, const float* b3, float* pooled, int Mv, int H,
+                             int W, hipStream_t s);
 // mean over P positions: x (M,P,C) -> y (M,C)
 hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event leg (roofline = path only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
 
@@ -138,13 +139,15 @@ def main():
 
         # ---- per-kernel roofline, live: eager forwards with every launch bracketed by HIP events
         prof_iters = 3
-        model.run_static(mixed, lips, masks, sep, graph=False)
-        stream.synchronize()
-        model.profile_begin()
-        for _ in range(prof_iters):
+        kernels = []
+        if not a.no_profile:
             model.run_static(mixed, lips, masks, sep, graph=False)
-        stream.synchronize()
-        kernels = model.profile_end()
+            stream.synchronize()
+            model.profile_begin()
+            for _ in range(prof_iters):
+                model.run_static(mixed, lips, masks, sep, graph=False)
+            stream.synchronize()
+            kernels = model.profile_end()
 
     gflop_clip = flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
     value = world * B * a.steps / elapsed
@@ -153,6 +156,10 @@ def main():
         k["avg_us"] = k["ms"] / k["calls"] * 1e3
         k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+    if not kernels:   # --no-profile: price the whole path only
+        kernels = [{"name": "whole forward (hipGraph)", "calls": prof_iters, "ms": ms_step * prof_iters,
+                    "flops": gflop_clip * 1e9 * B * prof_iters, "bytes": 0.0, "avg_us": ms_step * 1e3,
+                    "tflops": gflop_clip * B / ms_step, "gbs": 0.0}]
     dom = max(kernels, key=lambda k: k["ms"])
     launches_per_fwd = dom["calls"] / prof_iters
     roofline = {

@@ -4,7 +4,7 @@ workload.  Tiles are forced through the AVSEP_GEMM_TILE developer override, one 
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))
-TILES = ["128x128", "128x64", "64x128", "64x64", "64x32", "32x64", "32x32"]
+TILES = ["128x64x32", "64x64x32", "64x64x64", "64x32x32", "64x32x64", "32x32x32", "32x32x64", "32x32x128"]
 SHAPES = [(2016, 256, 256), (2016, 256, 1024), (2016, 768, 256), (2016, 1024, 256), (2016, 512, 256),
           (2016, 514, 512), (1600, 256, 256), (1600, 768, 256), (1600, 1024, 256), (1600, 256, 1024),
           (1600, 256, 128), (16064, 512, 512), (16064, 2048, 512), (16064, 512, 2048)]
@@ -43,9 +43,9 @@ if __name__ == "__main__":
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         res[t] = json.loads(line[-1]) if line else {}
         if not line: print(t, "FAILED", r.stderr[-500:])
-    print(f"{'shape':>18s} " + " ".join(f"{t:>9s}" for t in TILES + ['auto']) + "   best  TF(best)")
+    print(f"{'shape':>18s} " + " ".join(f"{t:>10s}" for t in TILES + ['auto']) + "   best  TF(best)")
     for (M, N, K) in SHAPES:
         k = f"{M}x{N}x{K}"
         vals = [res[t].get(k) for t in TILES + ["auto"]]
         best = min((v, t) for v, t in zip(vals[:-1], TILES) if v)
-        print(f"{k:>18s} " + " ".join(f"{v:9.1f}" if v else f"{'-':>9s}" for v in vals) + f"   {best[1]:>7s} {2*M*N*K/best[0]/1e6:6.1f}")
+        print(f"{k:>18s} " + " ".join(f"{v:10.1f}" if v else f"{'-':>10s}" for v in vals) + f"   {best[1]:>7s} {2*M*N*K/best[0]/1e6:6.1f}")

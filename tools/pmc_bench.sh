@@ -1,0 +1,29 @@
+#!/bin/bash
+# Developer tool (GPU box): HBM-side traffic per kernel of the bench forward (separate PMC passes, no tracing).
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph > /dev/null 2>&1
+python3 - <<'PY'
+import csv, glob, collections, os
+R=os.environ["GRAFT_REPO_ROOT"]; OUT=R+"/gpurun_out/pmc_bench"
+tot=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
+for tag in ("fetch","write","l2"):
+    f=glob.glob(f"{OUT}/{tag}/*/*counter_collection.csv")[0]
+    for r in csv.DictReader(open(f)):
+        n=r["Kernel_Name"]
+        if "anonymous" not in n: continue
+        n=n.replace("void (anonymous namespace)::","").replace("(anonymous namespace)::","").split("(")[0]
+        tot[n][r["Counter_Name"]]+=float(r["Counter_Value"])
+        if tag=="fetch": calls[n]+=1
+fw=25.0
+print(f"{'kernel':34s} {'calls/fwd':>9s} {'fetch MB/fwd (x2 corr)':>22s} {'write MB/fwd':>12s} {'L2 hit%':>8s}")
+TF=TW=0
+for n,c in sorted(tot.items(), key=lambda kv: -kv[1].get("FETCH_SIZE",0)):
+    f=c.get("FETCH_SIZE",0)*1024*2/1e6/fw; w=c.get("WRITE_SIZE",0)*1024/1e6/fw   # FETCH_SIZE in KB, x2 gfx950 correction
+    h=c.get("TCC_HIT_sum",0); m=c.get("TCC_MISS_sum",0)
+    TF+=f; TW+=w
+    print(f"{n:34s} {calls[n]/fw:9.1f} {f:22.1f} {w:12.1f} {100*h/max(1,h+m):8.1f}")
+print(f"TOTAL per forward: fetch {TF:.0f} MB (corrected x2), write {TW:.0f} MB")
+PY
