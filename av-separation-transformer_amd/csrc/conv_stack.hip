@@ -237,8 +237,11 @@ hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t 
                                      (int)lds_bytes);
   if (e != hipSuccess) return e;
   const int ngroups = (p.Mv + G - 1) / G;
-  const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;
-  int grid = 256 * (per_cu > 2 ? 2 : per_cu);
+  // One workgroup per CU: the audio branch runs concurrently on the other stream and its GEMMs need LDS too
+  // (measured: with the CUs' LDS full of conv images the two branches serialise, profiles/r01c_step_timeline.txt).
+  int per_cu = 1;
+  if (const char* e = getenv("AVSEP_CONV_WGPC")) per_cu = atoi(e) > 0 ? atoi(e) : 1;   // developer A/B switch
+  int grid = 256 * per_cu;
   if (grid > ngroups) grid = ngroups;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, s, p);
   return hipGetLastError();

@@ -278,6 +278,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // through the same swizzled 2-buffer LDS image / MFMA loop as gemm_kernel.
 // Row statistics: shifted one-pass sums (relative to the row's first element), combined across the SLOTS
 // lanes that own the row with in-wave shuffles; biased variance, eps inside the sqrt like nn.LayerNorm.
+// NK = K / BK exactly (compile time): a runtime "if (kc < nk)" around the register arrays makes hipcc copy them
+// through v_mov / v_accvgpr webs (measured 4.5 TFLOP/s on the 8-chunk variant).
 template <int BM, int BN, int BK, int NKMAX>
 __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
   constexpr int SLOTS = BK / 4;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
   const int bm = tile / nbn;
   const int bn = tile - bm * nbn;
   const int m0 = bm * BM, n0 = bn * BN;
-  const int nk = p.K / BK;
+  constexpr int nk = NKMAX;
 
   const int srow = tid / SLOTS;
   const int sslot = tid % SLOTS;
@@ -424,8 +426,7 @@ struct Tile { int bm, bn, bk; };
 
 // Block tile and K-chunk for one launch.
 //  * (BM,BN): measured on MI355X (tools/gemm_sweep.py, profiles/r01a_gemm_tile_sweep.txt): what decides the
-//    time at M ~ 2k is how many workgroups are resident.  Take the largest tile that still gives >= 4
-//    workgroups per CU, else >= 2, else the smallest tile.
+//    time at M ~ 2k is how many workgroups are resident, so small problems take small tiles.
 //  * BK: 64 where it divides K (and the per-tap K of the conv modes) and the tile is small, else 32
 //    (profiles/r01b_gemm_tile_sweep.txt: BK changes little; 64 halves the barriers of the small tiles).
 Tile pick_tile(const GemmParams& p) {
@@ -440,28 +441,31 @@ Tile pick_tile(const GemmParams& p) {
       if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
     }
   }
-  static const Tile cands[] = {{128, 64, 32}, {64, 64, 32}, {64, 32, 32}, {32, 32, 32}};
-  auto blocks = [&](const Tile& t) { return (long)((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn); };
+  // largest of {64x64, 64x32} that still gives >= 2 workgroups per CU, else 32x32; 128x64 only when even it
+  // yields >= 8 per CU (cuts L2 traffic on the very large problems; never faster than 64x64 below that)
+  auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   Tile pick{32, 32, 32};
-  bool found = false;
-  for (long need : {1024L, 512L})
-    for (const Tile& t : cands)
-      if (!found && blocks(t) >= need) { pick = t; found = true; }
+  if (blocks(128, 64) >= 2048) pick = Tile{128, 64, 32};
+  else if (blocks(64, 64) >= 512) pick = Tile{64, 64, 32};
+  else if (blocks(64, 32) >= 512) pick = Tile{64, 32, 32};
   const int kunit = p.amode == AMODE_PLAIN ? p.K : p.Kt;   // a chunk must not straddle a tap
   if (pick.bm + pick.bn <= 96 && kunit % 64 == 0) pick.bk = 64;
   return pick;
 }
 
-// LN-fused launch.  BK = 64 (or 32 when d % 64 != 0) and the whole K (<= 8 chunks) in registers; the 64-row /
-// 64-column tiles are only instantiated for <= 4 chunks (d_model <= 256), where they fit the register file.
+// LN-fused launch.  BK = 64 (or 32 when d % 64 != 0); the whole K = NK chunks lives in registers, NK in
+// {1,2,4} (d_model <= 256).
+int ln_bk(int K) { return (K % 64 == 0) ? 64 : 32; }
 bool ln_fusable(const GemmParams& p) {
   if (!p.ln_gamma || !p.ln_beta || p.amode != AMODE_PLAIN) return false;
-  const int bk = (p.K % 64 == 0) ? 64 : 32;
-  return p.K / bk <= 8;
+  // NK = 8 (d_model = 512) needs ~230 VGPRs and measured 11 TFLOP/s: not worth fusing, the stand-alone
+  // LayerNorm + plain GEMM is used there
+  const int nk = p.K / ln_bk(p.K);
+  return nk == 1 || nk == 2 || nk == 4;
 }
 
 Tile pick_ln_tile(const GemmParams& p) {
-  const int bk = (p.K % 64 == 0) ? 64 : 32;
+  const int bk = ln_bk(p.K);
   if (const char* e = getenv("AVSEP_LN_TILE")) {   // developer override: AVSEP_LN_TILE=BMxBN
     Tile t{32, 32, bk};
     if (sscanf(e, "%dx%d", &t.bm, &t.bn) == 2) return t;
@@ -471,31 +475,38 @@ Tile pick_ln_tile(const GemmParams& p) {
     static const Tile cands[] = {{64, 64, 64}, {64, 32, 64}};
     auto blocks = [&](const Tile& t) { return (long)((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn); };
     bool found = false;
-    for (long need : {1024L, 512L})
-      for (const Tile& t : cands)
-        if (!found && blocks(t) >= need) { pick = t; found = true; }
+    for (const Tile& t : cands)
+      if (!found && blocks(t) >= 512) { pick = t; found = true; }
   }
   return pick;
 }
 
-template <int BM, int BN, int BK, int NKMAX>
+template <int BM, int BN, int BK, int NK>
 hipError_t launch_ln_t(const GemmParams& p, hipStream_t s) {
   const int nb = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, BK, NKMAX>), dim3(nb), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, BK, NK>), dim3(nb), dim3(256), 0, s, p);
   return hipGetLastError();
+}
+
+template <int BM, int BN, int BK>
+hipError_t launch_ln_nk(const GemmParams& p, int nk, hipStream_t s) {
+  switch (nk) {
+    case 1: return launch_ln_t<BM, BN, BK, 1>(p, s);
+    case 2: return launch_ln_t<BM, BN, BK, 2>(p, s);
+    case 4: return launch_ln_t<BM, BN, BK, 4>(p, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
   const Tile t = pick_ln_tile(p);
   const int nk = p.K / t.bk;
   if (t.bk == 64) {
-    if (t.bm == 64 && t.bn == 64 && nk <= 4) return launch_ln_t<64, 64, 64, 4>(p, s);
-    if (t.bm == 64 && t.bn == 32 && nk <= 4) return launch_ln_t<64, 32, 64, 4>(p, s);
-    if (nk <= 4) return launch_ln_t<32, 32, 64, 4>(p, s);
-    return launch_ln_t<32, 32, 64, 8>(p, s);
+    if (t.bm == 64 && t.bn == 64 && nk <= 4) return launch_ln_nk<64, 64, 64>(p, nk, s);
+    if (t.bm == 64 && t.bn == 32 && nk <= 4) return launch_ln_nk<64, 32, 64>(p, nk, s);
+    return launch_ln_nk<32, 32, 64>(p, nk, s);
   }
-  if (nk <= 4) return launch_ln_t<32, 32, 32, 4>(p, s);
-  return launch_ln_t<32, 32, 32, 8>(p, s);
+  return launch_ln_nk<32, 32, 32>(p, nk, s);
 }
 
 }  // namespace
@@ -513,7 +524,7 @@ const char* gemm_instance_name(const GemmParams& p) {
   static thread_local char buf[64];
   if (p.ln_gamma) {
     const Tile t = pick_ln_tile(p);
-    snprintf(buf, sizeof buf, "gemm_ln_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.K / t.bk <= 4 ? 4 : 8);
+    snprintf(buf, sizeof buf, "gemm_ln_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.K / t.bk);
     return buf;
   }
   const Tile t = pick_tile(p);
