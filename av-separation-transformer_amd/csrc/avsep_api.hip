@@ -929,11 +929,9 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
     c->graphs.push_back(g);
     hit = &c->graphs.back();
   }
-  HCK(hipEventRecord(c->ev_gin, s));
-  HCK(hipStreamWaitEvent(c->gstream, c->ev_gin, 0));
-  HCK(hipGraphLaunch(hit->exec, c->gstream));
-  HCK(hipEventRecord(c->ev_gout, c->gstream));
-  HCK(hipStreamWaitEvent(s, c->ev_gout, 0));
+  // Replay on the caller's own stream: no event fences between consecutive steps (the fenced hand-off to the
+  // capture stream left a ~40-60 us bubble per step).  Only capture needs a non-legacy stream, launch does not.
+  HCK(hipGraphLaunch(hit->exec, s));
   return AVSEP_OK;
 }
 
