@@ -49,15 +49,17 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   constexpr int RB2MAX = (RB2 + RSPLIT - 1) / RSPLIT;  // conv2 row blocks per wave
   constexpr int CB3 = 8 / NW;                          // conv3 16-channel blocks per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* a1 = lds;                         // G x (H1+2) x (W1+2) x C1P
-  float* a2 = lds + G * p.a1_frame;        // G x (H2+2) x (W2+2) x C2P
+  float* a1 = lds;                         // G x (2*H2+1) x (2*W2+1) x C1P
+  float* a2 = lds + G * p.a1_frame;        // G x (2*H3+1) x (2*W3+1) x C2P
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int c = lane & 15;
   const int q = lane >> 4;
   const int P1 = p.H1 * p.W1, P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
-  const int s1w = p.W1 + 2, s2w = p.W2 + 2;
+  // row strides (pixels) of the haloed images: a stride-2 3x3 window over Ho outputs touches halo rows 0..2*Ho,
+  // so 2*Ho+1 rows/cols are enough (one halo line less than H+2 for even sizes: leaves LDS for the other stream)
+  const int s1w = 2 * p.W2 + 1, s2w = 2 * p.W3 + 1;
 
   // zero both images once: the halo is never written again
   for (int i = tid * 4; i < G * (p.a1_frame + p.a2_frame); i += 4 * NT)
@@ -268,8 +270,8 @@ hipError_t launch_conv_stack(const float* frames, const float* w1, const float* 
   p.H1 = conv_out(H); p.W1 = conv_out(W);
   p.H2 = conv_out(p.H1); p.W2 = conv_out(p.W1);
   p.H3 = conv_out(p.H2); p.W3 = conv_out(p.W2);
-  p.a1_frame = (p.H1 + 2) * (p.W1 + 2) * C1P;
-  p.a2_frame = (p.H2 + 2) * (p.W2 + 2) * C2P;
+  p.a1_frame = (2 * p.H2 + 1) * (2 * p.W2 + 1) * C1P;
+  p.a2_frame = (2 * p.H3 + 1) * (2 * p.W3 + 1) * C2P;
   const int P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
   const size_t frame_bytes = (size_t)(p.a1_frame + p.a2_frame) * sizeof(float);
   const size_t LDS_MAX = 160 * 1024;

@@ -148,6 +148,9 @@ def main():
                 model.run_static(mixed, lips, masks, sep, graph=False)
             stream.synchronize()
             kernels = model.profile_end()
+            # a profiled forward's outputs are meaningless (each launch is repeated): leave a clean result behind
+            model.run_static(mixed, lips, masks, sep, graph=graph)
+            stream.synchronize()
 
     gflop_clip = flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
     value = world * B * a.steps / elapsed
@@ -173,6 +176,18 @@ def main():
         "path_tflops_per_gpu": round(value / world * gflop_clip / 1e3, 3),
         "path_frac": round(value / world * gflop_clip / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
     }
+
+    # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same command
+    # (tools/pmc_bench.sh -> profiles/pmc_hbm_traffic.json; counters cannot be read from inside the process)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))["kernels"]
+        hit = pmc.get(dom["name"])
+        if hit:
+            roofline["traffic"] = round(hit["fetch_bytes_per_launch"] + hit["write_bytes_per_launch"])
+            roofline["traffic_unit"] = "HBM-side bytes per launch (PMC, profiles/pmc_hbm_traffic.json)"
+            roofline["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["calls"])
+    except (OSError, KeyError, ValueError):
+        pass
 
     out = {
         "metric": "separated clips/sec (2-spk, 1s@8kHz, d=256) forward, fp32",

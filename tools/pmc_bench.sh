@@ -26,4 +26,10 @@ for n,c in sorted(tot.items(), key=lambda kv: -kv[1].get("FETCH_SIZE",0)):
     TF+=f; TW+=w
     print(f"{n:34s} {calls[n]/fw:9.1f} {f:22.1f} {w:12.1f} {100*h/max(1,h+m):8.1f}")
 print(f"TOTAL per forward: fetch {TF:.0f} MB (corrected x2), write {TW:.0f} MB")
+import json
+js={n:{"calls_per_forward":calls[n]/fw,
+       "fetch_bytes_per_launch":c.get("FETCH_SIZE",0)*1024*2/max(1,calls[n]),
+       "write_bytes_per_launch":c.get("WRITE_SIZE",0)*1024/max(1,calls[n]),
+       "l2_hit_rate":c.get("TCC_HIT_sum",0)/max(1,c.get("TCC_HIT_sum",0)+c.get("TCC_MISS_sum",0))} for n,c in tot.items()}
+json.dump({"note":"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes over `bench.py --no-graph`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream)","kernels":js}, open(OUT+"/pmc_hbm_traffic.json","w"), indent=1)
 PY
