@@ -17,6 +17,7 @@
 // workgroup through the CU's L1); fp32 MFMA needs 1 operand dword per lane per 32 cycles, so there is
 // nothing for an LDS stage to win here.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -175,6 +176,104 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// Short-sequence specialisation (49 <= Lk <= 64, dh = 64: the 1 s @ 8 kHz clips of BASELINE configs 1/2, T = 63
+// audio frames / N = 50 lip frames): all NKT = 4 key tiles of K and V are loaded before the first MFMA, so the
+// wave pays ONE memory round trip instead of one per tile (the generic kernel's 1-tile prefetch leaves a ~4 us
+// latency chain at this size), and the softmax is the plain two-pass one over registers.
+template <int NB, int NKT>
+__global__ __launch_bounds__(256) void attention_short_kernel(const float* __restrict__ q, int ldq,
+                                                              const float* __restrict__ k, int ldk,
+                                                              const float* __restrict__ v, int ldv,
+                                                              float* __restrict__ o, int ldo, int nhead, int Lq,
+                                                              int Lk, int nqt) {
+  constexpr int DH = 16 * NB;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c = lane & 15;
+  const int g = lane >> 4;
+  const int wg_per_head = (nqt + 3) >> 2;
+  const int bh = blockIdx.x / wg_per_head;
+  const int qt = (blockIdx.x - bh * wg_per_head) * 4 + wave;
+  if (qt >= nqt) return;
+  const int b = bh / nhead, h = bh - b * nhead;
+  const float* qb = q + (size_t)b * Lq * ldq + h * DH;
+  const float* kb = k + (size_t)b * Lk * ldk + h * DH;
+  const float* vb = v + (size_t)b * Lk * ldv + h * DH;
+  float* ob = o + (size_t)b * Lq * ldo + h * DH;
+
+  const int qrow = min(qt * 16 + c, Lq - 1);
+  f32x4 qf[NB], kf[NKT][NB], vf[NKT][4];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) qf[s] = *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g);
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int krow = min(kt * 16 + c, Lk - 1);
+#pragma unroll
+    for (int s = 0; s < NB; ++s) kf[kt][s] = *reinterpret_cast<const f32x4*>(kb + (size_t)krow * ldk + 16 * s + 4 * g);
+  }
+  static_assert(NB == 4, "V fragment = one float4 per key row");
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int vrow = min(kt * 16 + 4 * g + r, Lk - 1);
+      vf[kt][r] = *reinterpret_cast<const f32x4*>(vb + (size_t)vrow * ldv + NB * c);
+    }
+
+  // All scores at once: NKT independent accumulators, MFMAs interleaved across tiles so the 40-cycle
+  // dependent-accumulator latency never stalls the pipe; then ONE exact softmax over the <= 64 keys held in
+  // registers (row max, exp, row sum -- the order nn.MultiheadAttention itself uses), then P V.
+  f32x4 st[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NB; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][s][j], qf[s][j], st[kt], 0, 0, 0);
+  float mrow = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      st[kt][r] = key < Lk ? st[kt][r] : -INFINITY;
+      mrow = fmaxf(mrow, st[kt][r]);
+    }
+  mrow = fmaxf(mrow, __shfl_xor(mrow, 16));
+  mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+  float lrun = 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      st[kt][r] = exp_neg(st[kt][r] - mrow);
+      lrun += st[kt][r];
+    }
+  f32x4 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][blk], st[kt][r], acc[blk], 0, 0, 0);
+  lrun += __shfl_xor(lrun, 16);
+  lrun += __shfl_xor(lrun, 32);
+  const float inv = 1.0f / lrun;
+  const int qo = qt * 16 + c;
+  if (qo < Lq) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(ob + (size_t)qo * ldo + NB * (4 * g + r)) =
+          f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
@@ -185,6 +284,12 @@ hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, co
   const int wg_per_head = (nqt + 3) / 4;
   const dim3 grid((unsigned)(B * nhead * wg_per_head)), block(256);
   if (dh <= 0 || dh > 128 || (dh & 3)) return hipErrorInvalidValue;
+  static const bool no_short = getenv("AVSEP_NO_SHORT_ATTN") != nullptr;   // developer A/B switch
+  if (dh == 64 && Lk > 48 && Lk <= 64 && !no_short) {
+    hipLaunchKernelGGL((attention_short_kernel<4, 4>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq,
+                       Lk, nqt);
+    return hipGetLastError();
+  }
   const int nb = (dh + 15) / 16;
   const bool reg = (dh == 16 * nb);
 #define AVSEP_ATT(NB_)                                                                                              \
