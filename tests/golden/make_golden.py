@@ -280,6 +280,26 @@ def make_losses(outdir):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_eval(outdir):
+    """demo.py's evaluate_separation / snr_db / _permutation_snr on the trained tiny model (reference numbers)."""
+    sys.path.insert(0, "/root/reference")
+    import demo as refdemo
+    z = np.load(os.path.join(outdir, "trained_tiny.npz"))
+    c = json.loads(str(z["config"]))
+    m = build_reference(c, {k[2:]: z[k] for k in z.files if k.startswith("w.")})
+    ds = ref.SyntheticAVDataset(num_samples=64, sample_rate=8000, duration=0.496, n_fft=128, hop_length=128,
+                                num_frames=5, frame_h=16, frame_w=16)
+    in_snr, out_snr = refdemo.evaluate_separation(m, ds, torch.device("cpu"), num_eval=6)
+    a = seeded.tensor(51, "ev.a", (3, 9, 7), 0.0, 2.0)
+    b = seeded.tensor(51, "ev.b", (3, 9, 7), 0.0, 2.0)
+    out = {"in_snr": np.float64(in_snr), "out_snr": np.float64(out_snr), "a": a, "b": b,
+           "snr_db": np.float64(refdemo.snr_db(a, b)), "perm_snr": np.float64(refdemo._permutation_snr(a, b)),
+           "perm_snr_shuffled": np.float64(refdemo._permutation_snr(b[[2, 0, 1]] * 1.01, b))}
+    path = os.path.join(outdir, "eval.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: in {in_snr:.3f} dB out {out_snr:.3f} dB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -295,6 +315,8 @@ def main():
         make_dataset(a.out)
     if a.only in (None, "losses"):
         make_losses(a.out)
+    if a.only in (None, "eval"):
+        make_eval(a.out)
 
 
 if __name__ == "__main__":
