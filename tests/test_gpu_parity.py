@@ -285,3 +285,70 @@ def test_op_interp_linear(lib, dev, B, N, T, d):
     tref = torch.nn.functional.interpolate(torch.from_numpy(x).permute(0, 2, 1), size=T, mode="linear",
                                            align_corners=False).permute(0, 2, 1).numpy()
     assert maxabs(ref, tref) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+def _random_model(dev, seed=0, **kw):
+    import av_separation as av
+    torch.manual_seed(seed)
+    m = av.AVSeparationTransformer(dropout=0.0, **kw)
+    # non-trivial BatchNorm statistics so the folding is exercised
+    for k, v in m.state_dict().items():
+        if k.endswith("running_mean"):
+            v.uniform_(-0.3, 0.3)
+        elif k.endswith("running_var"):
+            v.uniform_(0.5, 1.5)
+    return m.to(dev).eval()
+
+
+def _oracle(m, mixed, lips, nhead, S):
+    state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    return onp.forward(state, mixed, lips, nhead, S)
+
+
+@pytest.mark.parametrize("kw,B,T,N,H,W", [
+    (dict(freq_bins=9, d_model=32, nhead=4, num_encoder_layers=1, num_fusion_layers=1, num_speakers=2), 1, 5000, 3, 8, 8),   # T = max_len
+    (dict(freq_bins=33, d_model=64, nhead=2, num_encoder_layers=1, num_fusion_layers=1, num_speakers=2), 2, 21, 4, 64, 64),  # frames too big for the fused conv kernel
+    (dict(freq_bins=33, d_model=64, nhead=2, num_encoder_layers=1, num_fusion_layers=1, num_speakers=2), 2, 21, 5, 48, 40),  # fused conv, one frame per pass
+    (dict(freq_bins=17, d_model=96, nhead=4, num_encoder_layers=1, num_fusion_layers=2, num_speakers=4), 67, 9, 3, 6, 10),  # d % 64 != 0, dh = 24, ragged M tiles, S = 4
+    (dict(freq_bins=20, d_model=128, nhead=1, num_encoder_layers=0, num_fusion_layers=0, num_speakers=1), 3, 7, 2, 5, 5),    # no layers at all, dh = 128, S = 1
+])
+def test_edge_shapes_against_oracle(dev, kw, B, T, N, H, W):
+    m = _random_model(dev, **kw)
+    mixed, lips = seeded.inputs(99, B, kw["freq_bins"], T, N, H, W)
+    with torch.no_grad():
+        sep, masks = m(t(mixed, dev), t(lips, dev))
+    rs, rm = _oracle(m, mixed, lips, kw["nhead"], kw["num_speakers"])
+    assert maxabs(masks.cpu().numpy(), rm) < MASK_TOL
+    assert maxabs(sep.cpu().numpy(), rs) < MASK_TOL * max(1.0, float(np.abs(mixed).max()))
+
+
+def test_input_plumbing_and_multiple_models(dev):
+    import copy
+    kw = dict(freq_bins=33, d_model=64, nhead=4, num_encoder_layers=1, num_fusion_layers=1, num_speakers=2)
+    m1, m2 = _random_model(dev, seed=1, **kw), _random_model(dev, seed=2, **kw)
+    mixed, lips = seeded.inputs(5, 3, 33, 20, 6, 16, 16)
+    x, y = t(mixed, dev), t(lips, dev)
+    with torch.no_grad():
+        s1, k1 = m1(x, y)
+        s2, k2 = m2(x, y)
+        assert not torch.equal(k1, k2)                                   # two live contexts do not interfere
+        s1b, k1b = m1(x, y)
+        assert torch.equal(k1, k1b)
+        # non-contiguous and float64 inputs are converted, not rejected
+        xnc = t(np.ascontiguousarray(mixed.transpose(0, 2, 1)), dev).permute(0, 2, 1)
+        assert not xnc.is_contiguous()
+        _, k1c = m1(xnc.double(), y.double())
+        assert torch.equal(k1c, k1)
+        # a deep copy owns its own native context and gives the same answer
+        m3 = copy.deepcopy(m1)
+        _, k3 = m3(x, y)
+        assert torch.equal(k3, k1)
+        # a second stream works (work is enqueued on the caller's current stream)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            _, k4 = m1(x, y)
+        st.synchronize()
+        assert torch.equal(k4, k1)
+    rs, rm = _oracle(m1, mixed, lips, 4, 2)
+    assert maxabs(k1.cpu().numpy(), rm) < MASK_TOL
