@@ -18,6 +18,12 @@ ABI_SYMBOLS = (
     "avsep_audio_encoder", "avsep_visual_encoder", "avsep_fusion", "avsep_decoder",
     "avsep_set_debug_taps", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_layernorm",
     "avsep_op_attention", "avsep_op_interp_linear",
+    # training ops
+    "avsep_op_linear_ex", "avsep_op_attention_train", "avsep_op_attention_bwd", "avsep_op_transpose",
+    "avsep_op_transpose_pad", "avsep_op_im2col1d", "avsep_op_col2im1d", "avsep_op_im2col2d", "avsep_op_col2im2d",
+    "avsep_op_colreduce_scratch_floats", "avsep_op_colreduce", "avsep_op_bn_train_fwd", "avsep_op_bn_train_bwd",
+    "avsep_op_act_fwd", "avsep_op_act_bwd", "avsep_op_mul_mixed", "avsep_op_add_rows", "avsep_op_avgpool_fwd", "avsep_op_avgpool_bwd",
+    "avsep_op_interp_linear_bwd", "avsep_op_layernorm_bwd",
 )
 
 
@@ -68,6 +74,29 @@ def load():
     lib.avsep_op_layernorm.argtypes = [fp, fp, fp, fp, i, i, C.c_float, p]
     lib.avsep_op_attention.argtypes = [fp, i, fp, i, fp, i, fp, i, i, i, i, i, i, p]
     lib.avsep_op_interp_linear.argtypes = [fp, fp, i, i, i, i, p]
+    f = C.c_float
+    lib.avsep_op_linear_ex.argtypes = [fp, i, fp, i, fp, fp, i, i, fp, i, i, i, i, i, p]
+    lib.avsep_op_attention_train.argtypes = [fp, i, fp, i, fp, i, fp, i, fp, i, i, i, i, i, f, p]
+    lib.avsep_op_attention_bwd.argtypes = [fp, i, fp, i, fp, i, fp, i, fp, i, fp, fp, fp, i, fp, i, fp, i, i, i, i, i, i, f, p]
+    lib.avsep_op_transpose.argtypes = [fp, fp, i, i, i, p]
+    lib.avsep_op_transpose_pad.argtypes = [fp, fp, i, i, i, i, p]
+    lib.avsep_op_im2col1d.argtypes = [fp, fp, i, i, i, p]
+    lib.avsep_op_col2im1d.argtypes = [fp, fp, i, i, i, p]
+    lib.avsep_op_im2col2d.argtypes = [fp, fp, i, i, i, i, i, p]
+    lib.avsep_op_col2im2d.argtypes = [fp, fp, i, i, i, i, i, p]
+    lib.avsep_op_colreduce_scratch_floats.argtypes = [i, i]
+    lib.avsep_op_colreduce_scratch_floats.restype = i64
+    lib.avsep_op_colreduce.argtypes = [fp, fp, fp, fp, fp, i, i, p]
+    lib.avsep_op_bn_train_fwd.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, i, i, f, f, i, p]
+    lib.avsep_op_bn_train_bwd.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, i, i, f, i, p]
+    lib.avsep_op_act_fwd.argtypes = [fp, fp, i64, i, p]
+    lib.avsep_op_act_bwd.argtypes = [fp, fp, fp, i64, i, p]
+    lib.avsep_op_mul_mixed.argtypes = [fp, fp, fp, i64, i, i, i, p]
+    lib.avsep_op_add_rows.argtypes = [fp, fp, fp, i64, i, i, p]
+    lib.avsep_op_avgpool_fwd.argtypes = [fp, fp, i, i, i, p]
+    lib.avsep_op_avgpool_bwd.argtypes = [fp, fp, i, i, i, p]
+    lib.avsep_op_interp_linear_bwd.argtypes = [fp, fp, i, i, i, i, p]
+    lib.avsep_op_layernorm_bwd.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, i, i, f, p]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)     # AttributeError here = ABI drift between header and library
         if fn.restype is C.c_int and name not in ("avsep_abi_version",):

@@ -1,0 +1,459 @@
+"""Training path: train-mode forward + backward of the model on the HIP ops.
+
+What the reference gets from torch autograd over torch.nn modules (demo.py:83-113, tests/test_model.py:210-217,
+332-353) is rebuilt here as a composition of hand-written HIP ops (C ABI section "training ops" of
+include/avsep.h), each wrapped in a ``torch.autograd.Function`` whose forward AND backward are HIP kernels:
+
+    Linear / Conv1d / Conv2d   im2col (HIP) + fp32-MFMA GEMM; backward dX = dY W, dW = dY^T X on the same GEMM
+                               through HIP transposes, bias gradient by a deterministic column reduction
+    LayerNorm, BatchNorm2d(train: batch statistics, running-stat update), ReLU/GELU/sigmoid, attention
+    (forward keeps the log-sum-exp; backward recomputes the scores), average pool, linear interpolation,
+    mask * mixed
+
+torch supplies only what BASELINE.json's north star leaves to it: tensor allocation, views/permutes/pads of
+parameters (layout plumbing whose adjoints autograd replays), the graph bookkeeping, and the SI-SNR/L1 loss.
+Gradient parity against the reference is pinned by tests/golden/train_*.npz (tests/test_train_gpu.py).
+
+Round-1 scope: correctness; every op is its own launch (no fusion, no graph), dropout must be 0 (the reference's
+own gradient tests use dropout=0.0 too) -- a non-zero dropout in train mode raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _native
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def _lib():
+    return _native.load()
+
+
+def _st(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ck(rc, what):
+    _native.check(rc, what)
+
+
+def _up32(n):
+    return (n + 31) // 32 * 32
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _scratch(M, Cc, like):
+    n = int(_lib().avsep_op_colreduce_scratch_floats(M, Cc))
+    return torch.empty(max(n, 1), device=like.device, dtype=torch.float32)
+
+
+def _gemm(x, w, bias, res, rperiod, act):
+    """act(x [M,K] @ w[N,K]^T + bias) (+ res rows); K % 32 == 0."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _ck(_lib().avsep_op_linear_ex(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                  res.data_ptr() if res is not None else None, N, rperiod, y.data_ptr(), N, M, N, K,
+                                  act, _st(x)), "avsep_op_linear_ex")
+    return y
+
+
+def _transpose(x, rp):
+    """x [R,C] -> [C,rp] (rows beyond R zero)."""
+    R, Cc = x.shape
+    y = torch.empty(Cc, rp, device=x.device, dtype=torch.float32)
+    _ck(_lib().avsep_op_transpose(x.data_ptr(), y.data_ptr(), R, Cc, rp, _st(x)), "avsep_op_transpose")
+    return y
+
+
+def _colsum(a, b=None):
+    M, Cc = a.shape
+    s = _scratch(M, Cc, a)
+    o0 = torch.empty(Cc, device=a.device)
+    o1 = torch.empty(Cc, device=a.device) if b is not None else None
+    _ck(_lib().avsep_op_colreduce(a.data_ptr(), b.data_ptr() if b is not None else None, s.data_ptr(), o0.data_ptr(),
+                                  o1.data_ptr() if b is not None else None, M, Cc, _st(a)), "avsep_op_colreduce")
+    return o0, o1
+
+
+# ----------------------------------------------------------------------------------------------- autograd ops
+class LinearFn(torch.autograd.Function):
+    """y = act(x w^T + b) + res;  act in {none, relu}; res: same-shape residual (grad flows) or constant rows with
+    period `rperiod` (positional encoding, no grad)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, res, rperiod):
+        assert not (act == ACT_RELU and res is not None), "the ReLU mask needs the pre-residual output"
+        x, w = _c(x), _c(w)
+        y = _gemm(x, w, b, res, rperiod, act)
+        ctx.act, ctx.res_grad = act, (res is not None and rperiod <= 0)
+        ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        M, K = x.shape
+        N = w.shape[0]
+        lib = _lib()
+        if ctx.act == ACT_RELU:
+            dpre = torch.empty_like(dy)
+            _ck(lib.avsep_op_act_bwd(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dy.numel(), ACT_RELU, _st(dy)), "act_bwd")
+        else:
+            dpre = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            Np = _up32(N)
+            dpp = dpre if Np == N else F.pad(dpre, (0, Np - N))          # zero K-padding (layout only)
+            wt = _transpose(w, Np)                                         # [K, Np] = w^T
+            dx = _gemm(dpp, wt, None, None, 0, ACT_NONE)                   # dY W
+        if ctx.needs_input_grad[1]:
+            Mp = _up32(M)
+            dw = _gemm(_transpose(dpre, Mp), _transpose(x, Mp), None, None, 0, ACT_NONE)   # dY^T X  [N, K]
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db, _ = _colsum(dpre)
+        dres = dy if (ctx.res_grad and ctx.needs_input_grad[4]) else None
+        return dx, dw, db, None, dres, None
+
+
+class ActFn(torch.autograd.Function):
+    """GELU(erf) / sigmoid as separate ops (their backward needs the pre-activation / output)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _ck(_lib().avsep_op_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, _st(x)), "act_fwd")
+        ctx.act = act
+        ctx.save_for_backward(x if act == ACT_GELU else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (aux,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _ck(_lib().avsep_op_act_bwd(dy.data_ptr(), aux.data_ptr(), dx.data_ptr(), dy.numel(), ctx.act, _st(dy)), "act_bwd")
+        return dx, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = _c(x)
+        M, d = x.shape
+        y = torch.empty_like(x)
+        _ck(_lib().avsep_op_layernorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), M, d, eps, _st(x)), "layernorm")
+        ctx.eps = eps
+        ctx.save_for_backward(x, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dy = _c(dy)
+        M, d = x.shape
+        dx, xh = torch.empty_like(x), torch.empty_like(x)
+        dg, db = torch.empty_like(g), torch.empty_like(g)
+        s = _scratch(M, d, x)
+        _ck(_lib().avsep_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                          db.data_ptr(), xh.data_ptr(), s.data_ptr(), M, d, ctx.eps, _st(x)), "layernorm_bwd")
+        return dx, dg, db, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax((scale q) k^T) v per (batch, head).  q [B*Lq, *] / kv tensors given as (tensor, column offset): the
+    packed in_proj output is used in place (leading dimension = row width)."""
+
+    @staticmethod
+    def forward(ctx, qt, kvt, qoff, koff, voff, B, h, dh, Lq, Lk, scale):
+        qt, kvt = _c(qt), _c(kvt)
+        d = h * dh
+        o = torch.empty(B * Lq, d, device=qt.device)
+        lse = torch.empty(B * h * Lq, device=qt.device)
+        ldq, ldk = qt.shape[1], kvt.shape[1]
+        base_q, base_kv = qt.data_ptr(), kvt.data_ptr()
+        _ck(_lib().avsep_op_attention_train(base_q + 4 * qoff, ldq, base_kv + 4 * koff, ldk, base_kv + 4 * voff, ldk,
+                                            o.data_ptr(), d, lse.data_ptr(), B, h, dh, Lq, Lk, scale, _st(qt)), "attention_train")
+        ctx.meta = (qoff, koff, voff, B, h, dh, Lq, Lk, scale, qt is kvt)
+        ctx.save_for_backward(qt, kvt, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qt, kvt, o, lse = ctx.saved_tensors
+        qoff, koff, voff, B, h, dh, Lq, Lk, scale, same = ctx.meta
+        do = _c(do)
+        d = h * dh
+        dqt = torch.zeros_like(qt)
+        dkvt = dqt if same else torch.zeros_like(kvt)
+        dvec = torch.empty(B * h * Lq, device=qt.device)
+        ldq, ldk = qt.shape[1], kvt.shape[1]
+        _ck(_lib().avsep_op_attention_bwd(qt.data_ptr() + 4 * qoff, ldq, kvt.data_ptr() + 4 * koff, ldk,
+                                          kvt.data_ptr() + 4 * voff, ldk, o.data_ptr(), d, do.data_ptr(), d,
+                                          lse.data_ptr(), dvec.data_ptr(), dqt.data_ptr() + 4 * qoff, ldq,
+                                          dkvt.data_ptr() + 4 * koff, ldk, dkvt.data_ptr() + 4 * voff, ldk, B, h, dh, Lq,
+                                          Lk, scale, _st(qt)), "attention_bwd")
+        return dqt, (None if same else dkvt), None, None, None, None, None, None, None, None, None
+
+
+class Im2col1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, T):
+        x = _c(x)
+        M, Cc = x.shape
+        col = torch.empty(M, 3 * Cc, device=x.device)
+        _ck(_lib().avsep_op_im2col1d(x.data_ptr(), col.data_ptr(), M, T, Cc, _st(x)), "im2col1d")
+        ctx.T = T
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        dcol = _c(dcol)
+        M, C3 = dcol.shape
+        dx = torch.empty(M, C3 // 3, device=dcol.device)
+        _ck(_lib().avsep_op_col2im1d(dcol.data_ptr(), dx.data_ptr(), M, ctx.T, C3 // 3, _st(dcol)), "col2im1d")
+        return dx, None
+
+
+class Im2col2dFn(torch.autograd.Function):
+    """x rows [I*H*W, C] (channels last) -> [I*Ho*Wo, Kp] with column tap*C + c."""
+
+    @staticmethod
+    def forward(ctx, x, I, H, W, Kp):
+        x = _c(x)
+        Cc = x.shape[1]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        col = torch.empty(I * Ho * Wo, Kp, device=x.device)
+        _ck(_lib().avsep_op_im2col2d(x.data_ptr(), col.data_ptr(), I, H, W, Cc, Kp, _st(x)), "im2col2d")
+        ctx.meta = (I, H, W, Cc, Kp)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        I, H, W, Cc, Kp = ctx.meta
+        dcol = _c(dcol)
+        dx = torch.empty(I * H * W, Cc, device=dcol.device)
+        _ck(_lib().avsep_op_col2im2d(dcol.data_ptr(), dx.data_ptr(), I, H, W, Cc, Kp, _st(dcol)), "col2im2d")
+        return dx, None, None, None, None
+
+
+class BatchNormReluFn(torch.autograd.Function):
+    """BatchNorm2d (training: batch statistics over all rows, running stats updated in place) + ReLU on rows [M, C]."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, rmean, rvar, eps, momentum):
+        x = _c(x)
+        M, Cc = x.shape
+        mean, var = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+        xh, y = torch.empty_like(x), torch.empty_like(x)
+        s = _scratch(M, Cc, x)
+        # the kernel updates copies of the running statistics; copy_ back so torch sees the buffers change
+        # (their version counters drive the inference path's weight re-packing)
+        rm, rv = rmean.detach().clone(), rvar.detach().clone()
+        _ck(_lib().avsep_op_bn_train_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                         xh.data_ptr(), y.data_ptr(), rm.data_ptr(), rv.data_ptr(), s.data_ptr(), M,
+                                         Cc, eps, momentum, 1, _st(x)), "bn_train_fwd")
+        with torch.no_grad():
+            rmean.copy_(rm)
+            rvar.copy_(rv)
+        ctx.eps = eps
+        ctx.save_for_backward(y, xh, g, var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, xh, g, var = ctx.saved_tensors
+        dy = _c(dy)
+        M, Cc = y.shape
+        dx, tmp = torch.empty_like(y), torch.empty_like(y)
+        dg, db = torch.empty_like(g), torch.empty_like(g)
+        s = _scratch(M, Cc, y)
+        _ck(_lib().avsep_op_bn_train_bwd(dy.data_ptr(), y.data_ptr(), xh.data_ptr(), g.data_ptr(), var.data_ptr(),
+                                         dx.data_ptr(), dg.data_ptr(), db.data_ptr(), tmp.data_ptr(), s.data_ptr(), M, Cc,
+                                         ctx.eps, 1, _st(y)), "bn_train_bwd")
+        return dx, dg, db, None, None, None, None
+
+
+class AddRowsFn(torch.autograd.Function):
+    """x + r[m % period]  (the PositionalEncoding add after a ReLU, where it cannot ride the GEMM epilogue because
+    the ReLU mask of the backward needs the pre-add output)."""
+
+    @staticmethod
+    def forward(ctx, x, r, period):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _ck(_lib().avsep_op_add_rows(x.data_ptr(), r.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], period, _st(x)), "add_rows")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, M, P):
+        x = _c(x)
+        Cc = x.shape[1]
+        y = torch.empty(M, Cc, device=x.device)
+        _ck(_lib().avsep_op_avgpool_fwd(x.data_ptr(), y.data_ptr(), M, P, Cc, _st(x)), "avgpool_fwd")
+        ctx.meta = (M, P, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        M, P, Cc = ctx.meta
+        dy = _c(dy)
+        dx = torch.empty(M * P, Cc, device=dy.device)
+        _ck(_lib().avsep_op_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), M, P, Cc, _st(dy)), "avgpool_bwd")
+        return dx, None, None
+
+
+class InterpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, B, N, T):
+        x = _c(x)
+        d = x.shape[1]
+        y = torch.empty(B * T, d, device=x.device)
+        _ck(_lib().avsep_op_interp_linear(x.data_ptr(), y.data_ptr(), B, N, T, d, _st(x)), "interp")
+        ctx.meta = (B, N, T, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, T, d = ctx.meta
+        dy = _c(dy)
+        dx = torch.empty(B * N, d, device=dy.device)
+        _ck(_lib().avsep_op_interp_linear_bwd(dy.data_ptr(), dx.data_ptr(), B, N, T, d, _st(dy)), "interp_bwd")
+        return dx, None, None, None
+
+
+class MulMixedFn(torch.autograd.Function):
+    """separated[m, s*F+f] = masks[m, s*F+f] * mixed^T[m, f]   (SeparationDecoder.separate, model.py:220)."""
+
+    @staticmethod
+    def forward(ctx, masks, xt, S, Fq):
+        masks = _c(masks)
+        out = torch.empty_like(masks)
+        _ck(_lib().avsep_op_mul_mixed(masks.data_ptr(), xt.data_ptr(), out.data_ptr(), masks.shape[0], S, Fq, xt.shape[1],
+                                      _st(masks)), "mul_mixed")
+        ctx.meta = (S, Fq)
+        ctx.save_for_backward(xt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dsep):
+        (xt,) = ctx.saved_tensors
+        S, Fq = ctx.meta
+        dsep = _c(dsep)
+        dm = torch.empty_like(dsep)
+        _ck(_lib().avsep_op_mul_mixed(dsep.data_ptr(), xt.data_ptr(), dm.data_ptr(), dsep.shape[0], S, Fq, xt.shape[1],
+                                      _st(dsep)), "mul_mixed(bwd)")
+        return dm, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------- model composition
+def _encoder_layer(x, P, pre, B, L, h):
+    """nn.TransformerEncoderLayer(norm_first=True, relu, ff=4d), dropout 0  (model.py:48-52)."""
+    d = x.shape[1]
+    dh = d // h
+    n = LayerNormFn.apply(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5)
+    qkv = LinearFn.apply(n, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"], ACT_NONE, None, 0)
+    o = AttentionFn.apply(qkv, qkv, 0, d, 2 * d, B, h, dh, L, L, 1.0 / math.sqrt(dh))
+    x = LinearFn.apply(o, P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], ACT_NONE, x, 0)
+    n = LayerNormFn.apply(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)
+    f = LinearFn.apply(n, P[pre + "linear1.weight"], P[pre + "linear1.bias"], ACT_RELU, None, 0)
+    return LinearFn.apply(f, P[pre + "linear2.weight"], P[pre + "linear2.bias"], ACT_NONE, x, 0)
+
+
+def _count(P, prefix):
+    n = 0
+    while f"{prefix}{n}.norm1.weight" in P:
+        n += 1
+    return n
+
+
+def train_forward(model, mixed, lips):
+    """Train-mode AVSeparationTransformer.forward (model.py:268-276) with autograd through the HIP ops.
+    Returns (separated, masks) as (B,S,F,T) views of (B,T,S,F) tensors, like the inference path."""
+    if any(getattr(m, "dropout_p", 0.0) > 0 for m in model.modules()):
+        raise NotImplementedError("train-mode dropout > 0 is not built yet on the HIP path (use dropout=0.0, as the "
+                                  "reference's gradient tests do)")
+    P = dict(model.named_parameters())
+    Bf = dict(model.named_buffers())
+    B, Fq, T = mixed.shape
+    _, N, H, W = lips.shape
+    d, h, S = model.d_model, model.nhead, model.num_speakers
+    dev = mixed.device
+    lib = _lib()
+    Fp = _up32(Fq)
+    M = B * T
+
+    # ---- audio encoder (model.py:54-60)
+    xt = torch.empty(M, Fp, device=dev)
+    _ck(lib.avsep_op_transpose_pad(mixed.data_ptr(), xt.data_ptr(), B, Fq, T, Fp, _st(mixed)), "transpose_pad")
+    col = Im2col1dFn.apply(xt, T)                                                     # [M, 3*Fp]
+    w1 = F.pad(P["audio_encoder.input_proj.0.weight"].permute(0, 2, 1), (0, Fp - Fq)).reshape(d, 3 * Fp)
+    hcur = LinearFn.apply(col, w1, P["audio_encoder.input_proj.0.bias"], ACT_RELU, None, 0)
+    w2 = P["audio_encoder.input_proj.2.weight"].permute(0, 2, 1).reshape(d, 3 * d)
+    pe_a = _c(Bf["audio_encoder.pos_enc.pe"][0, :T])
+    a = LinearFn.apply(Im2col1dFn.apply(hcur, T), w2, P["audio_encoder.input_proj.2.bias"], ACT_RELU, None, 0)
+    a = AddRowsFn.apply(a, pe_a, T)
+    for i in range(_count(P, "audio_encoder.transformer.layers.")):
+        a = _encoder_layer(a, P, f"audio_encoder.transformer.layers.{i}.", B, T, h)
+
+    # ---- visual encoder (model.py:103-117), BatchNorm in training mode
+    Mv = B * N
+    x = _c(lips).reshape(Mv * H * W, 1)
+    hh, ww, cin = H, W, 1
+    for conv_i, bn_i, cout in ((0, 1, 32), (3, 4, 64), (6, 7, 128)):
+        cw = P[f"visual_encoder.conv.{conv_i}.weight"].permute(0, 2, 3, 1).reshape(cout, 9 * cin)   # [Co, tap*Ci + ci]
+        Kp = _up32(9 * cin)
+        if Kp != 9 * cin:
+            cw = F.pad(cw, (0, Kp - 9 * cin))
+        colv = Im2col2dFn.apply(x, Mv, hh, ww, Kp)
+        y = LinearFn.apply(colv, cw, P[f"visual_encoder.conv.{conv_i}.bias"], ACT_NONE, None, 0)
+        bn = f"visual_encoder.conv.{bn_i}."
+        x = BatchNormReluFn.apply(y, P[bn + "weight"], P[bn + "bias"], Bf[bn + "running_mean"], Bf[bn + "running_var"],
+                                  1e-5, 0.1)
+        Bf[bn + "num_batches_tracked"].add_(1)
+        hh, ww, cin = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1, cout
+    pooled = AvgPoolFn.apply(x, Mv, hh * ww)
+    pe_v = _c(Bf["visual_encoder.pos_enc.pe"][0, :N])
+    v = LinearFn.apply(pooled, P["visual_encoder.frame_proj.weight"], P["visual_encoder.frame_proj.bias"], ACT_NONE, pe_v, N)
+    for i in range(_count(P, "visual_encoder.transformer.layers.")):
+        v = _encoder_layer(v, P, f"visual_encoder.transformer.layers.{i}.", B, N, h)
+    v = InterpFn.apply(v, B, N, T)
+
+    # ---- cross-modal fusion (model.py:145-173): visual is not normalised and feeds every layer
+    dh = d // h
+    for i in range(_count(P, "fusion.layers.")):
+        p = f"fusion.layers.{i}."
+        win, bin_ = P[p + "cross_attn.in_proj_weight"], P[p + "cross_attn.in_proj_bias"]
+        n = LayerNormFn.apply(a, P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-5)
+        q = LinearFn.apply(n, win[:d], bin_[:d], ACT_NONE, None, 0)
+        kv = LinearFn.apply(v, win[d:], bin_[d:], ACT_NONE, None, 0)
+        o = AttentionFn.apply(q, kv, 0, 0, d, B, h, dh, T, T, 1.0 / math.sqrt(dh))
+        a = LinearFn.apply(o, P[p + "cross_attn.out_proj.weight"], P[p + "cross_attn.out_proj.bias"], ACT_NONE, a, 0)
+        n = LayerNormFn.apply(a, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5)
+        f = ActFn.apply(LinearFn.apply(n, P[p + "ff.0.weight"], P[p + "ff.0.bias"], ACT_NONE, None, 0), ACT_GELU)
+        a = LinearFn.apply(f, P[p + "ff.3.weight"], P[p + "ff.3.bias"], ACT_NONE, a, 0)
+    a = LayerNormFn.apply(a, P["fusion.norm.weight"], P["fusion.norm.bias"], 1e-5)
+
+    # ---- decoder (model.py:201-220)
+    hmid = ActFn.apply(LinearFn.apply(a, P["decoder.decoder.0.weight"], P["decoder.decoder.0.bias"], ACT_NONE, None, 0), ACT_GELU)
+    logits = LinearFn.apply(hmid, P["decoder.decoder.3.weight"], P["decoder.decoder.3.bias"], ACT_NONE, None, 0)
+    masks = ActFn.apply(logits, ACT_SIGMOID)                                           # [M, S*F]
+    sep = MulMixedFn.apply(masks, xt, S, Fq)
+    return sep.view(B, T, S, Fq).permute(0, 2, 3, 1), masks.view(B, T, S, Fq).permute(0, 2, 3, 1)

@@ -16,9 +16,10 @@ The parameter tree is built from a key/shape/initialiser table instead of compos
 initialisers reproduce the distributions torch.nn gives the reference's layers (kaiming-uniform(a=sqrt 5)
 for Conv/Linear, xavier-uniform for MultiheadAttention.in_proj_weight, zeros for its biases).
 
-Training (autograd through the HIP path, BatchNorm batch statistics, dropout) is SURVEY.md §8(f) row N1
-and not built yet: ``forward`` in ``.train()`` mode raises NotImplementedError instead of silently
-running eval semantics.
+Training: ``AVSeparationTransformer.forward`` in ``.train()`` mode runs the op-by-op
+HIP training path of ``_train.py`` (autograd wrappers whose forward and backward are HIP kernels, BatchNorm batch
+statistics); dropout must be 0 there for now.  The stand-alone stage modules are inference-only and raise in
+train mode instead of silently running eval semantics.
 """
 from __future__ import annotations
 
@@ -487,6 +488,18 @@ class AVSeparationTransformer(nn.Module):
         return json.loads(buf.value.decode())
 
     def forward(self, mixed_spec: torch.Tensor, lip_frames: torch.Tensor):
+        if self.training:
+            # training path: same HIP library, op by op under autograd (av_separation/_train.py)
+            from ._train import train_forward
+            mixed = _prep(mixed_spec, "mixed_spec", 3)
+            lips = _prep(lip_frames, "lip_frames", 4)
+            if mixed.shape[1] != self.freq_bins:
+                raise RuntimeError(f"expected input with {self.freq_bins} channels (freq_bins), got {mixed.shape[1]}")
+            if lips.shape[0] != mixed.shape[0]:
+                raise RuntimeError(f"batch mismatch: mixed_spec {mixed.shape[0]}, lip_frames {lips.shape[0]}")
+            if mixed.shape[2] > _MAX_LEN or lips.shape[1] > _MAX_LEN:
+                raise RuntimeError(f"sequence length exceeds PositionalEncoding max_len {_MAX_LEN}")
+            return train_forward(self, mixed, lips)
         _guard_mode(self)
         mixed = _prep(mixed_spec, "mixed_spec", 3)
         lips = _prep(lip_frames, "lip_frames", 4)

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         const float* __restrict__ k, int ldk,
                                                         const float* __restrict__ v, int ldv,
                                                         float* __restrict__ o, int ldo, int nhead, int Lq,
-                                                        int Lk, int nqt, int DH) {
+                                                        int Lk, int nqt, int DH, float qscale,
+                                                        float* __restrict__ lse) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int c = lane & 15;    // query column (as B operand / C column); key row (as A operand of S^T)
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   f32x4 qf[NB];
 #pragma unroll
   for (int s = 0; s < NB; ++s)
-    qf[s] = (REG || 16 * s + 4 * g < DH) ? *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g)
-                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    qf[s] = ((REG || 16 * s + 4 * g < DH) ? *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f}) * qscale;
 
   f32x4 acc[NB];
 #pragma unroll
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   lrun += __shfl_xor(lrun, 32);
   const float inv = 1.0f / lrun;
   const int qo = qt * 16 + c;
+  if (lse && g == 0 && qo < Lq) lse[(size_t)bh * Lq + qo] = mrun + logf(lrun);   // training: softmax statistics
   if (qo < Lq) {
     // lane (c, g) holds O[qo][dv = NB*(4g+reg) + blk]; for a fixed reg the NB blks are contiguous
 #pragma unroll
@@ -278,6 +280,14 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const float* __res
 
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                             int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s) {
+  return launch_attention_ex(q, ldq, k, ldk, v, ldv, o, ldo, B, nhead, dh, Lq, Lk, 1.0f, nullptr, s);
+}
+
+// qscale: multiplies q on load (training path keeps 1/sqrt(dh) out of the weights); lse (B*nhead*Lq floats, may be
+// null): log-sum-exp of each query's scores, consumed by the backward kernels.
+hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                               int ldo, int B, int nhead, int dh, int Lq, int Lk, float qscale, float* lse,
+                               hipStream_t s) {
   if (B <= 0 || nhead <= 0 || Lq <= 0 || Lk <= 0) return hipErrorInvalidValue;
   if ((ldq | ldk | ldv | ldo) & 3) return hipErrorInvalidValue;   // float4 row alignment
   const int nqt = (Lq + 15) / 16;
@@ -285,7 +295,7 @@ hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, co
   const dim3 grid((unsigned)(B * nhead * wg_per_head)), block(256);
   if (dh <= 0 || dh > 128 || (dh & 3)) return hipErrorInvalidValue;
   static const bool no_short = getenv("AVSEP_NO_SHORT_ATTN") != nullptr;   // developer A/B switch
-  if (dh == 64 && Lk > 48 && Lk <= 64 && !no_short) {
+  if (dh == 64 && Lk > 48 && Lk <= 64 && !no_short && !lse && qscale == 1.0f) {
     hipLaunchKernelGGL((attention_short_kernel<4, 4>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq,
                        Lk, nqt);
     return hipGetLastError();
@@ -295,9 +305,9 @@ hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, co
 #define AVSEP_ATT(NB_)                                                                                              \
   if (nb == NB_) {                                                                                                  \
     if (reg) hipLaunchKernelGGL((attention_kernel<NB_, true>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,   \
-                                nhead, Lq, Lk, nqt, dh);                                                            \
+                                nhead, Lq, Lk, nqt, dh, qscale, lse);                                               \
     else hipLaunchKernelGGL((attention_kernel<NB_, false>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,      \
-                            nhead, Lq, Lk, nqt, dh);                                                                \
+                            nhead, Lq, Lk, nqt, dh, qscale, lse);                                                   \
   }
   AVSEP_ATT(1) AVSEP_ATT(2) AVSEP_ATT(3) AVSEP_ATT(4) AVSEP_ATT(5) AVSEP_ATT(6) AVSEP_ATT(7) AVSEP_ATT(8)
 #undef AVSEP_ATT

@@ -667,6 +667,8 @@ int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* mas
 }  // namespace
 
 // ============================================================================================ C ABI
+extern "C" void avsep_set_error_(const char* msg) { g_err = msg ? msg : ""; }   // used by train_api.hip
+
 extern "C" {
 
 int avsep_abi_version(void) { return AVSEP_ABI_VERSION; }

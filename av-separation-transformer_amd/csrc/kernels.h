@@ -46,6 +46,38 @@ hipError_t launch_layernorm(const float* x, const float* g, const float* b, floa
                             hipStream_t s);
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                             float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s);
+hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                               float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, float qscale, float* lse,
+                               hipStream_t s);
+hipError_t launch_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                const float* o, int ldo, const float* dO, int lddo, const float* lse, float* dvec,
+                                float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh,
+                                int Lq, int Lk, float qscale, hipStream_t s);
+// training-path kernels (train_ops.hip)
+hipError_t launch_transpose2d(const float* x, float* y, int R, int C, int Rp, hipStream_t s);
+hipError_t launch_im2col1d(const float* x, float* col, int M, int T, int C, hipStream_t s);
+hipError_t launch_col2im1d(const float* dcol, float* dx, int M, int T, int C, hipStream_t s);
+hipError_t launch_im2col2d(const float* x, float* col, int I, int H, int W, int C, int Ho, int Wo, int Kp, hipStream_t s);
+hipError_t launch_col2im2d(const float* dcol, float* dx, int I, int H, int W, int C, int Ho, int Wo, int Kp, hipStream_t s);
+hipError_t launch_colreduce(const float* a, const float* b, float* part, float* out0, float* out1, int M, int C,
+                            float scale, hipStream_t s);
+int colreduce_part_floats(int M, int C);
+hipError_t launch_bn_var(const float* x, const float* mean, float* part, float* out, int M, int C, hipStream_t s);
+hipError_t launch_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                           float* xhat, float* y, size_t n, int C, int relu, float eps, hipStream_t s);
+hipError_t launch_bn_bwd(const float* dyr, const float* xhat, const float* gamma, const float* var,
+                         const float* sum_dy, const float* sum_dyx, float* dx, size_t n, int C, float invM, float eps,
+                         hipStream_t s);
+hipError_t launch_bn_running(float* rmean, float* rvar, const float* mean, const float* var, int C, float momentum,
+                             int M, hipStream_t s);
+hipError_t launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t s);
+hipError_t launch_act_bwd(const float* dy, const float* aux, float* dx, size_t n, int act, hipStream_t s);
+hipError_t launch_mul_mixed(const float* a, const float* xt, float* out, size_t M, int S, int F, int ldx, hipStream_t s);
+hipError_t launch_add_rows(const float* x, const float* r, float* y, size_t M, int C, int period, hipStream_t s);
+hipError_t launch_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, hipStream_t s);
+hipError_t launch_interp_bwd(const float* dy, float* dx, int B, int N, int T, int d, hipStream_t s);
+hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* xhat, int M,
+                                int d, float eps, hipStream_t s);
 // (B,F,T) -> (B,T,Fp) zero padded
 hipError_t launch_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, hipStream_t s);
 // first visual conv (Cin=1) + folded BN + ReLU: frames (M,H,W) -> act (M,Ho,Wo,32) channels-last

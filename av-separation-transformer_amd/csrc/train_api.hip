@@ -1,0 +1,180 @@
+// train_api.hip -- C ABI of the training-path ops (include/avsep.h, section "training ops").  Stateless wrappers
+// around the kernels of train_ops.hip / attention_bwd.hip / gemm.hip; the Python autograd layer
+// (av_separation/_train.py) composes them.  Scratch buffers are caller-provided; nothing allocates or syncs.
+#include "../../include/avsep.h"
+#include "kernels.h"
+
+#include <string>
+
+extern "C" void avsep_set_error_(const char* msg);   // avsep_api.hip (thread-local message for avsep_last_error)
+
+namespace {
+int fail(int code, const char* msg) {
+  avsep_set_error_(msg);
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  avsep_set_error_((std::string(what) + ": " + hipGetErrorString(e)).c_str());
+  return AVSEP_EHIP;
+}
+#define TCK(x)                                        \
+  do {                                                \
+    hipError_t e_ = (x);                              \
+    if (e_ != hipSuccess) return hip_fail(e_, #x);    \
+  } while (0)
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+
+extern "C" {
+
+int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
+                       int ldr, int rperiod, float* y, int ldc, int M, int N, int K, int act, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || (lda & 3) || (ldw & 3)) return fail(AVSEP_EINVAL, "K must be a multiple of 32 and rows 16-byte aligned");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  GemmParams p{};
+  p.A = x; p.W = w; p.bias = bias; p.C = y;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+  p.amode = AMODE_PLAIN;
+  p.act = act;
+  p.R = residual; p.ldr = ldr; p.rperiod = rperiod;
+  TCK(launch_gemm(p, S(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
+                             int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, void* stream) {
+  if (!q || !k || !v || !out || !lse) return fail(AVSEP_EINVAL, "null pointer");
+  TCK(launch_attention_ex(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, qscale, lse, S(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                           int ldo, const float* d_out, int lddo, const float* lse, float* dvec, float* dq, int lddq,
+                           float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh, int Lq, int Lk,
+                           float qscale, void* stream) {
+  if (!q || !k || !v || !o || !d_out || !lse || !dvec || !dq || !dk || !dv) return fail(AVSEP_EINVAL, "null pointer");
+  if (dh % 16) return fail(AVSEP_EINVAL, "training path: head dim must be a multiple of 16");
+  TCK(launch_attention_bwd(q, ldq, k, ldk, v, ldv, o, ldo, d_out, lddo, lse, dvec, dq, lddq, dk, lddk, dv, lddv, B, nhead,
+                           dh, Lq, Lk, qscale, S(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_transpose(const float* x, float* y, int R, int C, int Rp, void* stream) {
+  if (!x || !y || R <= 0 || C <= 0 || Rp < R) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_transpose2d(x, y, R, C, Rp, S(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, void* stream) {
+  if (!x || !y || B <= 0 || F <= 0 || T <= 0 || Fp < F) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_transpose_pad(x, y, B, F, T, Fp, S(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_im2col1d(const float* x, float* col, int M, int T, int C, void* stream) {
+  if (!x || !col || M <= 0 || T <= 0 || M % T || C <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_im2col1d(x, col, M, T, C, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_col2im1d(const float* dcol, float* dx, int M, int T, int C, void* stream) {
+  if (!dcol || !dx || M <= 0 || T <= 0 || M % T || C <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_col2im1d(dcol, dx, M, T, C, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_im2col2d(const float* x, float* col, int I, int H, int W, int C, int Kp, void* stream) {
+  if (!x || !col || I <= 0 || H <= 0 || W <= 0 || C <= 0 || Kp < 9 * C) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_im2col2d(x, col, I, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Kp, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_col2im2d(const float* dcol, float* dx, int I, int H, int W, int C, int Kp, void* stream) {
+  if (!dcol || !dx || I <= 0 || H <= 0 || W <= 0 || C <= 0 || Kp < 9 * C) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_col2im2d(dcol, dx, I, H, W, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1, Kp, S(stream)));
+  return AVSEP_OK;
+}
+
+int64_t avsep_op_colreduce_scratch_floats(int M, int C) { return colreduce_part_floats(M, C); }
+
+int avsep_op_colreduce(const float* a, const float* b, float* scratch, float* out0, float* out1, int M, int C,
+                       void* stream) {
+  if (!a || !scratch || !out0 || (b && !out1) || M <= 0 || C <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_colreduce(a, b, scratch, out0, out1, M, C, 1.0f, S(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* xhat,
+                          float* y, float* running_mean, float* running_var, float* scratch, int M, int C, float eps,
+                          float momentum, int relu, void* stream) {
+  if (!x || !gamma || !beta || !mean || !var || !xhat || !y || !scratch || M <= 0 || C <= 0)
+    return fail(AVSEP_EINVAL, "bad argument");
+  hipStream_t s = S(stream);
+  TCK(launch_colreduce(x, nullptr, scratch, mean, nullptr, M, C, 1.0f / (float)M, s));
+  TCK(launch_bn_var(x, mean, scratch, var, M, C, s));
+  TCK(launch_bn_apply(x, mean, var, gamma, beta, xhat, y, (size_t)M * C, C, relu, eps, s));
+  if (running_mean && running_var) TCK(launch_bn_running(running_mean, running_var, mean, var, C, momentum, M, s));
+  return AVSEP_OK;
+}
+
+int avsep_op_bn_train_bwd(const float* dy, const float* y, const float* xhat, const float* gamma, const float* var,
+                          float* dx, float* dgamma, float* dbeta, float* dyr_scratch, float* scratch, int M, int C,
+                          float eps, int relu, void* stream) {
+  if (!dy || !y || !xhat || !gamma || !var || !dx || !dgamma || !dbeta || !dyr_scratch || !scratch || M <= 0 || C <= 0)
+    return fail(AVSEP_EINVAL, "bad argument");
+  hipStream_t s = S(stream);
+  const size_t n = (size_t)M * C;
+  const float* dyr = dy;
+  if (relu) {
+    TCK(launch_act_bwd(dy, y, dyr_scratch, n, ACT_RELU, s));
+    dyr = dyr_scratch;
+  }
+  TCK(launch_colreduce(dyr, xhat, scratch, dbeta, dgamma, M, C, 1.0f, s));
+  TCK(launch_bn_bwd(dyr, xhat, gamma, var, dbeta, dgamma, dx, n, C, 1.0f / (float)M, eps, s));
+  return AVSEP_OK;
+}
+
+int avsep_op_act_fwd(const float* x, float* y, int64_t n, int act, void* stream) {
+  if (!x || !y || n <= 0 || act < 1 || act > 3) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_act_fwd(x, y, (size_t)n, act, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_act_bwd(const float* dy, const float* aux, float* dx, int64_t n, int act, void* stream) {
+  if (!dy || !aux || !dx || n <= 0 || act < 1 || act > 3) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_act_bwd(dy, aux, dx, (size_t)n, act, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_mul_mixed(const float* a, const float* xt, float* out, int64_t M, int S_, int F, int ldx, void* stream) {
+  if (!a || !xt || !out || M <= 0 || S_ <= 0 || F <= 0 || ldx < F) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_mul_mixed(a, xt, out, (size_t)M, S_, F, ldx, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_add_rows(const float* x, const float* r, float* y, int64_t M, int C, int period, void* stream) {
+  if (!x || !r || !y || M <= 0 || C <= 0 || period <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_add_rows(x, r, y, (size_t)M, C, period, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_avgpool_fwd(const float* x, float* y, int M, int P, int C, void* stream) {
+  if (!x || !y || M <= 0 || P <= 0 || C <= 0 || (C & 3)) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_avgpool(x, y, M, P, C, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, void* stream) {
+  if (!dy || !dx || M <= 0 || P <= 0 || C <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_avgpool_bwd(dy, dx, M, P, C, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_interp_linear_bwd(const float* dy, float* dx, int B, int N, int T, int d, void* stream) {
+  if (!dy || !dx || B <= 0 || N <= 0 || T <= 0 || d <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_interp_bwd(dy, dx, B, N, T, d, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                           float* xhat_scratch, float* scratch, int M, int d, float eps, void* stream) {
+  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !xhat_scratch || !scratch) return fail(AVSEP_EINVAL, "null pointer");
+  hipStream_t s = S(stream);
+  TCK(launch_layernorm_bwd(dy, x, gamma, dx, xhat_scratch, M, d, eps, s));
+  TCK(launch_colreduce(dy, xhat_scratch, scratch, dbeta, dgamma, M, d, 1.0f, s));
+  return AVSEP_OK;
+}
+
+}  // extern "C"

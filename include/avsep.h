@@ -129,6 +129,57 @@ int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const f
                        int ldo, int B, int nhead, int dh, int Lq, int Lk, void* stream);
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Training ops (what demo.py:83-113 / tests/test_model.py:210-217,332-353 exercise through
+ * torch autograd).  Stateless; activations are row tensors [rows][C] (channels last); scratch is caller-owned.
+ * The Python layer (av_separation/_train.py) composes them under torch.autograd.Function wrappers.  Dense
+ * contractions of the backward pass reuse avsep_op_linear_ex on transposed operands (dX = dY W, dW = dY^T X).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* y[m][n] = act(x W^T + b) (+ residual[(m % rperiod)][n], rperiod <= 0: row m); general leading dimensions */
+int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
+                       int ldr, int rperiod, float* y, int ldc, int M, int N, int K, int act, void* stream);
+/* attention forward that also returns the per-query log-sum-exp (B*nhead*Lq) and scales q by qscale on load */
+int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
+                             int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, void* stream);
+/* gradients of softmax((qscale q) k^T) v w.r.t. q, k, v; dvec: B*nhead*Lq floats of scratch; dh % 16 == 0 */
+int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                           int ldo, const float* d_out, int lddo, const float* lse, float* dvec, float* dq, int lddq,
+                           float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh, int Lq, int Lk,
+                           float qscale, void* stream);
+/* y[c][r] = x[r][c] (x [R][C] -> y [C][Rp], zero for r >= R) */
+int avsep_op_transpose(const float* x, float* y, int R, int C, int Rp, void* stream);
+/* (B,F,T) -> (B,T,Fp), zero padded: the layout pass in front of the first Conv1d */
+int avsep_op_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, void* stream);
+/* Conv1d k3 p1 / Conv2d k3 s2 p1 as im2col (+ GEMM) and their adjoints */
+int avsep_op_im2col1d(const float* x, float* col, int M, int T, int C, void* stream);
+int avsep_op_col2im1d(const float* dcol, float* dx, int M, int T, int C, void* stream);
+int avsep_op_im2col2d(const float* x, float* col, int I, int H, int W, int C, int Kp, void* stream);
+int avsep_op_col2im2d(const float* dcol, float* dx, int I, int H, int W, int C, int Kp, void* stream);
+/* deterministic two-stage column sums: out0[c] = sum_r a[r][c]; with b: out1[c] = sum_r a[r][c] b[r][c] */
+int64_t avsep_op_colreduce_scratch_floats(int M, int C);
+int avsep_op_colreduce(const float* a, const float* b, float* scratch, float* out0, float* out1, int M, int C,
+                       void* stream);
+/* BatchNorm2d in training mode on rows [M][C] (+ optional fused ReLU): batch mean / biased var out, xhat saved,
+ * running statistics updated in place (unbiased variance, momentum) when given */
+int avsep_op_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* xhat,
+                          float* y, float* running_mean, float* running_var, float* scratch, int M, int C, float eps,
+                          float momentum, int relu, void* stream);
+int avsep_op_bn_train_bwd(const float* dy, const float* y, const float* xhat, const float* gamma, const float* var,
+                          float* dx, float* dgamma, float* dbeta, float* dyr_scratch, float* scratch, int M, int C,
+                          float eps, int relu, void* stream);
+/* activations (1 relu, 2 gelu-erf, 3 sigmoid); backward aux = output (relu, sigmoid) or pre-activation (gelu) */
+int avsep_op_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
+int avsep_op_act_bwd(const float* dy, const float* aux, float* dx, int64_t n, int act, void* stream);
+/* out[m][s*F+f] = a[m][s*F+f] * xt[m][f]: SeparationDecoder.separate and its adjoint w.r.t. the masks */
+int avsep_op_mul_mixed(const float* a, const float* xt, float* out, int64_t M, int S, int F, int ldx, void* stream);
+/* y[m][c] = x[m][c] + r[m % period][c]  (PositionalEncoding add, model.py:300) */
+int avsep_op_add_rows(const float* x, const float* r, float* y, int64_t M, int C, int period, void* stream);
+int avsep_op_avgpool_fwd(const float* x, float* y, int M, int P, int C, void* stream);
+int avsep_op_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, void* stream);
+int avsep_op_interp_linear_bwd(const float* dy, float* dx, int B, int N, int T, int d, void* stream);
+int avsep_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                           float* xhat_scratch, float* scratch, int M, int d, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -280,6 +280,42 @@ def make_losses(outdir):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def make_train(outdir):
+    """Train-mode forward + backward of the reference (dropout 0 so it is deterministic, as in the reference's own
+    gradient tests, tests/test_model.py:195,338): BatchNorm batch statistics, SeparationLoss(0.5), every
+    parameter gradient, updated BN buffers.  Pins the N1 training path."""
+    for name, base, full in (("tiny", "tiny", True), ("odd", "odd", False)):
+        c = dict(CONFIGS[base], seed=CONFIGS[base]["seed"] + 100)
+        shapes = seeded.model_shapes(c["F"], c["d"], c["h"], c["Le"], c["Lf"], c["S"])
+        state = seeded.fill_state(shapes, c["seed"], gain=1.0)
+        m = build_reference(c, state).train()
+        mx, lp = seeded.inputs(c["seed"], c["B"], c["F"], c["T"], c["N"], c["H"], c["W"])
+        tg = (seeded.tensor(c["seed"], "train.targets", (c["B"], c["S"], c["F"], c["T"]), 0.0, 1.0).astype(np.float64)
+              ** 2 * mx[:, None]).astype(np.float32)
+        mixed, lips, targets = torch.from_numpy(mx), torch.from_numpy(lp), torch.from_numpy(tg)
+        sep, masks = m(mixed, lips)
+        loss = SeparationLoss(l1_weight=0.5)(sep, targets)
+        loss.backward()
+        out = {"config": np.array(json.dumps(c)), "targets": tg, "loss": np.float64(loss.item()),
+               "gain": np.float64(1.0)}
+        out["separated"] = sep.detach().contiguous().numpy()
+        out["masks"] = masks.detach().contiguous().numpy()
+        for k, p_ in m.named_parameters():
+            g_ = p_.grad.numpy()
+            if full:
+                out["g." + k] = g_
+            else:
+                out["g." + k + ".slice"] = g_.reshape(-1)[::5].copy()
+                out["g." + k + ".norm"] = np.float64(np.linalg.norm(g_.astype(np.float64)))
+        for k, v in m.state_dict().items():
+            if "running_" in k or k.endswith("num_batches_tracked"):
+                out["buf." + k] = v.numpy()
+        path = os.path.join(outdir, f"train_{name}.npz")
+        np.savez_compressed(path, **out)
+        gn = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in m.parameters())))
+        print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB loss {loss.item():.4f} |grad| {gn:.4f}")
+
+
 def make_eval(outdir):
     """demo.py's evaluate_separation / snr_db / _permutation_snr on the trained tiny model (reference numbers)."""
     sys.path.insert(0, "/root/reference")
@@ -317,6 +353,8 @@ def main():
         make_losses(a.out)
     if a.only in (None, "eval"):
         make_eval(a.out)
+    if a.only in (None, "train"):
+        make_train(a.out)
 
 
 if __name__ == "__main__":

@@ -113,10 +113,12 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         m.audio_encoder(torch.zeros(2, 65, 32))
 
 
-def test_train_mode_is_refused_not_faked():
+def test_train_mode_never_fakes_eval_semantics():
     m = AVSeparationTransformer(freq_bins=65, d_model=64).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # the training path is HIP-only as well
         m(torch.zeros(2, 65, 32), torch.zeros(2, 10, 16, 16))
+    with pytest.raises(NotImplementedError):                         # stage modules are inference-only
+        m.audio_encoder(torch.zeros(2, 65, 32))
 
 
 def test_separate_is_broadcast_multiply():
