@@ -14,8 +14,12 @@ torch supplies only what BASELINE.json's north star leaves to it: tensor allocat
 parameters (layout plumbing whose adjoints autograd replays), the graph bookkeeping, and the SI-SNR/L1 loss.
 Gradient parity against the reference is pinned by tests/golden/train_*.npz (tests/test_train_gpu.py).
 
-Round-1 scope: correctness; every op is its own launch (no fusion, no graph), dropout must be 0 (the reference's
-own gradient tests use dropout=0.0 too) -- a non-zero dropout in train mode raises.
+Round-1 scope: correctness; every op is its own launch (no fusion, no graph).  Dropout (the reference's default
+0.1: PositionalEncoding, the attention probabilities, the residual branches and FFN/decoder hidden layers) uses a
+stateless counter-based mask generated in the kernels from (seed, element index), so the backward regenerates it;
+the per-forward base seed is drawn from torch's CPU generator (``torch.manual_seed`` makes runs repeatable).  Mask
+streams cannot match torch's Philox streams, so gradient parity is pinned with dropout = 0 (as the reference's own
+gradient tests do) and dropout > 0 by self-consistency tests.
 """
 from __future__ import annotations
 
@@ -176,7 +180,7 @@ class AttentionFn(torch.autograd.Function):
     packed in_proj output is used in place (leading dimension = row width)."""
 
     @staticmethod
-    def forward(ctx, qt, kvt, qoff, koff, voff, B, h, dh, Lq, Lk, scale):
+    def forward(ctx, qt, kvt, qoff, koff, voff, B, h, dh, Lq, Lk, scale, drop_p=0.0, drop_seed=0):
         qt, kvt = _c(qt), _c(kvt)
         d = h * dh
         o = torch.empty(B * Lq, d, device=qt.device)
@@ -184,15 +188,16 @@ class AttentionFn(torch.autograd.Function):
         ldq, ldk = qt.shape[1], kvt.shape[1]
         base_q, base_kv = qt.data_ptr(), kvt.data_ptr()
         _ck(_lib().avsep_op_attention_train(base_q + 4 * qoff, ldq, base_kv + 4 * koff, ldk, base_kv + 4 * voff, ldk,
-                                            o.data_ptr(), d, lse.data_ptr(), B, h, dh, Lq, Lk, scale, _st(qt)), "attention_train")
-        ctx.meta = (qoff, koff, voff, B, h, dh, Lq, Lk, scale, qt is kvt)
+                                            o.data_ptr(), d, lse.data_ptr(), B, h, dh, Lq, Lk, scale, drop_p, drop_seed,
+                                            _st(qt)), "attention_train")
+        ctx.meta = (qoff, koff, voff, B, h, dh, Lq, Lk, scale, qt is kvt, drop_p, drop_seed)
         ctx.save_for_backward(qt, kvt, o, lse)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qt, kvt, o, lse = ctx.saved_tensors
-        qoff, koff, voff, B, h, dh, Lq, Lk, scale, same = ctx.meta
+        qoff, koff, voff, B, h, dh, Lq, Lk, scale, same, drop_p, drop_seed = ctx.meta
         do = _c(do)
         d = h * dh
         dqt = torch.zeros_like(qt)
@@ -203,8 +208,8 @@ class AttentionFn(torch.autograd.Function):
                                           kvt.data_ptr() + 4 * voff, ldk, o.data_ptr(), d, do.data_ptr(), d,
                                           lse.data_ptr(), dvec.data_ptr(), dqt.data_ptr() + 4 * qoff, ldq,
                                           dkvt.data_ptr() + 4 * koff, ldk, dkvt.data_ptr() + 4 * voff, ldk, B, h, dh, Lq,
-                                          Lk, scale, _st(qt)), "attention_bwd")
-        return dqt, (None if same else dkvt), None, None, None, None, None, None, None, None, None
+                                          Lk, scale, drop_p, drop_seed, _st(qt)), "attention_bwd")
+        return dqt, (None if same else dkvt), None, None, None, None, None, None, None, None, None, None, None
 
 
 class Im2col1dFn(torch.autograd.Function):
@@ -283,6 +288,42 @@ class BatchNormReluFn(torch.autograd.Function):
                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), tmp.data_ptr(), s.data_ptr(), M, Cc,
                                          ctx.eps, 1, _st(y)), "bn_train_bwd")
         return dx, dg, db, None, None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """Inverted dropout with the kernels' stateless mask; backward = the same op on the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _ck(_lib().avsep_op_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _st(x)), "dropout")
+        ctx.meta = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _ck(_lib().avsep_op_dropout(dy.data_ptr(), dx.data_ptr(), dy.numel(), p, seed, _st(dy)), "dropout(bwd)")
+        return dx, None, None
+
+
+class AddFn(torch.autograd.Function):
+    """x + y (same shape), for residual branches that pass through dropout first."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _c(x), _c(y)
+        out = torch.empty_like(x)
+        _ck(_lib().avsep_op_add_rows(x.data_ptr(), y.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.shape[0],
+                                     _st(x)), "add")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
 
 
 class AddRowsFn(torch.autograd.Function):
@@ -364,17 +405,40 @@ class MulMixedFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------- model composition
-def _encoder_layer(x, P, pre, B, L, h):
-    """nn.TransformerEncoderLayer(norm_first=True, relu, ff=4d), dropout 0  (model.py:48-52)."""
+class _Drop:
+    """Dropout bookkeeping of one forward: probability per module and a fresh seed per site."""
+
+    def __init__(self, seed):
+        self.base = int(seed) & 0x3FFFFFFFFFFFFFFF
+        self.site = 0
+
+    def seed(self):
+        self.site += 1
+        return (self.base + 0x9E3779B97F4A7C15 * self.site) & 0xFFFFFFFFFFFFFFFF
+
+    def __call__(self, x, p):
+        return DropoutFn.apply(x, p, self.seed()) if p > 0 else x
+
+
+def _residual_linear(x_res, inp, w, b, p, drop):
+    """x_res + dropout(inp w^T + b): the residual rides the GEMM epilogue unless dropout sits in between."""
+    if p > 0:
+        return AddFn.apply(x_res, drop(LinearFn.apply(inp, w, b, ACT_NONE, None, 0), p))
+    return LinearFn.apply(inp, w, b, ACT_NONE, x_res, 0)
+
+
+def _encoder_layer(x, P, pre, B, L, h, p, drop):
+    """nn.TransformerEncoderLayer(norm_first=True, relu, ff=4d)  (model.py:48-52): attention-probability dropout,
+    dropout1 on the attention branch, dropout after the ReLU and dropout2 on the FFN branch."""
     d = x.shape[1]
     dh = d // h
     n = LayerNormFn.apply(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5)
     qkv = LinearFn.apply(n, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"], ACT_NONE, None, 0)
-    o = AttentionFn.apply(qkv, qkv, 0, d, 2 * d, B, h, dh, L, L, 1.0 / math.sqrt(dh))
-    x = LinearFn.apply(o, P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], ACT_NONE, x, 0)
+    o = AttentionFn.apply(qkv, qkv, 0, d, 2 * d, B, h, dh, L, L, 1.0 / math.sqrt(dh), p, drop.seed() if p > 0 else 0)
+    x = _residual_linear(x, o, P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], p, drop)
     n = LayerNormFn.apply(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)
-    f = LinearFn.apply(n, P[pre + "linear1.weight"], P[pre + "linear1.bias"], ACT_RELU, None, 0)
-    return LinearFn.apply(f, P[pre + "linear2.weight"], P[pre + "linear2.bias"], ACT_NONE, x, 0)
+    f = drop(LinearFn.apply(n, P[pre + "linear1.weight"], P[pre + "linear1.bias"], ACT_RELU, None, 0), p)
+    return _residual_linear(x, f, P[pre + "linear2.weight"], P[pre + "linear2.bias"], p, drop)
 
 
 def _count(P, prefix):
@@ -384,12 +448,15 @@ def _count(P, prefix):
     return n
 
 
-def train_forward(model, mixed, lips):
+def train_forward(model, mixed, lips, seed=None):
     """Train-mode AVSeparationTransformer.forward (model.py:268-276) with autograd through the HIP ops.
-    Returns (separated, masks) as (B,S,F,T) views of (B,T,S,F) tensors, like the inference path."""
-    if any(getattr(m, "dropout_p", 0.0) > 0 for m in model.modules()):
-        raise NotImplementedError("train-mode dropout > 0 is not built yet on the HIP path (use dropout=0.0, as the "
-                                  "reference's gradient tests do)")
+    Returns (separated, masks) as (B,S,F,T) views of (B,T,S,F) tensors, like the inference path.
+    ``seed``: base seed of this forward's dropout masks (default: drawn from torch's CPU generator)."""
+    pa, pv = model.audio_encoder.dropout_p, model.visual_encoder.dropout_p
+    pf, pd = model.fusion.dropout_p, model.decoder.dropout_p
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if max(pa, pv, pf, pd) > 0 else 0
+    drop = _Drop(seed)
     P = dict(model.named_parameters())
     Bf = dict(model.named_buffers())
     B, Fq, T = mixed.shape
@@ -409,9 +476,9 @@ def train_forward(model, mixed, lips):
     w2 = P["audio_encoder.input_proj.2.weight"].permute(0, 2, 1).reshape(d, 3 * d)
     pe_a = _c(Bf["audio_encoder.pos_enc.pe"][0, :T])
     a = LinearFn.apply(Im2col1dFn.apply(hcur, T), w2, P["audio_encoder.input_proj.2.bias"], ACT_RELU, None, 0)
-    a = AddRowsFn.apply(a, pe_a, T)
+    a = drop(AddRowsFn.apply(a, pe_a, T), pa)
     for i in range(_count(P, "audio_encoder.transformer.layers.")):
-        a = _encoder_layer(a, P, f"audio_encoder.transformer.layers.{i}.", B, T, h)
+        a = _encoder_layer(a, P, f"audio_encoder.transformer.layers.{i}.", B, T, h, pa, drop)
 
     # ---- visual encoder (model.py:103-117), BatchNorm in training mode
     Mv = B * N
@@ -431,9 +498,10 @@ def train_forward(model, mixed, lips):
         hh, ww, cin = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1, cout
     pooled = AvgPoolFn.apply(x, Mv, hh * ww)
     pe_v = _c(Bf["visual_encoder.pos_enc.pe"][0, :N])
-    v = LinearFn.apply(pooled, P["visual_encoder.frame_proj.weight"], P["visual_encoder.frame_proj.bias"], ACT_NONE, pe_v, N)
+    v = drop(LinearFn.apply(pooled, P["visual_encoder.frame_proj.weight"], P["visual_encoder.frame_proj.bias"], ACT_NONE,
+                            pe_v, N), pv)
     for i in range(_count(P, "visual_encoder.transformer.layers.")):
-        v = _encoder_layer(v, P, f"visual_encoder.transformer.layers.{i}.", B, N, h)
+        v = _encoder_layer(v, P, f"visual_encoder.transformer.layers.{i}.", B, N, h, pv, drop)
     v = InterpFn.apply(v, B, N, T)
 
     # ---- cross-modal fusion (model.py:145-173): visual is not normalised and feeds every layer
@@ -444,15 +512,16 @@ def train_forward(model, mixed, lips):
         n = LayerNormFn.apply(a, P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-5)
         q = LinearFn.apply(n, win[:d], bin_[:d], ACT_NONE, None, 0)
         kv = LinearFn.apply(v, win[d:], bin_[d:], ACT_NONE, None, 0)
-        o = AttentionFn.apply(q, kv, 0, 0, d, B, h, dh, T, T, 1.0 / math.sqrt(dh))
-        a = LinearFn.apply(o, P[p + "cross_attn.out_proj.weight"], P[p + "cross_attn.out_proj.bias"], ACT_NONE, a, 0)
+        o = AttentionFn.apply(q, kv, 0, 0, d, B, h, dh, T, T, 1.0 / math.sqrt(dh), pf, drop.seed() if pf > 0 else 0)
+        a = _residual_linear(a, o, P[p + "cross_attn.out_proj.weight"], P[p + "cross_attn.out_proj.bias"], pf, drop)
         n = LayerNormFn.apply(a, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5)
-        f = ActFn.apply(LinearFn.apply(n, P[p + "ff.0.weight"], P[p + "ff.0.bias"], ACT_NONE, None, 0), ACT_GELU)
-        a = LinearFn.apply(f, P[p + "ff.3.weight"], P[p + "ff.3.bias"], ACT_NONE, a, 0)
+        f = drop(ActFn.apply(LinearFn.apply(n, P[p + "ff.0.weight"], P[p + "ff.0.bias"], ACT_NONE, None, 0), ACT_GELU), pf)
+        a = _residual_linear(a, f, P[p + "ff.3.weight"], P[p + "ff.3.bias"], pf, drop)
     a = LayerNormFn.apply(a, P["fusion.norm.weight"], P["fusion.norm.bias"], 1e-5)
 
     # ---- decoder (model.py:201-220)
-    hmid = ActFn.apply(LinearFn.apply(a, P["decoder.decoder.0.weight"], P["decoder.decoder.0.bias"], ACT_NONE, None, 0), ACT_GELU)
+    hmid = drop(ActFn.apply(LinearFn.apply(a, P["decoder.decoder.0.weight"], P["decoder.decoder.0.bias"], ACT_NONE, None, 0),
+                            ACT_GELU), pd)
     logits = LinearFn.apply(hmid, P["decoder.decoder.3.weight"], P["decoder.decoder.3.bias"], ACT_NONE, None, 0)
     masks = ActFn.apply(logits, ACT_SIGMOID)                                           # [M, S*F]
     sep = MulMixedFn.apply(masks, xt, S, Fq)

@@ -18,7 +18,7 @@ for Conv/Linear, xavier-uniform for MultiheadAttention.in_proj_weight, zeros for
 
 Training: ``AVSeparationTransformer.forward`` in ``.train()`` mode runs the op-by-op
 HIP training path of ``_train.py`` (autograd wrappers whose forward and backward are HIP kernels, BatchNorm batch
-statistics); dropout must be 0 there for now.  The stand-alone stage modules are inference-only and raise in
+statistics, stateless-mask dropout).  The stand-alone stage modules are inference-only and raise in
 train mode instead of silently running eval semantics.
 """
 from __future__ import annotations
@@ -263,8 +263,8 @@ def _guard_mode(module: nn.Module):
     global _warned_grad
     if module.training:
         raise NotImplementedError(
-            "train-mode forward (dropout, BatchNorm batch statistics, autograd) is not built yet on the "
-            "HIP path (SURVEY.md §8(f) N1); call .eval() for inference")
+            "the stand-alone stage modules are inference-only on the HIP path; train through "
+            "AVSeparationTransformer.forward (SURVEY.md §8(f) N1) or call .eval()")
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()) and not _warned_grad:
         _warned_grad = True
         warnings.warn("av_separation (MI355X): outputs of the HIP forward carry no autograd graph; "

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         const float* __restrict__ v, int ldv,
                                                         float* __restrict__ o, int ldo, int nhead, int Lq,
                                                         int Lk, int nqt, int DH, float qscale,
-                                                        float* __restrict__ lse) {
+                                                        float* __restrict__ lse, float drop_p,
+                                                        unsigned long long drop_seed) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int c = lane & 15;    // query column (as B operand / C column); key row (as A operand of S^T)
@@ -143,6 +144,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
     lrun = lrun * alpha + psum;                    // per-lane partial (own 4 keys per tile); reduced at the end
     mrun = mnew;
+    if (drop_p > 0.0f) {   // training: dropout on the attention probabilities (nn.MultiheadAttention dropout=p);
+                           // the normaliser keeps the undropped sum, kept entries are scaled by 1/(1-p)
+      const float keep_scale = 1.0f / (1.0f - drop_p);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned long long e = ((unsigned long long)bh * Lq + (qt * 16 + c)) * Lk + (kt * 16 + 4 * g + r);
+        pr[r] = dropout_keep(drop_seed, e, drop_p) ? pr[r] * keep_scale : 0.0f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[i] *= alpha;
 
@@ -280,14 +290,14 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const float* __res
 
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                             int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s) {
-  return launch_attention_ex(q, ldq, k, ldk, v, ldv, o, ldo, B, nhead, dh, Lq, Lk, 1.0f, nullptr, s);
+  return launch_attention_ex(q, ldq, k, ldk, v, ldv, o, ldo, B, nhead, dh, Lq, Lk, 1.0f, nullptr, 0.0f, 0ull, s);
 }
 
 // qscale: multiplies q on load (training path keeps 1/sqrt(dh) out of the weights); lse (B*nhead*Lq floats, may be
 // null): log-sum-exp of each query's scores, consumed by the backward kernels.
 hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                                int ldo, int B, int nhead, int dh, int Lq, int Lk, float qscale, float* lse,
-                               hipStream_t s) {
+                               float drop_p, unsigned long long drop_seed, hipStream_t s) {
   if (B <= 0 || nhead <= 0 || Lq <= 0 || Lk <= 0) return hipErrorInvalidValue;
   if ((ldq | ldk | ldv | ldo) & 3) return hipErrorInvalidValue;   // float4 row alignment
   const int nqt = (Lq + 15) / 16;
@@ -295,7 +305,7 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
   const dim3 grid((unsigned)(B * nhead * wg_per_head)), block(256);
   if (dh <= 0 || dh > 128 || (dh & 3)) return hipErrorInvalidValue;
   static const bool no_short = getenv("AVSEP_NO_SHORT_ATTN") != nullptr;   // developer A/B switch
-  if (dh == 64 && Lk > 48 && Lk <= 64 && !no_short && !lse && qscale == 1.0f) {
+  if (dh == 64 && Lk > 48 && Lk <= 64 && !no_short && !lse && qscale == 1.0f && drop_p == 0.0f) {
     hipLaunchKernelGGL((attention_short_kernel<4, 4>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq,
                        Lk, nqt);
     return hipGetLastError();
@@ -305,9 +315,9 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
 #define AVSEP_ATT(NB_)                                                                                              \
   if (nb == NB_) {                                                                                                  \
     if (reg) hipLaunchKernelGGL((attention_kernel<NB_, true>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,   \
-                                nhead, Lq, Lk, nqt, dh, qscale, lse);                                               \
+                                nhead, Lq, Lk, nqt, dh, qscale, lse, drop_p, drop_seed);                            \
     else hipLaunchKernelGGL((attention_kernel<NB_, false>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,      \
-                            nhead, Lq, Lk, nqt, dh, qscale, lse);                                                   \
+                            nhead, Lq, Lk, nqt, dh, qscale, lse, drop_p, drop_seed);                                \
   }
   AVSEP_ATT(1) AVSEP_ATT(2) AVSEP_ATT(3) AVSEP_ATT(4) AVSEP_ATT(5) AVSEP_ATT(6) AVSEP_ATT(7) AVSEP_ATT(8)
 #undef AVSEP_ATT

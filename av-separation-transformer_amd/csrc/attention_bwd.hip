@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                                                           const float* __restrict__ dO, int lddo,
                                                           const float* __restrict__ lse, float* __restrict__ dvec,
                                                           float* __restrict__ dq, int lddq, int nhead, int Lq, int Lk,
-                                                          int nqt, float qscale) {
+                                                          int nqt, float qscale, float drop_p,
+                                                          unsigned long long drop_seed) {
   constexpr int DH = 16 * NB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -103,7 +104,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     for (int r = 0; r < 4; ++r) {
       const int key = kt * 16 + 4 * g + r;
       const float pr = key < Lk ? exp_arg(st[r] - l) : 0.0f;
-      ds[r] = pr * (dp[r] - D);
+      float dpe = dp[r];
+      if (drop_p > 0.0f) {   // d/dP of the dropped-and-rescaled probabilities: same mask as the forward
+        const unsigned long long e = ((unsigned long long)bh * Lq + (qt * 16 + c)) * Lk + key;
+        dpe = dropout_keep(drop_seed, e, drop_p) ? dpe / (1.0f - drop_p) : 0.0f;
+      }
+      ds[r] = pr * (dpe - D);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -126,7 +132,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                                                            const float* __restrict__ dO, int lddo,
                                                            const float* __restrict__ lse, const float* __restrict__ dvec,
                                                            float* __restrict__ dk, int lddk, float* __restrict__ dv,
-                                                           int lddv, int nhead, int Lq, int Lk, int nkt, float qscale) {
+                                                           int lddv, int nhead, int Lq, int Lk, int nkt, float qscale,
+                                                           float drop_p, unsigned long long drop_seed) {
   constexpr int DH = 16 * NB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -175,7 +182,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
       const float l = lse[(size_t)bh * Lq + qc];
       const float D = dvec[(size_t)bh * Lq + qc];
       pr[r] = ok ? exp_arg(st[r] - l) : 0.0f;
-      ds[r] = pr[r] * (dp[r] - D);
+      float dpe = dp[r];
+      if (drop_p > 0.0f) {
+        const unsigned long long e = ((unsigned long long)bh * Lq + qc) * Lk + (kt * 16 + c);
+        const bool keep = dropout_keep(drop_seed, e, drop_p);
+        const float ks = 1.0f / (1.0f - drop_p);
+        dpe = keep ? dpe * ks : 0.0f;
+        ds[r] = pr[r] * (dpe - D);
+        pr[r] = keep ? pr[r] * ks : 0.0f;        // dV uses the dropped probabilities
+      } else {
+        ds[r] = pr[r] * (dpe - D);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 hipError_t launch_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                 const float* o, int ldo, const float* dO, int lddo, const float* lse, float* dvec,
                                 float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh,
-                                int Lq, int Lk, float qscale, hipStream_t s) {
+                                int Lq, int Lk, float qscale, float drop_p, unsigned long long drop_seed, hipStream_t s) {
   if (B <= 0 || nhead <= 0 || Lq <= 0 || Lk <= 0) return hipErrorInvalidValue;
   if (dh <= 0 || dh > 128 || (dh & 15)) return hipErrorInvalidValue;   // training path: head dim multiple of 16
   if ((ldq | ldk | ldv | ldo | lddo) & 3) return hipErrorInvalidValue;
@@ -214,9 +231,9 @@ hipError_t launch_attention_bwd(const float* q, int ldq, const float* k, int ldk
 #define AVSEP_ATTB(NB_)                                                                                              \
   if (dh == 16 * NB_) {                                                                                              \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<NB_>), gq, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, dO, lddo, lse,    \
-                       dvec, dq, lddq, nhead, Lq, Lk, nqt, qscale);                                                  \
+                       dvec, dq, lddq, nhead, Lq, Lk, nqt, qscale, drop_p, drop_seed);                               \
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<NB_>), gk, block, 0, s, q, ldq, k, ldk, v, ldv, dO, lddo, lse, dvec, dk, \
-                       lddk, dv, lddv, nhead, Lq, Lk, nkt, qscale);                                                  \
+                       lddk, dv, lddv, nhead, Lq, Lk, nkt, qscale, drop_p, drop_seed);                               \
   }
   AVSEP_ATTB(1) AVSEP_ATTB(2) AVSEP_ATTB(3) AVSEP_ATTB(4) AVSEP_ATTB(5) AVSEP_ATTB(6) AVSEP_ATTB(7) AVSEP_ATTB(8)
 #undef AVSEP_ATTB

@@ -6,6 +6,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Counter-based dropout mask (training path): splitmix64 of (seed, element index) -> uniform [0,1) from the top 24
+// bits; an element is kept when u >= p.  Stateless, so the backward regenerates exactly the forward's mask.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
+  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
 enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2 };
 
@@ -48,11 +58,12 @@ hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, co
                             float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s);
 hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, float qscale, float* lse,
-                               hipStream_t s);
+                               float drop_p, unsigned long long drop_seed, hipStream_t s);
 hipError_t launch_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                 const float* o, int ldo, const float* dO, int lddo, const float* lse, float* dvec,
                                 float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh,
-                                int Lq, int Lk, float qscale, hipStream_t s);
+                                int Lq, int Lk, float qscale, float drop_p, unsigned long long drop_seed, hipStream_t s);
+hipError_t launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s);
 // training-path kernels (train_ops.hip)
 hipError_t launch_transpose2d(const float* x, float* y, int R, int C, int Rp, hipStream_t s);
 hipError_t launch_im2col1d(const float* x, float* col, int M, int T, int C, hipStream_t s);

@@ -44,20 +44,28 @@ int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const f
 }
 
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
-                             int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, void* stream) {
+                             int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,
+                             uint64_t drop_seed, void* stream) {
   if (!q || !k || !v || !out || !lse) return fail(AVSEP_EINVAL, "null pointer");
-  TCK(launch_attention_ex(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, qscale, lse, S(stream)));
+  if (drop_p < 0.0f || drop_p >= 1.0f) return fail(AVSEP_EINVAL, "dropout probability must be in [0, 1)");
+  TCK(launch_attention_ex(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, qscale, lse, drop_p, drop_seed, S(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+  if (!x || !y || n <= 0 || p < 0.0f || p >= 1.0f) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_dropout(x, y, (size_t)n, p, seed, S(stream)));
   return AVSEP_OK;
 }
 
 int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                            int ldo, const float* d_out, int lddo, const float* lse, float* dvec, float* dq, int lddq,
                            float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh, int Lq, int Lk,
-                           float qscale, void* stream) {
+                           float qscale, float drop_p, uint64_t drop_seed, void* stream) {
   if (!q || !k || !v || !o || !d_out || !lse || !dvec || !dq || !dk || !dv) return fail(AVSEP_EINVAL, "null pointer");
   if (dh % 16) return fail(AVSEP_EINVAL, "training path: head dim must be a multiple of 16");
   TCK(launch_attention_bwd(q, ldq, k, ldk, v, ldv, o, ldo, d_out, lddo, lse, dvec, dq, lddq, dk, lddk, dv, lddv, B, nhead,
-                           dh, Lq, Lk, qscale, S(stream)));
+                           dh, Lq, Lk, qscale, drop_p, drop_seed, S(stream)));
   return AVSEP_OK;
 }
 

@@ -244,6 +244,15 @@ __global__ __launch_bounds__(256) void mul_mixed_kernel(const float* __restrict_
   out[idx] = a[idx] * xt[m * ldx + f];
 }
 
+// inverted dropout: y = keep ? x / (1-p) : 0 with the stateless mask of kernels.h (the backward applies the same op
+// to the gradient with the same seed)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                      float p, unsigned long long seed) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  y[idx] = dropout_keep(seed, idx, p) ? x[idx] / (1.0f - p) : 0.0f;
+}
+
 // y[m][c] = x[m][c] + r[m % period][c]   (x + pe[:, :L], model.py:300, when it cannot ride a GEMM epilogue)
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                        float* __restrict__ y, size_t n, int C, int period) {
@@ -432,6 +441,10 @@ hipError_t launch_act_bwd(const float* dy, const float* aux, float* dx, size_t n
 hipError_t launch_mul_mixed(const float* a, const float* xt, float* out, size_t M, int S, int F, int ldx,
                             hipStream_t s) {
   hipLaunchKernelGGL(mul_mixed_kernel, dim3(nblk(M * S * F)), dim3(256), 0, s, a, xt, out, M, S, F, ldx);
+  return hipGetLastError();
+}
+hipError_t launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s) {
+  hipLaunchKernelGGL(dropout_kernel, dim3(nblk(n)), dim3(256), 0, s, x, y, n, p, seed);
   return hipGetLastError();
 }
 hipError_t launch_add_rows(const float* x, const float* r, float* y, size_t M, int C, int period, hipStream_t s) {

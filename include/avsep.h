@@ -138,14 +138,19 @@ int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d,
 /* y[m][n] = act(x W^T + b) (+ residual[(m % rperiod)][n], rperiod <= 0: row m); general leading dimensions */
 int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
                        int ldr, int rperiod, float* y, int ldc, int M, int N, int K, int act, void* stream);
-/* attention forward that also returns the per-query log-sum-exp (B*nhead*Lq) and scales q by qscale on load */
+/* attention forward that also returns the per-query log-sum-exp (B*nhead*Lq) and scales q by qscale on load;
+ * drop_p > 0: dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training), stateless
+ * mask from (drop_seed, element index) that the backward regenerates */
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
-                             int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, void* stream);
+                             int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,
+                             uint64_t drop_seed, void* stream);
+/* inverted dropout y = keep ? x/(1-p) : 0 with the same stateless mask; its backward is the same call on dy */
+int avsep_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
 /* gradients of softmax((qscale q) k^T) v w.r.t. q, k, v; dvec: B*nhead*Lq floats of scratch; dh % 16 == 0 */
 int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                            int ldo, const float* d_out, int lddo, const float* lse, float* dvec, float* dq, int lddq,
                            float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh, int Lq, int Lk,
-                           float qscale, void* stream);
+                           float qscale, float drop_p, uint64_t drop_seed, void* stream);
 /* y[c][r] = x[r][c] (x [R][C] -> y [C][Rp], zero for r >= R) */
 int avsep_op_transpose(const float* x, float* y, int R, int C, int Rp, void* stream);
 /* (B,F,T) -> (B,T,Fp), zero padded: the layout pass in front of the first Conv1d */

@@ -100,3 +100,52 @@ def test_training_step_reduces_loss_and_eval_sees_new_weights():
     with torch.no_grad():
         _, masks_after = m(mixed, lips)
     assert float((masks_after - masks_before).abs().max()) > 1e-2
+
+
+def test_dropout_training_is_self_consistent():
+    """dropout > 0 (the reference's default 0.1): masks cannot match torch's RNG stream, so check what must hold
+    anyway: same seed -> same output, different seed -> different; keep rate and 1/(1-p) scaling of the mask;
+    and the analytic gradient of a fixed-mask forward agrees with a central finite difference along a random
+    direction."""
+    import ctypes as C
+    import av_separation as av
+    from av_separation import _native
+    from av_separation._train import train_forward
+    from av_separation.losses import SeparationLoss
+    dev = torch.device("cuda:0")
+    lib = _native.load()
+    x = torch.ones(1 << 16, device=dev)
+    y = torch.empty_like(x)
+    _native.check(lib.avsep_op_dropout(x.data_ptr(), y.data_ptr(), x.numel(), 0.25, 1234,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    kept = float((y > 0).float().mean())
+    assert abs(kept - 0.75) < 0.01 and abs(float(y.max()) - 1 / 0.75) < 1e-6
+
+    torch.manual_seed(3)
+    m = av.AVSeparationTransformer(freq_bins=33, d_model=64, nhead=4, num_encoder_layers=1, num_fusion_layers=1,
+                                   num_speakers=2, dropout=0.1).to(dev).train()
+    mx, lp = seeded.inputs(77, 2, 33, 12, 4, 8, 8)
+    mixed, lips = torch.from_numpy(mx).to(dev), torch.from_numpy(lp).to(dev)
+    tg = torch.rand(2, 2, 33, 12, device=dev) * mixed.unsqueeze(1)
+    crit = SeparationLoss(0.5)
+    s1, _ = train_forward(m, mixed, lips, seed=11)
+    s2, _ = train_forward(m, mixed, lips, seed=11)
+    s3, _ = train_forward(m, mixed, lips, seed=12)
+    assert torch.equal(s1, s2) and not torch.equal(s1, s3)
+    m.zero_grad()
+    crit(s1, tg).backward()
+    params = [p for p in m.parameters()]
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    dirs = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
+    analytic = sum(float((p.grad * d_).sum()) for p, d_ in zip(params, dirs))
+    eps = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sgn in (+1, -1):
+            for p, d_ in zip(params, dirs):
+                p.add_(sgn * eps * d_)
+            vals.append(float(crit(train_forward(m, mixed, lips, seed=11)[0], tg)))
+            for p, d_ in zip(params, dirs):
+                p.sub_(sgn * eps * d_)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) < 0.05 * max(1.0, abs(analytic)), (numeric, analytic)
