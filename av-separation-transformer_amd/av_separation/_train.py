@@ -290,6 +290,57 @@ class BatchNormReluFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None
 
 
+class SyncBatchNormReluFn(torch.autograd.Function):
+    """BatchNormReluFn with the statistics taken over the rows of ALL ranks of ``group`` (the
+    reference's BatchNorm sees the full batch, so a data-parallel step has to as well).  Two tiny exchanges per
+    layer: forward all-gathers (mean, biased var, row count) per rank and merges them with the parallel-variance
+    formula; backward all-reduces (sum dy, sum dy*xhat).  The kernels are the split halves of the single-GPU op."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, rmean, rvar, eps, momentum, group):
+        from .parallel import all_gather_rows, combine_bn_stats
+        x = _c(x)
+        M, Cc = x.shape
+        lib = _lib()
+        stats = torch.empty(2 * Cc + 1, device=x.device)
+        s = _scratch(M, Cc, x)
+        _ck(lib.avsep_op_bn_stats(x.data_ptr(), stats.data_ptr(), stats[Cc:].data_ptr(), s.data_ptr(), M, Cc, _st(x)),
+            "bn_stats")
+        stats[2 * Cc] = float(M)
+        allst = all_gather_rows(stats, group)                                   # [G, 2C+1]
+        mean, var, total = combine_bn_stats(allst[:, :Cc], allst[:, Cc:2 * Cc], allst[:, 2 * Cc])
+        mean, var = mean.contiguous(), var.contiguous()
+        xh, y = torch.empty_like(x), torch.empty_like(x)
+        _ck(lib.avsep_op_bn_apply(x.data_ptr(), mean.data_ptr(), var.data_ptr(), g.data_ptr(), b.data_ptr(),
+                                  xh.data_ptr(), y.data_ptr(), M, Cc, eps, 1, _st(x)), "bn_apply")
+        with torch.no_grad():
+            n = float(total)
+            rmean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            rvar.mul_(1.0 - momentum).add_(var, alpha=momentum * n / max(n - 1.0, 1.0))
+        ctx.eps, ctx.group, ctx.inv_count = eps, group, 1.0 / float(total)
+        ctx.save_for_backward(y, xh, g, var)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .parallel import all_reduce_sum_
+        y, xh, g, var = ctx.saved_tensors
+        dy = _c(dy)
+        M, Cc = y.shape
+        lib = _lib()
+        dx, dyr = torch.empty_like(y), torch.empty_like(y)
+        sums = torch.empty(2 * Cc, device=y.device)                                # [sum dy | sum dy*xhat] = [dbeta|dgamma]
+        s = _scratch(M, Cc, y)
+        _ck(lib.avsep_op_bn_bwd_sums(dy.data_ptr(), y.data_ptr(), xh.data_ptr(), dyr.data_ptr(), sums.data_ptr(),
+                                     sums[Cc:].data_ptr(), s.data_ptr(), M, Cc, 1, _st(y)), "bn_bwd_sums")
+        local = sums.clone()              # parameter gradients stay per-rank; the bucket all-reduce averages them
+        all_reduce_sum_(sums, ctx.group)
+        _ck(lib.avsep_op_bn_bwd_dx(dyr.data_ptr(), xh.data_ptr(), g.data_ptr(), var.data_ptr(), sums.data_ptr(),
+                                   sums[Cc:].data_ptr(), dx.data_ptr(), M, Cc, ctx.inv_count, ctx.eps, _st(y)),
+            "bn_bwd_dx")
+        return dx, local[Cc:].clone(), local[:Cc].clone(), None, None, None, None, None
+
+
 class DropoutFn(torch.autograd.Function):
     """Inverted dropout with the kernels' stateless mask; backward = the same op on the gradient."""
 
@@ -448,14 +499,25 @@ def _count(P, prefix):
     return n
 
 
-def train_forward(model, mixed, lips, seed=None):
+def train_forward(model, mixed, lips, seed=None, group=None):
     """Train-mode AVSeparationTransformer.forward (model.py:268-276) with autograd through the HIP ops.
     Returns (separated, masks) as (B,S,F,T) views of (B,T,S,F) tensors, like the inference path.
-    ``seed``: base seed of this forward's dropout masks (default: drawn from torch's CPU generator)."""
+    ``seed``: base seed of this forward's dropout masks (default: drawn from torch's CPU generator).
+    ``group``: process group of a data-parallel job (default: ``model._dp_group`` set by ``parallel.DataParallel``):
+    BatchNorm statistics then span all ranks and every rank draws different dropout masks."""
+    if group is None:
+        group = getattr(model, "_dp_group", None)
+    world = 1
+    if group is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
     pa, pv = model.audio_encoder.dropout_p, model.visual_encoder.dropout_p
     pf, pd = model.fusion.dropout_p, model.decoder.dropout_p
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if max(pa, pv, pf, pd) > 0 else 0
+    if world > 1:
+        import torch.distributed as dist
+        seed = int(seed) + 0x632BE59BD9B4E019 * (dist.get_rank(group) + 1)
     drop = _Drop(seed)
     P = dict(model.named_parameters())
     Bf = dict(model.named_buffers())
@@ -492,8 +554,12 @@ def train_forward(model, mixed, lips, seed=None):
         colv = Im2col2dFn.apply(x, Mv, hh, ww, Kp)
         y = LinearFn.apply(colv, cw, P[f"visual_encoder.conv.{conv_i}.bias"], ACT_NONE, None, 0)
         bn = f"visual_encoder.conv.{bn_i}."
-        x = BatchNormReluFn.apply(y, P[bn + "weight"], P[bn + "bias"], Bf[bn + "running_mean"], Bf[bn + "running_var"],
-                                  1e-5, 0.1)
+        if world > 1:
+            x = SyncBatchNormReluFn.apply(y, P[bn + "weight"], P[bn + "bias"], Bf[bn + "running_mean"],
+                                          Bf[bn + "running_var"], 1e-5, 0.1, group)
+        else:
+            x = BatchNormReluFn.apply(y, P[bn + "weight"], P[bn + "bias"], Bf[bn + "running_mean"],
+                                      Bf[bn + "running_var"], 1e-5, 0.1)
         Bf[bn + "num_batches_tracked"].add_(1)
         hh, ww, cin = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1, cout
     pooled = AvgPoolFn.apply(x, Mv, hh * ww)

@@ -33,13 +33,25 @@ class SeparationLoss(nn.Module):
         super().__init__()
         self.l1_weight = l1_weight
 
-    def forward(self, separated: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    def forward(self, separated: torch.Tensor, targets: torch.Tensor, group=None) -> torch.Tensor:
+        """``group``: data-parallel process group (equal shards).  The reference picks the permutation from the mean
+        over the WHOLE batch, so the candidates' values are averaged over ranks before comparing; the returned
+        (differentiable) loss is this rank's term of the chosen permutation -- its mean over ranks is the
+        reference's batch loss."""
         n_spk = separated.shape[1]
-        best = None
+        cands = []
         for order in permutations(range(n_spk)):
             cand = separated[:, list(order)]
-            loss = self.l1_weight * (cand - targets).abs().mean() - si_snr(cand, targets)
+            cands.append(self.l1_weight * (cand - targets).abs().mean() - si_snr(cand, targets))
+        ranking = cands
+        if group is not None:
+            import torch.distributed as dist
+            from .parallel import all_reduce_sum_
+            if dist.get_world_size(group) > 1:
+                ranking = all_reduce_sum_(torch.stack([c.detach() for c in cands]), group) / dist.get_world_size(group)
+        best = 0
+        for i in range(1, len(cands)):
             # strict "<" like the reference (losses.py:70): ties keep the earlier permutation
-            if best is None or loss < best:
-                best = loss
-        return best
+            if ranking[i] < ranking[best]:
+                best = i
+        return cands[best]

@@ -1,0 +1,195 @@
+"""Data-parallel training around the HIP training path: one process per MI355X, torch.distributed over RCCL
+(backend "nccl" on ROCm), SURVEY.md §8(e) "Training" row.  The reference has no distributed code (single
+process, demo.py:121), so this is new functionality whose contract is: G ranks x B/G clips produce the SAME
+parameter update as the reference's single process on the B-clip batch.  That needs three exchanges per step:
+
+  1. gradients     : all-reduce(sum)/G of every parameter gradient, in flat buckets launched from autograd hooks
+                     while the rest of the backward still runs (``GradBuckets``);
+  2. BatchNorm     : per-channel statistics over the rows of all ranks, forward (mean/var/count all-gather) and
+                     backward (two sums all-reduce) -- ``_train.SyncBatchNormReluFn``, 3 layers x 224 channels total;
+  3. PIT loss      : the permutation is chosen for the WHOLE batch from the batch-mean loss (losses.py:65-71), so the
+                     S! candidate losses are all-reduced before the argmin (``losses.SeparationLoss(group=...)``).
+
+``clip_grad_norm_`` (demo.py:103) needs no exchange of its own: after (1) every rank holds the same gradients.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): small all-reduces are latency-bound and a ring only ever
+drives one link per hop, so buckets are LARGE (default 64 MB; cfg 4/5 have 212/262 MB of fp32 gradients -> 4-5
+collectives per step) with a smaller first bucket so the first collective starts early in the backward.
+
+gloo (the CPU tests, and >1 rank sharing one GPU) has no device collectives here, so device tensors are staged
+through the host for that backend only.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+# ------------------------------------------------------------------------------------------- small collectives
+def _staged(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks of ``group``."""
+    if _staged(t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[n] on every rank -> [G, n] (row r = rank r's vector)."""
+    world = dist.get_world_size(group)
+    src = t.detach().cpu() if _staged(t, group) else t.detach().contiguous()
+    out = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(out, src, group=group)
+    return torch.stack(out).to(t.device)
+
+
+def combine_bn_stats(means: torch.Tensor, variances: torch.Tensor, counts: torch.Tensor):
+    """Merge per-rank (mean, biased variance, row count) into the statistics of the union of all rows:
+    mean = sum n_r mean_r / N;  var = sum n_r (var_r + (mean_r - mean)^2) / N.  means/variances [G, C], counts [G]."""
+    n = counts.reshape(-1, 1)
+    total = counts.sum()
+    mean = (means * n).sum(0) / total
+    var = ((variances + (means - mean) ** 2) * n).sum(0) / total
+    return mean, var, total
+
+
+# ------------------------------------------------------------------------------------------- gradient buckets
+class GradBuckets:
+    """Flat gradient buckets with the all-reduce overlapped with the backward pass.
+
+    Parameters are taken in REVERSE registration order (roughly the order the backward produces their gradients);
+    each parameter's ``.grad`` is a view into its bucket's flat buffer, so there is no gather/scatter copy: autograd
+    accumulates in place, the post-accumulate hook counts arrivals and the bucket's collective is launched
+    (``async_op``) the moment its last gradient lands.  ``finish()`` launches any bucket that did not fill (unused
+    parameters contribute zeros), waits, and scales by 1/G.  Use ``zero_grad()`` of this object (it keeps the views)."""
+
+    def __init__(self, params, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.params = [p for p in reversed(list(params)) if p.requires_grad]
+        self.buckets = []                      # dict(flat, params, pending, work)
+        self._where = {}                       # param -> (bucket index, byte offset in its flat buffer)
+        cap = int(first_bucket_mb * (1 << 20)) // 4
+        cur, used = [], 0
+        for p in self.params:
+            if cur and used + p.numel() > cap:
+                self._close(cur)
+                cur, used, cap = [], 0, int(bucket_mb * (1 << 20)) // 4
+            cur.append(p)
+            used += p.numel()
+        if cur:
+            self._close(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._arrived) for p in self.params]
+        self._begin()
+
+    def _close(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            self._where[p] = (len(self.buckets), off * p.element_size())
+            off += p.numel()
+        self.buckets.append(dict(flat=flat, params=plist, pending=len(plist), work=None, launched=False))
+
+    def _begin(self):
+        for b in self.buckets:
+            b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
+
+    def _launch(self, b):
+        b["launched"] = True
+        if self.world == 1:
+            return
+        if _staged(b["flat"], self.group):
+            all_reduce_sum_(b["flat"], self.group)           # host-staged (gloo + device tensor): synchronous
+        else:
+            b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
+
+    def _arrived(self, p):
+        bi, off = self._where[p]
+        b = self.buckets[bi]
+        if p.grad is None or p.grad.data_ptr() != b["flat"].data_ptr() + off:
+            raise RuntimeError("a parameter's .grad no longer aliases its bucket: use GradBuckets.zero_grad(), "
+                               "not zero_grad(set_to_none=True)")
+        b["pending"] -= 1
+        if b["pending"] == 0 and not b["launched"]:
+            self._launch(b)
+
+    def finish(self):
+        """Call after ``backward()``: every gradient is the mean over ranks when this returns."""
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
+        for b in self.buckets:
+            if b["work"] is not None:
+                b["work"].wait()
+            if self.world > 1:
+                b["flat"].mul_(1.0 / self.world)
+        self._begin()
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b["flat"].zero_()
+        self._begin()
+
+    @property
+    def bucket_sizes(self):
+        return [b["flat"].numel() * 4 for b in self.buckets]
+
+
+# ------------------------------------------------------------------------------------------- module wrapper
+class DataParallel(nn.Module):
+    """``DataParallel(AVSeparationTransformer(...).to(dev))``: broadcasts rank 0's parameters and buffers, makes the
+    BatchNorm statistics span all ranks, and owns the gradient buckets.  A training step reads like the reference's
+    (demo.py:96-106) plus one line::
+
+        dp.zero_grad(); sep, _ = dp(mixed_shard, lips_shard)
+        loss = criterion(sep, targets_shard, group=dp.group); loss.backward()
+        dp.reduce_gradients()                      # <- the exchange step
+        torch.nn.utils.clip_grad_norm_(dp.parameters(), 1.0); optimizer.step()
+    """
+
+    def __init__(self, module: nn.Module, group=None, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0,
+                 sync_bn: bool = True):
+        super().__init__()
+        self.module = module
+        group = group if group is not None else dist.group.WORLD
+        self.group = group
+        self.world = dist.get_world_size(group)
+        src = dist.get_global_rank(group, 0)
+        with torch.no_grad():
+            for t in list(module.parameters()) + [b for b in module.buffers() if b.dtype.is_floating_point]:
+                if _staged(t, group):
+                    h = t.detach().cpu()
+                    dist.broadcast(h, src, group=group)
+                    t.copy_(h)
+                else:
+                    dist.broadcast(t.data, src, group=group)
+        object.__setattr__(module, "_dp_group", group if (sync_bn and self.world > 1) else None)
+        self.buckets = GradBuckets(module.parameters(), bucket_mb, first_bucket_mb, group)
+
+    def forward(self, mixed_spec, lip_frames):
+        return self.module(mixed_spec, lip_frames)
+
+    def reduce_gradients(self):
+        self.buckets.finish()
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.buckets.zero_grad()
+
+
+def shard_range(rank: int, world: int, batch: int) -> range:
+    """Clips [rank*B/G, (rank+1)*B/G) of a global batch; the batch must divide evenly so that the
+    mean of per-rank mean losses equals the reference's batch mean."""
+    if batch % world:
+        raise ValueError(f"global batch {batch} does not divide over {world} ranks")
+    per = batch // world
+    return range(rank * per, (rank + 1) * per)

@@ -141,6 +141,39 @@ int avsep_op_bn_train_bwd(const float* dy, const float* y, const float* xhat, co
   return AVSEP_OK;
 }
 
+// ---- split BatchNorm (cross-rank statistics: the host all-reduces the C-length vectors between the two halves)
+int avsep_op_bn_stats(const float* x, float* mean, float* var, float* scratch, int M, int C, void* stream) {
+  if (!x || !mean || !var || !scratch || M <= 0 || C <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  hipStream_t s = S(stream);
+  TCK(launch_colreduce(x, nullptr, scratch, mean, nullptr, M, C, 1.0f / (float)M, s));
+  TCK(launch_bn_var(x, mean, scratch, var, M, C, s));
+  return AVSEP_OK;
+}
+int avsep_op_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                      float* xhat, float* y, int M, int C, float eps, int relu, void* stream) {
+  if (!x || !mean || !var || !gamma || !beta || !xhat || !y || M <= 0 || C <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_bn_apply(x, mean, var, gamma, beta, xhat, y, (size_t)M * C, C, relu, eps, S(stream)));
+  return AVSEP_OK;
+}
+int avsep_op_bn_bwd_sums(const float* dy, const float* y, const float* xhat, float* dyr, float* sum_dy, float* sum_dyx,
+                         float* scratch, int M, int C, int relu, void* stream) {
+  if (!dy || !y || !xhat || !dyr || !sum_dy || !sum_dyx || !scratch || M <= 0 || C <= 0)
+    return fail(AVSEP_EINVAL, "bad argument");
+  hipStream_t s = S(stream);
+  const size_t n = (size_t)M * C;
+  if (relu) TCK(launch_act_bwd(dy, y, dyr, n, ACT_RELU, s));
+  else TCK(hipMemcpyAsync(dyr, dy, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  TCK(launch_colreduce(dyr, xhat, scratch, sum_dy, sum_dyx, M, C, 1.0f, s));
+  return AVSEP_OK;
+}
+int avsep_op_bn_bwd_dx(const float* dyr, const float* xhat, const float* gamma, const float* var, const float* sum_dy,
+                       const float* sum_dyx, float* dx, int M, int C, float inv_count, float eps, void* stream) {
+  if (!dyr || !xhat || !gamma || !var || !sum_dy || !sum_dyx || !dx || M <= 0 || C <= 0 || !(inv_count > 0.f))
+    return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_bn_bwd(dyr, xhat, gamma, var, sum_dy, sum_dyx, dx, (size_t)M * C, C, inv_count, eps, S(stream)));
+  return AVSEP_OK;
+}
+
 int avsep_op_act_fwd(const float* x, float* y, int64_t n, int act, void* stream) {
   if (!x || !y || n <= 0 || act < 1 || act > 3) return fail(AVSEP_EINVAL, "bad argument");
   TCK(launch_act_fwd(x, y, (size_t)n, act, S(stream)));

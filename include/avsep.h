@@ -172,6 +172,18 @@ int avsep_op_bn_train_fwd(const float* x, const float* gamma, const float* beta,
 int avsep_op_bn_train_bwd(const float* dy, const float* y, const float* xhat, const float* gamma, const float* var,
                           float* dx, float* dgamma, float* dbeta, float* dyr_scratch, float* scratch, int M, int C,
                           float eps, int relu, void* stream);
+
+/* Split BatchNorm for data-parallel training ("BN statistics all-reduce ... to keep parity with the
+ * reference's full-batch BatchNorm", model.py:83-89 in train mode).  The host combines the C-length vectors across
+ * ranks between the halves: stats -> [all-gather mean/var/count, combine] -> apply;  bwd_sums -> [all-reduce] -> bwd_dx
+ * with inv_count = 1 / (global row count).  var is the biased variance of this rank's M rows. */
+int avsep_op_bn_stats(const float* x, float* mean, float* var, float* scratch, int M, int C, void* stream);
+int avsep_op_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                      float* xhat, float* y, int M, int C, float eps, int relu, void* stream);
+int avsep_op_bn_bwd_sums(const float* dy, const float* y, const float* xhat, float* dyr, float* sum_dy, float* sum_dyx,
+                         float* scratch, int M, int C, int relu, void* stream);
+int avsep_op_bn_bwd_dx(const float* dyr, const float* xhat, const float* gamma, const float* var, const float* sum_dy,
+                       const float* sum_dyx, float* dx, int M, int C, float inv_count, float eps, void* stream);
 /* activations (1 relu, 2 gelu-erf, 3 sigmoid); backward aux = output (relu, sigmoid) or pre-activation (gelu) */
 int avsep_op_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
 int avsep_op_act_bwd(const float* dy, const float* aux, float* dx, int64_t n, int act, void* stream);

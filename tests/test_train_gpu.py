@@ -149,3 +149,64 @@ def test_dropout_training_is_self_consistent():
                 p.sub_(sgn * eps * d_)
     numeric = (vals[0] - vals[1]) / (2 * eps)
     assert abs(numeric - analytic) < 0.05 * max(1.0, abs(analytic)), (numeric, analytic)
+
+
+def _dp_worker(rank, world, port, name, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # 2 ranks share the one GPU of the test box
+    from conftest import load_golden
+    from av_separation import parallel
+    from av_separation.losses import SeparationLoss
+    g = load_golden(name)
+    c = g["config"]
+    dev = torch.device("cuda:0")
+    m = _build(g, dev)
+    if rank == 1:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(0.5)                                             # must be overwritten by rank 0's broadcast
+    dp = parallel.DataParallel(m, bucket_mb=0.25, first_bucket_mb=0.05)
+    mx, lp = seeded.inputs(c["seed"], c["B"], c["F"], c["T"], c["N"], c["H"], c["W"])
+    idx = list(parallel.shard_range(rank, world, c["B"]))
+    dp.zero_grad()
+    sep, masks = dp(torch.from_numpy(mx[idx]).to(dev), torch.from_numpy(lp[idx]).to(dev))
+    loss = SeparationLoss(0.5)(sep, torch.from_numpy(g["targets"][idx]).to(dev), group=dp.group)
+    loss.backward()
+    dp.reduce_gradients()
+    tot = loss.detach().cpu().clone()
+    dist.all_reduce(tot)
+    torch.save({"grads": {k: p.grad.cpu() for k, p in m.named_parameters()}, "loss": float(tot) / world,
+                "masks": masks.detach().cpu(), "buckets": dp.buckets.bucket_sizes,
+                "bufs": {k: v.cpu() for k, v in m.state_dict().items() if "running_" in k}}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_matches_reference_full_batch(golden, tmp_path):
+    """SURVEY.md §8(e) training row on the HIP path: 2 ranks x 1 clip (gradient buckets, cross-rank BatchNorm
+    statistics, batch-global PIT) give the reference's single-process gradients for the 2-clip batch."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "dp")
+    mp.spawn(_dp_worker, args=(2, port, "train_tiny", out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    g = golden("train_tiny")
+    assert len(r0["buckets"]) >= 2
+    assert abs(r0["loss"] - float(g["loss"])) < 2e-5
+    assert maxabs(torch.cat([r0["masks"], r1["masks"]]).numpy(), g["masks"]) < 1e-5
+    worst = 0.0
+    for k, got in r0["grads"].items():
+        assert torch.equal(got, r1["grads"][k]), k
+        ref = g["g." + k]
+        worst = max(worst, maxabs(got.numpy(), ref) / max(1e-3, float(np.abs(ref).max())))
+    assert worst < 2e-3, worst
+    for k, v in r0["bufs"].items():
+        assert maxabs(v.numpy(), g["buf." + k]) < 1e-5, k
+        assert torch.equal(v, r1["bufs"][k])
+    print(f"2-rank DP: worst relative gradient error {worst:.2e}")
