@@ -89,6 +89,19 @@ def _colsum(a, b=None):
 
 
 # ----------------------------------------------------------------------------------------------- autograd ops
+def _wgrad(dyt, xt):
+    """dW [N, K] from the transposed operands dY^T [N, R], X^T [K, R] (split over the rows R when N*K is small)."""
+    N, R = dyt.shape
+    K = xt.shape[0]
+    lib = _lib()
+    dw = torch.empty(N, K, device=dyt.device)
+    ns = lib.avsep_op_wgrad_scratch_floats(N, K, R)
+    scratch = torch.empty(ns, device=dyt.device) if ns else None
+    _ck(lib.avsep_op_wgrad(dyt.data_ptr(), xt.data_ptr(), dw.data_ptr(), scratch.data_ptr() if ns else None, N, K, R,
+                           _st(dyt)), "wgrad")
+    return dw
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x w^T + b) + res;  act in {none, relu}; res: same-shape residual (grad flows) or constant rows with
     period `rperiod` (positional encoding, no grad)."""
@@ -122,8 +135,8 @@ class LinearFn(torch.autograd.Function):
             wt = _transpose(w, Np)                                         # [K, Np] = w^T
             dx = _gemm(dpp, wt, None, None, 0, ACT_NONE)                   # dY W
         if ctx.needs_input_grad[1]:
-            Mp = _up32(M)
-            dw = _gemm(_transpose(dpre, Mp), _transpose(x, Mp), None, None, 0, ACT_NONE)   # dY^T X  [N, K]
+            Mp = (M + 63) // 64 * 64                                                      # zero rows: layout only
+            dw = _wgrad(_transpose(dpre, Mp), _transpose(x, Mp))                          # dY^T X  [N, K]
         if ctx.has_b and ctx.needs_input_grad[2]:
             db, _ = _colsum(dpre)
         dres = dy if (ctx.res_grad and ctx.needs_input_grad[4]) else None

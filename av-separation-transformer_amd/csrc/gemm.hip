@@ -113,7 +113,15 @@ __device__ __forceinline__ int swz(int row) {
 }
 
 template <int BM, int BN, int BK, int AMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
+  GemmParams p = pin;
+  if (p.ksplit > 1) {                      // block-uniform: slice blockIdx.y of the contraction
+    const int z = blockIdx.y;
+    p.A += (size_t)z * p.kchunk;
+    p.W += (size_t)z * p.kchunk;
+    p.C += (size_t)z * p.cstride;
+    p.K = min(p.kchunk, p.K - z * p.kchunk);
+  }
   constexpr int SLOTS = BK / 4;            // 16-byte slots per LDS row
   constexpr int RPP = 256 / SLOTS;         // rows staged per pass (256 threads x float4)
   constexpr int APASS = BM / RPP;
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
 template <int BM, int BN, int BK, int AMODE>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE>), dim3(nbm * nbn), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE>), dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -443,7 +451,8 @@ Tile pick_tile(const GemmParams& p) {
   }
   // largest of {64x64, 64x32} that still gives >= 2 workgroups per CU, else 32x32; 128x64 only when even it
   // yields >= 8 per CU (cuts L2 traffic on the very large problems; never faster than 64x64 below that)
-  auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const long slices = p.ksplit > 1 ? p.ksplit : 1;
+  auto blocks = [&](int bm, int bn) { return slices * ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   Tile pick{32, 32, 32};
   if (blocks(128, 64) >= 2048) pick = Tile{128, 64, 32};
   else if (blocks(64, 64) >= 512) pick = Tile{64, 64, 32};
@@ -538,6 +547,10 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   p.no_xcd_remap = no_remap ? 1 : 0;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 31)) return hipErrorInvalidValue;
   if (p.amode != AMODE_PLAIN && (p.Kt <= 0 || (p.Kt & 31))) return hipErrorInvalidValue;
+  if (p.ksplit > 1) {
+    if (p.amode != AMODE_PLAIN || p.bias || p.R || p.C2 || p.ln_gamma || p.act != ACT_NONE) return hipErrorInvalidValue;
+    if (p.kchunk <= 0 || (p.kchunk & 63) || (long long)(p.ksplit - 1) * p.kchunk >= p.K) return hipErrorInvalidValue;
+  }
   if (p.ln_gamma) {
     if (!ln_fusable(p)) return hipErrorInvalidValue;   // callers check gemm_ln_supported() first
     return launch_gemm_ln(p, s);

@@ -46,6 +46,11 @@ struct GemmParams {
   const float* ln_gamma;
   const float* ln_beta;
   float ln_eps;
+  // Split-K (weight gradients: K = rows >> M, N): gridDim.y = ksplit slices of kchunk columns each (kchunk % 64 == 0),
+  // slice z reads A/W columns [z*kchunk, ...) and writes its partial product to C + z*cstride; the caller sums the
+  // slices with a column reduction (deterministic, no atomics).  PLAIN mode, no bias/act/residual.  0/1 = off.
+  int ksplit, kchunk;
+  long long cstride;
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
@@ -73,6 +78,7 @@ hipError_t launch_col2im2d(const float* dcol, float* dx, int I, int H, int W, in
 hipError_t launch_colreduce(const float* a, const float* b, float* part, float* out0, float* out1, int M, int C,
                             float scale, hipStream_t s);
 int colreduce_part_floats(int M, int C);
+hipError_t launch_sum_slices(const float* part, float* out, int S, size_t n, hipStream_t s);
 hipError_t launch_bn_var(const float* x, const float* mean, float* part, float* out, int M, int C, hipStream_t s);
 hipError_t launch_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                            float* xhat, float* y, size_t n, int C, int relu, float eps, hipStream_t s);

@@ -4,6 +4,8 @@
 #include "../../include/avsep.h"
 #include "kernels.h"
 
+#include <algorithm>
+
 #include <string>
 
 extern "C" void avsep_set_error_(const char* msg);   // avsep_api.hip (thread-local message for avsep_last_error)
@@ -40,6 +42,53 @@ int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const f
   p.act = act;
   p.R = residual; p.ldr = ldr; p.rperiod = rperiod;
   TCK(launch_gemm(p, S(stream)));
+  return AVSEP_OK;
+}
+
+// ---- weight gradient dW[N][K] = dYt[N][R] . Xt[K][R]^T with the (long) row index R as the contraction.  Few output
+// tiles and R in the thousands to hundreds of thousands (conv layers: N*K = 32x32, R = 307200) would leave the chip
+// idle, so the contraction is cut into slices (gridDim.y) whose partial products are summed in a fixed order.
+namespace {
+struct WgradPlan { int ksplit, kchunk; };
+WgradPlan wgrad_plan(int N, int K, int R) {
+  const long tiles = (long)((N + 31) / 32) * ((K + 31) / 32);
+  WgradPlan pl{1, R};
+  if (tiles >= 512 || R < 1024 || (R & 63)) return pl;
+  long want = (1024 + tiles - 1) / tiles;
+  want = std::min<long>(want, R / 256);
+  if (want < 2) return pl;
+  pl.kchunk = (int)(((R + want - 1) / want + 63) / 64 * 64);
+  pl.ksplit = (R + pl.kchunk - 1) / pl.kchunk;
+  if (pl.ksplit < 2) pl = WgradPlan{1, R};
+  return pl;
+}
+}  // namespace
+
+int64_t avsep_op_wgrad_scratch_floats(int N, int K, int R) {
+  const WgradPlan pl = wgrad_plan(N, K, R);
+  return pl.ksplit > 1 ? (int64_t)pl.ksplit * N * K : 0;
+}
+
+int avsep_op_wgrad(const float* dyt, const float* xt, float* dw, float* scratch, int N, int K, int R, void* stream) {
+  if (!dyt || !xt || !dw || N <= 0 || K <= 0 || R <= 0 || (R & 31)) return fail(AVSEP_EINVAL, "bad argument");
+  const WgradPlan pl = wgrad_plan(N, K, R);
+  GemmParams p{};
+  p.A = dyt; p.W = xt;
+  p.M = N; p.N = K; p.K = R;
+  p.lda = R; p.ldw = R; p.ldc = K;
+  p.amode = AMODE_PLAIN;
+  p.act = ACT_NONE;
+  if (pl.ksplit > 1) {
+    if (!scratch) return fail(AVSEP_EINVAL, "wgrad needs avsep_op_wgrad_scratch_floats() floats of scratch");
+    if (((size_t)N * K) & 3) return fail(AVSEP_EINVAL, "N*K must be a multiple of 4");
+    p.C = scratch;
+    p.ksplit = pl.ksplit; p.kchunk = pl.kchunk; p.cstride = (long long)N * K;
+    TCK(launch_gemm(p, S(stream)));
+    TCK(launch_sum_slices(scratch, dw, pl.ksplit, (size_t)N * K, S(stream)));
+  } else {
+    p.C = dw;
+    TCK(launch_gemm(p, S(stream)));
+  }
   return AVSEP_OK;
 }
 

@@ -9,9 +9,9 @@
 // column reductions done in two deterministic stages (no float atomics: bit-reproducible gradients).
 #include "kernels.h"
 
-namespace {
+#include <algorithm>
 
-constexpr int RED_ROWS = 256;   // rows per first-stage block of the column reductions
+namespace {
 
 // ------------------------------------------------------------------------------------------ transposes / im2col
 // y[c][r] = x[r][c] for r < R, zero for R <= r < Rp  (x: [R][C], y: [C][Rp]); used for dW = dY^T X operands.
@@ -119,56 +119,111 @@ __global__ __launch_bounds__(256) void col2im2d_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------ column reductions
-// stage 1: part[blk][j][c] = sum over this block's rows of f_j(row, c); stage 2 sums the blocks in order.
-// MODE 0: f0 = a                      (bias gradient, BN mean with a = x)
-// MODE 1: f0 = a, f1 = a*b            (BN/LN affine gradients: a = dy, b = xhat; BN variance: a = x-mean...)
-template <int MODE>
-__global__ __launch_bounds__(256) void colreduce1_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         float* __restrict__ part, int M, int C) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= C) return;
-  const int r0 = blockIdx.x * RED_ROWS;
-  const int r1 = min(r0 + RED_ROWS, M);
-  float s0 = 0.f, s1 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const float av = a[(size_t)r * C + c];
-    s0 += av;
-    if (MODE == 1) s1 = fmaf(av, b[(size_t)r * C + c], s1);
-  }
-  const int nj = MODE == 1 ? 2 : 1;
-  part[((size_t)blockIdx.x * nj + 0) * C + c] = s0;
-  if (MODE == 1) part[((size_t)blockIdx.x * nj + 1) * C + c] = s1;
+// Deterministic two-stage column sums of a row-major [M][C] matrix.  A 256-thread block covers CW columns (power of
+// two, 32..256) x RL = 256/CW row lanes, so narrow matrices (C = 32 conv channels x 300k rows) still fill their
+// wavefronts; the row lanes are folded through LDS in a fixed order.
+//   stage 1: part[blk][j][c] = sum over the block's rows of f_j(row, c)     grid (nb, ceil(C/CW))
+//   stage 2: out_j[c] = scale * sum_blk part[blk][j][c]                       same kernel shape, 32 columns x 8 lanes
+// MODE 0: f0 = a                      (bias gradients, BN mean)
+// MODE 1: f0 = a, f1 = a*b            (BN/LN affine gradients: a = dy, b = xhat)
+// MODE 2: f0 = (a - b[c])^2           (BN variance, b = mean)
+struct RedPlan { int cwl, rows, nb; };
+inline RedPlan red_plan(int M, int C) {
+  RedPlan r;
+  r.cwl = 5;
+  while (r.cwl < 8 && (1 << r.cwl) < C) ++r.cwl;
+  const int cw = 1 << r.cwl, rl = 256 / cw;
+  const int nby = (C + cw - 1) / cw;
+  int nb = (1024 + nby - 1) / nby;                       // ~1024 workgroups in stage 1
+  const int maxnb = (M + 4 * rl - 1) / (4 * rl);         // at least 4 rows per lane
+  nb = std::max(1, std::min(std::min(nb, maxnb), 512));
+  r.rows = (M + nb - 1) / nb;
+  r.rows = (r.rows + rl - 1) / rl * rl;
+  r.nb = (M + r.rows - 1) / r.rows;
+  return r;
 }
 
-__global__ void colreduce2_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
-                                  int nblk, int nj, int C, float scale) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce1_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ part, int M, int C, int rows, int cwl) {
+  __shared__ float red[2][256];
+  const int cw = 1 << cwl, rl = 256 >> cwl;
+  const int cl = threadIdx.x & (cw - 1), lane = threadIdx.x >> cwl;
+  const int c = blockIdx.y * cw + cl;
+  const int r0 = blockIdx.x * rows, r1 = min(r0 + rows, M);
   float s0 = 0.f, s1 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    s0 += part[((size_t)b * nj + 0) * C + c];
-    if (nj == 2) s1 += part[((size_t)b * nj + 1) * C + c];
+  if (c < C) {
+    const float mu = MODE == 2 ? b[c] : 0.f;
+    int r = r0 + lane;
+    // 4 independent loads in flight per lane
+    for (; r + 3 * rl < r1; r += 4 * rl) {
+      float v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = a[(size_t)(r + u * rl) * C + c];
+        if (MODE == 1) w[u] = b[(size_t)(r + u * rl) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (MODE == 2) { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
+        else s0 += v[u];
+        if (MODE == 1) s1 = fmaf(v[u], w[u], s1);
+      }
+    }
+    for (; r < r1; r += rl) {
+      const float v = a[(size_t)r * C + c];
+      if (MODE == 2) { const float d = v - mu; s0 = fmaf(d, d, s0); }
+      else s0 += v;
+      if (MODE == 1) s1 = fmaf(v, b[(size_t)r * C + c], s1);
+    }
   }
-  out0[c] = s0 * scale;
-  if (nj == 2) out1[c] = s1 * scale;
+  red[0][threadIdx.x] = s0;
+  if (MODE == 1) red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    for (int l = 1; l < rl; ++l) {
+      s0 += red[0][l * cw + cl];
+      if (MODE == 1) s1 += red[1][l * cw + cl];
+    }
+    const int nj = MODE == 1 ? 2 : 1;
+    part[((size_t)blockIdx.x * nj + 0) * C + c] = s0;
+    if (MODE == 1) part[((size_t)blockIdx.x * nj + 1) * C + c] = s1;
+  }
+}
+
+// stage 2 over the nblk partial rows of width W = nj*C: 32 columns x 8 row lanes per block
+__global__ __launch_bounds__(256) void colreduce2_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                         float* __restrict__ out1, int nblk, int nj, int C, float scale) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, Wd = nj * C;
+  float s = 0.f;
+  if (c < Wd)
+    for (int r = lane; r < nblk; r += 8) s += part[(size_t)r * Wd + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (lane == 0 && c < Wd) {
+    for (int l = 1; l < 8; ++l) s += red[l * 32 + cl];
+    if (c < C) out0[c] = s * scale;
+    else out1[c - C] = s * scale;
+  }
+}
+
+// out[i] = sum_z part[z][i]  (split-K weight gradients; slices summed in a fixed order)
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, float* __restrict__ out, int S,
+                                                         size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4* p4 = reinterpret_cast<const float4*>(part);
+  float4 acc = p4[i];
+  for (int z = 1; z < S; ++z) {
+    const float4 v = p4[(size_t)z * n4 + i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = acc;
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm (train)
-// variance pass: part sums of (x - mean)^2 use colreduce with a = b = x - mean materialised on the fly
-__global__ __launch_bounds__(256) void bn_var1_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                                      float* __restrict__ part, int M, int C) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= C) return;
-  const int r0 = blockIdx.x * RED_ROWS, r1 = min(r0 + RED_ROWS, M);
-  const float mu = mean[c];
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const float d = x[(size_t)r * C + c] - mu;
-    s = fmaf(d, d, s);
-  }
-  part[(size_t)blockIdx.x * C + c] = s;
-}
-
 // y = relu?( (x - mean) * rstd * gamma + beta ),  xhat saved for the backward
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ gamma,
@@ -394,25 +449,34 @@ hipError_t launch_col2im2d(const float* dcol, float* dx, int I, int H, int W, in
   hipLaunchKernelGGL(col2im2d_kernel, dim3(nblk((size_t)I * H * W * C)), dim3(256), 0, s, dcol, dx, I, H, W, C, Ho, Wo, Kp);
   return hipGetLastError();
 }
-// out0[c] = sum_r a[r][c];  if b: out1[c] = sum_r a[r][c]*b[r][c].  `part` needs ceil(M/256)*(b?2:1)*C floats.
+// out0[c] = sum_r a[r][c];  if b: out1[c] = sum_r a[r][c]*b[r][c].  `part` needs colreduce_part_floats(M, C) floats.
 hipError_t launch_colreduce(const float* a, const float* b, float* part, float* out0, float* out1, int M, int C,
                             float scale, hipStream_t s) {
-  const int nb = (M + RED_ROWS - 1) / RED_ROWS;
-  const dim3 grid(nb, (C + 255) / 256);
-  if (b) hipLaunchKernelGGL((colreduce1_kernel<1>), grid, dim3(256), 0, s, a, b, part, M, C);
-  else hipLaunchKernelGGL((colreduce1_kernel<0>), grid, dim3(256), 0, s, a, b, part, M, C);
-  hipLaunchKernelGGL(colreduce2_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, out0, out1, nb, b ? 2 : 1, C, scale);
+  const RedPlan pl = red_plan(M, C);
+  const int cw = 1 << pl.cwl;
+  const dim3 grid(pl.nb, (C + cw - 1) / cw);
+  if (b) hipLaunchKernelGGL((colreduce1_kernel<1>), grid, dim3(256), 0, s, a, b, part, M, C, pl.rows, pl.cwl);
+  else hipLaunchKernelGGL((colreduce1_kernel<0>), grid, dim3(256), 0, s, a, b, part, M, C, pl.rows, pl.cwl);
+  const int nj = b ? 2 : 1;
+  hipLaunchKernelGGL(colreduce2_kernel, dim3((nj * C + 31) / 32), dim3(256), 0, s, part, out0, out1, pl.nb, nj, C, scale);
   return hipGetLastError();
 }
 // biased variance: out[c] = sum_r (x - mean)^2 / M
 hipError_t launch_bn_var(const float* x, const float* mean, float* part, float* out, int M, int C, hipStream_t s) {
-  const int nb = (M + RED_ROWS - 1) / RED_ROWS;
-  hipLaunchKernelGGL(bn_var1_kernel, dim3(nb, (C + 255) / 256), dim3(256), 0, s, x, mean, part, M, C);
-  hipLaunchKernelGGL(colreduce2_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, out, (float*)nullptr, nb, 1, C,
+  const RedPlan pl = red_plan(M, C);
+  const int cw = 1 << pl.cwl;
+  hipLaunchKernelGGL((colreduce1_kernel<2>), dim3(pl.nb, (C + cw - 1) / cw), dim3(256), 0, s, x, mean, part, M, C,
+                     pl.rows, pl.cwl);
+  hipLaunchKernelGGL(colreduce2_kernel, dim3((C + 31) / 32), dim3(256), 0, s, part, out, (float*)nullptr, pl.nb, 1, C,
                      1.0f / (float)M);
   return hipGetLastError();
 }
-int colreduce_part_floats(int M, int C) { return ((M + RED_ROWS - 1) / RED_ROWS) * 2 * C; }
+int colreduce_part_floats(int M, int C) { return red_plan(M, C).nb * 2 * C; }
+hipError_t launch_sum_slices(const float* part, float* out, int S, size_t n, hipStream_t s) {
+  if (n & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3(nblk(n / 4)), dim3(256), 0, s, part, out, S, n / 4);
+  return hipGetLastError();
+}
 hipError_t launch_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                            float* xhat, float* y, size_t n, int C, int relu, float eps, hipStream_t s) {
   hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(n)), dim3(256), 0, s, x, mean, var, gamma, beta, xhat, y, n, C, relu, eps);

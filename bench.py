@@ -49,6 +49,11 @@ WORKLOADS = {
                             num_speakers=2),
                  data=dict(sample_rate=16000, duration=4.0, num_frames=25, frame_h=48, frame_w=48,
                            speaker_freqs=(220.0, 440.0)), batch=32),
+    # training workloads (--mode train; SURVEY.md §8(f) N1 / BASELINE configs[3]: 3 speakers, d=512, 16 clips per GPU)
+    "cfg4": dict(model=dict(freq_bins=257, d_model=512, nhead=8, num_encoder_layers=6, num_fusion_layers=4,
+                            num_speakers=3),
+                 data=dict(sample_rate=16000, duration=2.0, num_frames=25, frame_h=32, frame_w=32,
+                           speaker_freqs=(220.0, 440.0, 660.0)), batch=16),
 }
 
 
@@ -81,7 +86,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event leg (roofline = path only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--mode", default="forward", choices=("forward", "train"),
+                    help="forward = the headline metric; train = one DP training step per 'step' (row N1, not the headline)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="train mode only (reference default 0.1)")
     a = ap.parse_args()
+    if a.mode == "train" and a.workload == "cfg2" and "--workload" not in " ".join(sys.argv):
+        a.workload = "cfg4"
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -99,6 +109,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import av_separation as av
+    if a.mode == "train":
+        return train_main(a, av, dev, dist, rank, world)
     wl = WORKLOADS[a.workload]
     B = a.batch or wl["batch"]
     mk, dk = wl["model"], wl["data"]
@@ -206,6 +218,90 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(model, mixed, lips, masks, mk, B, a.cpu_seconds)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def train_main(a, av, dev, dist, rank, world):
+    """--mode train: a step = zero_grad, train-mode forward (dropout, BatchNorm batch statistics), PIT loss, backward,
+    gradient all-reduce (N>1), clip_grad_norm_(1.0), Adam -- the reference's quick_train loop body (demo.py:96-106)
+    on one resident batch per rank.  Not the headline metric; reported for the N1 row."""
+    from av_separation import parallel
+    from av_separation.losses import SeparationLoss
+    wl = WORKLOADS[a.workload]
+    B = a.batch or wl["batch"]
+    mk, dk = wl["model"], wl["data"]
+    torch.manual_seed(0)
+    model = av.AVSeparationTransformer(dropout=a.dropout, **mk).to(dev).train()
+    ds = av.SyntheticAVDataset(num_samples=world * B, **dk)
+    items = [ds[i] for i in shard_range(rank, world, B)]
+    mixed = torch.stack([it["mixed_spec"] for it in items]).to(dev).contiguous()
+    lips = torch.stack([it["lip_frames"] for it in items]).to(dev).contiguous()
+    targets = torch.stack([it["clean_specs"] for it in items]).to(dev).contiguous()
+    _, F, T = mixed.shape
+    _, N, H, W = lips.shape
+    S = mk["num_speakers"]
+    crit = SeparationLoss(0.5)
+    dp = parallel.DataParallel(model) if dist is not None else None
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4, fused=True)
+    losses = []
+
+    def step():
+        if dp is not None:
+            dp.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=False)
+        sep, _ = model(mixed, lips)
+        loss = crit(sep, targets, group=dp.group if dp is not None else None)
+        loss.backward()
+        if dp is not None:
+            dp.reduce_gradients()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0, foreach=True)
+        opt.step()
+        losses.append(loss.detach())
+
+    for _ in range(max(1, a.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gflop_clip = 3 * flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
+    value = world * B * a.steps / elapsed
+    tf = value / world * gflop_clip / 1e3
+    nparam = sum(p.numel() for p in model.parameters())
+    out = {
+        "metric": "training clips/sec (forward+backward+Adam step), fp32", "value": round(value, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.workload} training: SyntheticAVDataset {S}-speaker, F={F}, T={T}, N={N}, {H}x{W} lips, "
+                               f"d_model={mk['d_model']}, nhead={mk['nhead']}, {mk['num_encoder_layers']}+"
+                               f"{mk['num_fusion_layers']} layers, dropout {a.dropout}, SeparationLoss(0.5), "
+                               f"clip 1.0, Adam lr 3e-4",
+                   "batch_per_gpu": B, "global_batch": world * B, "gflop_per_clip": round(gflop_clip, 3),
+                   "parameters": nparam, "launch": "eager, one launch per op",
+                   "parallelism": f"dp{world} (bucketed gradient all-reduce + cross-rank BatchNorm statistics)"
+                   if world > 1 else "single rank"},
+        "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward FLOPs)", "achieved": round(tf, 3),
+                     "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
+                     "traffic": None},
+        "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+    }
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

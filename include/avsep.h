@@ -141,6 +141,14 @@ int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const f
 /* attention forward that also returns the per-query log-sum-exp (B*nhead*Lq) and scales q by qscale on load;
  * drop_p > 0: dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training), stateless
  * mask from (drop_seed, element index) that the backward regenerates */
+/* Weight gradient of a linear/conv layer: dw[N][K] = dyt[N][R] . xt[K][R]^T, the row index R (a multiple of 32,
+ * zero padded) being the contraction -- both operands are the transposes avsep_op_transpose produces.  When N*K is
+ * small and R long (conv layers) the contraction is split over workgroups and summed in a fixed order; `scratch`
+ * must then hold avsep_op_wgrad_scratch_floats(N, K, R) floats (0 = not needed).  Replaces the autograd of
+ * nn.Linear / nn.Conv1d / nn.Conv2d weights (model.py:38-40, 82-93, ...). */
+int64_t avsep_op_wgrad_scratch_floats(int N, int K, int R);
+int avsep_op_wgrad(const float* dyt, const float* xt, float* dw, float* scratch, int N, int K, int R, void* stream);
+
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                              int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,
                              uint64_t drop_seed, void* stream);
