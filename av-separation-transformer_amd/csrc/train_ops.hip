@@ -198,8 +198,16 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(const float* __restrict
   const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, Wd = nj * C;
   float s = 0.f;
-  if (c < Wd)
-    for (int r = lane; r < nblk; r += 8) s += part[(size_t)r * Wd + c];
+  if (c < Wd) {
+    // the partial rows were just written by other XCDs: issue 16 loads together instead of paying their latency serially
+    for (int base = lane; base < nblk; base += 128) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (base + 8 * u < nblk) ? part[(size_t)(base + 8 * u) * Wd + c] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (lane == 0 && c < Wd) {
