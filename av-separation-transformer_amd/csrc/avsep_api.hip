@@ -364,7 +364,8 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
   p.amode = AMODE_PLAIN;
   p.act = act;
   const long big_tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  if (gemm_ln_supported(d) && big_tiles < 1024) {
+  static const bool no_fuse = getenv("AVSEP_NO_LN_FUSE") != nullptr;   // developer A/B switch
+  if (!no_fuse && gemm_ln_supported(d) && big_tiles < 1024) {
     p.ln_gamma = g; p.ln_beta = be; p.ln_eps = 1e-5f;
     return run_gemm(c, p, s);
   }

@@ -453,10 +453,12 @@ Tile pick_tile(const GemmParams& p) {
   // yields >= 8 per CU (cuts L2 traffic on the very large problems; never faster than 64x64 below that)
   const long slices = p.ksplit > 1 ? p.ksplit : 1;
   auto blocks = [&](int bm, int bn) { return slices * ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  static const long t64 = getenv("AVSEP_T64") ? atol(getenv("AVSEP_T64")) : 512;       // developer sweeps
+  static const long t6432 = getenv("AVSEP_T6432") ? atol(getenv("AVSEP_T6432")) : 512;
   Tile pick{32, 32, 32};
   if (blocks(128, 64) >= 2048) pick = Tile{128, 64, 32};
-  else if (blocks(64, 64) >= 512) pick = Tile{64, 64, 32};
-  else if (blocks(64, 32) >= 512) pick = Tile{64, 32, 32};
+  else if (blocks(64, 64) >= t64) pick = Tile{64, 64, 32};
+  else if (blocks(64, 32) >= t6432) pick = Tile{64, 32, 32};
   const int kunit = p.amode == AMODE_PLAIN ? p.K : p.Kt;   // a chunk must not straddle a tap
   if (pick.bm + pick.bn <= 96 && kunit % 64 == 0) pick.bk = 64;
   return pick;
@@ -483,9 +485,12 @@ Tile pick_ln_tile(const GemmParams& p) {
   if (bk == 64 && p.K / bk <= 4) {
     static const Tile cands[] = {{64, 64, 64}, {64, 32, 64}};
     auto blocks = [&](const Tile& t) { return (long)((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn); };
+    // measured in the full cfg2 step (two queues busy): 32x32 LN tiles beat 64x32/64x64 by 5 % even where the
+    // bigger tiles win in isolation -- more, shorter workgroups interleave better with the other queue's kernels
+    static const long tln = getenv("AVSEP_TLN") ? atol(getenv("AVSEP_TLN")) : 2048;     // developer sweeps
     bool found = false;
     for (const Tile& t : cands)
-      if (!found && blocks(t) >= 512) { pick = t; found = true; }
+      if (!found && blocks(t) >= tln) { pick = t; found = true; }
   }
   return pick;
 }
