@@ -98,6 +98,8 @@ struct avsep_ctx {
   struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
   bool prof_on = false;
   std::vector<ProfRec> prof;
+  // debug timeline: device wall-clock stamps at stage boundaries (AVSEP_STAMPS=1, avsep_read_stamps)
+  unsigned long long* stamps = nullptr;
   // debug taps
   bool keep_taps = false;
   struct Tap { std::string name; size_t off, n; };
@@ -565,14 +567,24 @@ Workspace shift_rows(const avsep_ctx* c, const Workspace& w, int b0, int T) {
 // After the join the visual stream would idle while fusion + decoder run on the audio stream (measured: one
 // hardware queue 84 % busy, the other 40 %, profiles/r01c_*), so the tail is cut in two halves of the batch,
 // one per stream -- same kernels, half the rows each, running concurrently.
+inline void stamp(avsep_ctx* c, int idx, hipStream_t s) {
+  if (c->stamps) (void)launch_stamp(c->stamps, idx, s);
+}
+
 int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const float* lips, float* masks, float* sep,
                  int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv, int p) {
+  stamp(c, 1, sv);
   int rv = visual_branch(c, w, lips, B, N, H, W, T, sv);
+  stamp(c, 2, sv);
   if (rv == AVSEP_OK) rv = fusion_kv(c, w, w.v_up, B, T, sv);
+  stamp(c, 3, sv);
   // always join, even on error, so a capture in progress is not left forked
   hipError_t ej = hipEventRecord(c->ev_vdone[p], sv);
+  stamp(c, 0, sa);
   int ra = audio_branch(c, w, mixed, B, T, sa);
+  stamp(c, 4, sa);
   hipError_t ew = hipStreamWaitEvent(sa, c->ev_vdone[p], 0);
+  stamp(c, 5, sa);
   const bool tail_split = c->tail_split && B >= 2 && !c->keep_taps && !c->prof_on;
   hipError_t ea = hipSuccess, eb = hipSuccess;
   if (tail_split) {
@@ -594,12 +606,16 @@ int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const flo
   const int b1 = (B + 1) / 2;   // clips [0,b1) on sa, [b1,B) on sv
   int r0 = fusion_layers(c, w, w.a_x, b1, T, sa, false);
   if (r0 == AVSEP_OK) r0 = decoder_stage(c, w, w.a_x, masks, sep, b1, T, sa, true);
+  stamp(c, 7, sa);
   const Workspace w1 = shift_rows(c, w, b1, T);
+  stamp(c, 6, sv);
   int r1 = fusion_layers(c, w1, w1.a_x, B - b1, T, sv, false);
   if (r1 == AVSEP_OK)
     r1 = decoder_stage(c, w1, w1.a_x, masks + (size_t)b1 * T * SF, sep + (size_t)b1 * T * SF, B - b1, T, sv, true);
+  stamp(c, 8, sv);
   hipError_t et = hipEventRecord(c->ev_tdone[p], sv);
   hipError_t eu = hipStreamWaitEvent(sa, c->ev_tdone[p], 0);
+  stamp(c, 9, sa);
   if (r0 != AVSEP_OK) return r0;
   if (r1 != AVSEP_OK) return r1;
   HCK(et);
@@ -716,6 +732,10 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) {
   if (const char* e = getenv("AVSEP_SPLIT")) c->split = atoi(e);
   if (const char* e = getenv("AVSEP_TAIL_SPLIT")) c->tail_split = atoi(e) != 0;
   c->no_fused_conv = getenv("AVSEP_NO_FUSED_CONV") != nullptr;
+  if (getenv("AVSEP_STAMPS")) {
+    if (hipMalloc(reinterpret_cast<void**>(&c->stamps), 16 * sizeof(unsigned long long)) != hipSuccess) c->stamps = nullptr;
+    else (void)hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long));
+  }
   if (!ok) { avsep_destroy(c); return fail(AVSEP_EHIP, "stream/event creation failed"); }
   *out = c;
   return AVSEP_OK;
@@ -740,6 +760,7 @@ void avsep_destroy(avsep_ctx* c) {
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->gstream) (void)hipStreamDestroy(c->gstream);
   if (c->arena) (void)hipFree(c->arena);
+  if (c->stamps) (void)hipFree(c->stamps);
   delete c;
 }
 
@@ -785,6 +806,14 @@ int64_t avsep_profile_end(avsep_ctx* c, char* json, size_t cap) {
   if (out.size() + 1 > cap) return fail(AVSEP_ENOMEM, "profile buffer too small");
   memcpy(json, out.c_str(), out.size() + 1);
   return (int64_t)out.size();
+}
+
+int avsep_read_stamps(avsep_ctx* c, uint64_t* out, int n) {
+  if (!c || !out || n <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (!c->stamps) return fail(AVSEP_EINVAL, "stamps are off: set AVSEP_STAMPS=1 before avsep_create()");
+  if (n > 16) n = 16;
+  HCK(hipMemcpy(out, c->stamps, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return n;
 }
 
 int avsep_set_debug_taps(avsep_ctx* c, int on) {

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   constexpr int RSPLIT = NW / 4;                       // conv2 row halves
   constexpr int RB2MAX = (RB2 + RSPLIT - 1) / RSPLIT;  // conv2 row blocks per wave
   constexpr int CB3 = 8 / NW;                          // conv3 16-channel blocks per wave
+  constexpr int RAWN = 5;                              // raw-frame prefetch registers per thread (G*H*W <= RAWN*NT)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* a1 = lds;                         // G x (2*H2+1) x (2*W2+1) x C1P
   float* a2 = lds + G * p.a1_frame;        // G x (2*H3+1) x (2*W3+1) x C2P
@@ -95,19 +96,48 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   const float bias2 = p.b2[16 * cb2 + c];
   const float bias3_0 = p.b3[ch3], bias3_1 = p.b3[ch3 + (CB3 > 1 ? 16 : 0)];
 
+  // conv1 weights of this thread's 4 channels (cq = tid & 7 is the same for every element a thread visits)
+  const int cq1 = tid & 7;
+  f32x4 w1r[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w1r[t] = *reinterpret_cast<const f32x4*>(p.w1 + t * C1 + 4 * cq1);
+  const f32x4 b1r = *reinterpret_cast<const f32x4*>(p.b1 + 4 * cq1);
+
+  // Raw frames are staged through LDS: the next pass's G*H*W pixels are fetched into registers (RAWN coalesced
+  // loads per thread) while this pass runs on the matrix cores, so conv1 never waits on HBM.
+  float* raw = lds + G * (p.a1_frame + p.a2_frame);
+  const int HW = p.H * p.W, nraw = G * HW;
+  float rawv[RAWN];
+  auto fetch_raw = [&](int grp) {
+    const float* src = p.frames + (size_t)grp * G * HW;
+    const int valid = min(G, p.Mv - grp * G) * HW;
+#pragma unroll
+    for (int k = 0; k < RAWN; ++k) {
+      const int i = tid + k * NT;
+      rawv[k] = i < valid ? src[i] : 0.0f;
+    }
+  };
+  if ((int)blockIdx.x < ngroups) fetch_raw(blockIdx.x);
+
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int f0 = grp * G;
-    __syncthreads();   // previous pass done with a1/a2 (and the zero fill on the first pass)
+    __syncthreads();   // previous pass done with a1/a2/raw (and the zero fill on the first pass)
+#pragma unroll
+    for (int k = 0; k < RAWN; ++k) {
+      const int i = tid + k * NT;
+      if (i < nraw) raw[i] = rawv[k];
+    }
+    __syncthreads();
+    if (grp + (int)gridDim.x < ngroups) fetch_raw(grp + gridDim.x);
 
     // ---------------- phase 1: conv1 + BN + ReLU on the VALU -> a1 interior ----------------------------
     for (int idx = tid; idx < G * P1 * 8; idx += NT) {
-      const int cq = idx & 7;
       const int px = idx >> 3;
       const int g = px / P1, pos = px - g * P1;
       const int y = pos / p.W1, x = pos - y * p.W1;
-      f32x4 acc = *reinterpret_cast<const f32x4*>(p.b1 + 4 * cq);
+      f32x4 acc = b1r;
       if (f0 + g < p.Mv) {
-        const float* fr = p.frames + (size_t)(f0 + g) * p.H * p.W;
+        const float* fr = raw + g * HW;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const int iy = 2 * y - 1 + ky;
@@ -116,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
             const int ix = 2 * x - 1 + kx;
             const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const float v = ok ? fr[iy * p.W + ix] : 0.0f;
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.w1 + (ky * 3 + kx) * C1 + 4 * cq);
+            const f32x4 w4 = w1r[ky * 3 + kx];
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, w4[e], acc[e]);
           }
@@ -126,7 +156,7 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
       } else {
         acc = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      *reinterpret_cast<f32x4*>(a1 + g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * cq) = acc;
+      *reinterpret_cast<f32x4*>(a1 + g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * cq1) = acc;
     }
     __syncthreads();
 
@@ -135,16 +165,22 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
       f32x4 acc[RB2MAX];
 #pragma unroll
       for (int i = 0; i < RB2MAX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 bw = *reinterpret_cast<const f32x4*>(w2l);
-#pragma unroll 1
+      // weights are fetched one whole tap ahead (2 x b128 per lane): a tap is ~0.5 us of MFMA work, more than an L2
+      // round trip, where a one-step look-ahead (0.13-0.25 us) left the matrix cores waiting on every step
+      f32x4 wc[2], wn[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) wc[s] = *reinterpret_cast<const f32x4*>(w2l + s * 16);
+#pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int toff = (ky * s1w + kx) * C1P;
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) wn[s] = *reinterpret_cast<const f32x4*>(w2l + (tap + 1) * C1 + s * 16);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const f32x4 b = bw;
-          const int nxt = tap * 2 + s + 1;
-          if (nxt < 18) bw = *reinterpret_cast<const f32x4*>(w2l + (nxt >> 1) * C1 + (nxt & 1) * 16);
+          const f32x4 b = wc[s];
           f32x4 fa[RB2MAX];
 #pragma unroll
           for (int i = 0; i < RB2MAX; ++i)
@@ -155,6 +191,8 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
             for (int i = 0; i < RB2MAX; ++i)
               acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], b[e], acc[i], 0, 0, 0);
         }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wc[s] = wn[s];
       }
       // bias + ReLU -> a2 interior (C/D: col = c -> channel 16*wave+c, row = 4q + r -> position)
 #pragma unroll
@@ -177,20 +215,26 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
       f32x4 acc0[RB3MAX], acc1[RB3MAX];
 #pragma unroll
       for (int i = 0; i < RB3MAX; ++i) acc0[i] = acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 bw0 = *reinterpret_cast<const f32x4*>(w3l0);
-      f32x4 bw1 = *reinterpret_cast<const f32x4*>(w3l1);
-#pragma unroll 1
+      f32x4 wc0[4], wc1[4], wn0[4], wn1[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        wc0[s] = *reinterpret_cast<const f32x4*>(w3l0 + s * 16);
+        wc1[s] = *reinterpret_cast<const f32x4*>(w3l1 + s * 16);
+      }
+#pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int toff = (ky * s2w + kx) * C2P;
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            wn0[s] = *reinterpret_cast<const f32x4*>(w3l0 + (tap + 1) * C2 + s * 16);
+            if constexpr (CB3 > 1) wn1[s] = *reinterpret_cast<const f32x4*>(w3l1 + (tap + 1) * C2 + s * 16);
+          }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const f32x4 b0 = bw0, b1 = bw1;
-          const int nxt = tap * 4 + s + 1;
-          if (nxt < 36) {
-            bw0 = *reinterpret_cast<const f32x4*>(w3l0 + (nxt >> 2) * C2 + (nxt & 3) * 16);
-            if constexpr (CB3 > 1) bw1 = *reinterpret_cast<const f32x4*>(w3l1 + (nxt >> 2) * C2 + (nxt & 3) * 16);
-          }
+          const f32x4 b0 = wc0[s], b1 = wc1[s];
           f32x4 fa[RB3MAX];
 #pragma unroll
           for (int i = 0; i < RB3MAX; ++i)
@@ -202,6 +246,11 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
               acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], b0[e], acc0[i], 0, 0, 0);
               if constexpr (CB3 > 1) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], b1[e], acc1[i], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          wc0[s] = wn0[s];
+          if constexpr (CB3 > 1) wc1[s] = wn1[s];
         }
       }
       // bias + ReLU, then the mean over each frame's P3 positions (rows g*P3 .. (g+1)*P3-1)
@@ -244,6 +293,7 @@ hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t 
   int per_cu = 1;
   if (const char* e = getenv("AVSEP_CONV_WGPC")) per_cu = atoi(e) > 0 ? atoi(e) : 1;   // developer A/B switch
   int grid = 256 * per_cu;
+  if (const char* e = getenv("AVSEP_CONV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer A/B switch
   if (grid > ngroups) grid = ngroups;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, s, p);
   return hipGetLastError();
@@ -273,20 +323,23 @@ hipError_t launch_conv_stack(const float* frames, const float* w1, const float* 
   p.a1_frame = (2 * p.H2 + 1) * (2 * p.W2 + 1) * C1P;
   p.a2_frame = (2 * p.H3 + 1) * (2 * p.W3 + 1) * C2P;
   const int P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
-  const size_t frame_bytes = (size_t)(p.a1_frame + p.a2_frame) * sizeof(float);
+  // per frame: the two haloed images + the raw pixels staged for conv1
+  const size_t frame_bytes = (size_t)(p.a1_frame + p.a2_frame + H * W) * sizeof(float);
+  static const bool four_waves = getenv("AVSEP_CONV_NW4") != nullptr;
+  const size_t raw_cap = (size_t)5 * (four_waves ? 256 : 512);            // RAWN * NT prefetch registers per pass
   const size_t LDS_MAX = 160 * 1024;
   static const bool force_g1 = getenv("AVSEP_CONV_G1") != nullptr;   // developer A/B switch
   // Instantiations (G frames per pass, conv2 row blocks, conv3 row blocks); the smallest one that covers the
   // frame size is used -- surplus row blocks recompute row 0 and are discarded.  Two frames per pass halve the
   // weight traffic per frame.
   const int r2g2 = (2 * P2 + 15) / 16, r3g2 = (2 * P3 + 15) / 16, r2 = (P2 + 15) / 16, r3 = (P3 + 15) / 16;
-  if (!force_g1 && 2 * frame_bytes <= LDS_MAX && Mv > 1) {
+  if (!force_g1 && 2 * frame_bytes <= LDS_MAX && Mv > 1 && (size_t)2 * H * W <= raw_cap) {
     if (r2g2 <= 1 && r3g2 <= 1) return launch_cs<2, 1, 1>(p, 2 * frame_bytes, s);
     if (r2g2 <= 2 && r3g2 <= 1) return launch_cs<2, 2, 1>(p, 2 * frame_bytes, s);
     if (r2g2 <= 4 && r3g2 <= 1) return launch_cs<2, 4, 1>(p, 2 * frame_bytes, s);
     if (r2g2 <= 8 && r3g2 <= 2) return launch_cs<2, 8, 2>(p, 2 * frame_bytes, s);
   }
-  if (frame_bytes > LDS_MAX) return hipErrorNotSupported;
+  if (frame_bytes > LDS_MAX || (size_t)H * W > raw_cap) return hipErrorNotSupported;
   if (r2 <= 1 && r3 <= 1) return launch_cs<1, 1, 1>(p, frame_bytes, s);
   if (r2 <= 4 && r3 <= 1) return launch_cs<1, 4, 1>(p, frame_bytes, s);
   if (r2 <= 9 && r3 <= 3) return launch_cs<1, 9, 3>(p, frame_bytes, s);

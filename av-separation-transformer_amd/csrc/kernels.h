@@ -109,7 +109,8 @@ hipError_t launch_conv_stack(const float* frames, const float* w1, const float* 
 hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);
 
-hipError_t launch_delay(unsigned us, hipStream_t s);   // profiling aid, see rowops.hip
+hipError_t launch_delay(unsigned us, hipStream_t s);
+hipError_t launch_stamp(unsigned long long* buf, int idx, hipStream_t s);   // profiling aid, see rowops.hip
 
 // weight packing (device -> device)
 hipError_t launch_pack_rows(const float* src, float* dst, int rows, int K, int Kp, float scale, int scale_rows,

@@ -162,6 +162,11 @@ __global__ void delay_kernel(unsigned us) {
   while (wall_clock64() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
 }
 
+// Timeline aid: one lane writes the 100 MHz wall clock into slot `idx` (avsep_read_stamps).
+__global__ void stamp_kernel(unsigned long long* buf, int idx) {
+  if (threadIdx.x == 0) buf[idx] = wall_clock64();
+}
+
 // ------------------------------------------------------------------------------------ weight packers
 __global__ void pack_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int K, int Kp,
                                  float scale, int scale_rows) {
@@ -206,6 +211,11 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, float* __restri
 }
 
 }  // namespace
+
+hipError_t launch_stamp(unsigned long long* buf, int idx, hipStream_t s) {
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, buf, idx);
+  return hipGetLastError();
+}
 
 hipError_t launch_delay(unsigned us, hipStream_t s) {
   hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, us);

@@ -115,6 +115,12 @@ int64_t avsep_read_tap(avsep_ctx* ctx, const char* name, float* dst, int64_t max
  *   [{"name":"gemm_kernel<64, 32, 0>","calls":n,"ms":total,"flops":algorithmic,"bytes":algorithmic},...]
  * Returns the JSON length or a negative error.  bench.py prices its roofline from this. */
 int avsep_profile_begin(avsep_ctx* ctx);
+/* Timeline aid (developer tool tools/stamps.py): with AVSEP_STAMPS=1 in the environment at avsep_create(), every
+ * forward also runs one-lane kernels that store the device's 100 MHz wall clock at stage boundaries (0 audio start,
+ * 1 visual start, 2 visual encoder done, 3 K/V projection done, 4 audio done, 5 tail start, 6/8 second-half tail
+ * start/end, 7 first-half tail end, 9 step end); this copies the last forward's first n (<= 16) stamps to the host
+ * (synchronous).  Works under graph replay, where no profiler-free timeline exists otherwise. */
+int avsep_read_stamps(avsep_ctx* ctx, uint64_t* out, int n);
 int64_t avsep_profile_end(avsep_ctx* ctx, char* json, size_t capacity);
 
 /* Single-kernel entry points (parity tests drive every kernel through the ABI).
