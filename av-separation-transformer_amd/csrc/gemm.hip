@@ -194,22 +194,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
 
   // the ring is statically indexed after unrolling; loads past the last chunk are skipped (block-uniform)
   f32x4 ra[D][APASS], rb[D][BPASS];
+  bool rok[D][APASS];   // tap modes: is this row's tap inside the sequence / image?
   auto load_chunk = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       if (AMODE == AMODE_PLAIN) {
         ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + kload * BK);
       } else if (AMODE == AMODE_TAPS3) {
+        // unconditional load from an always-valid address; out-of-sequence taps are zeroed when the chunk is
+        // written to LDS (store_chunk), so the load needs no exec-mask region and stays asynchronous in the ring
         const int t = a_aux0[i] + tap - 1;
         const bool ok = (t >= 0) && (t < p.T);
-        const float* src = a_src[i] + (ptrdiff_t)(tap - 1) * p.lda + sub * BK;
-        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* src = a_src[i] + (ptrdiff_t)(ok ? tap - 1 : 0) * p.lda + sub * BK;
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(src);
+        rok[slot][i] = ok;
       } else {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int iy = a_aux0[i] + ky, ix = a_aux1[i] + kx;
         const bool ok = (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
         const float* src = a_src[i] + ((size_t)(ok ? iy : 0) * p.Win + (ok ? ix : 0)) * p.Kt + sub * BK;
-        ra[slot][i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(src);
+        rok[slot][i] = ok;
       }
     }
 #pragma unroll
@@ -223,7 +228,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     float* a = As + buf * BM * BK;
     float* b = Bs + buf * BN * BK;
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + a_st[i]) = ra[slot][i];
+    for (int i = 0; i < APASS; ++i) {
+      f32x4 v = ra[slot][i];
+      if (AMODE != AMODE_PLAIN) v = rok[slot][i] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(a + a_st[i]) = v;
+    }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + b_st[i]) = rb[slot][i];
   };
