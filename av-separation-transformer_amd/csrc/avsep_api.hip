@@ -665,7 +665,9 @@ int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* mas
     hipStream_t sa = p == 0 ? s : c->pstream[2 * p];
     hipStream_t sv = p == 0 ? c->side : c->pstream[2 * p + 1];
     static const bool serial = getenv("AVSEP_SERIAL") != nullptr;   // developer A/B: everything on one stream
-    if (serial) sv = sa;
+    // the live profiler times every kernel alone on the chip: with two streams the 20x repeated launches of one
+    // branch would overlap the other branch's and inflate both (conv_stack's LDS footprint stalls the audio GEMMs)
+    if (serial || c->prof_on) sv = sa;
     if (p) HCK(hipStreamWaitEvent(sa, c->ev_fork, 0));
     HCK(hipStreamWaitEvent(sv, c->ev_fork, 0));
     const int r = forward_part(c, w[p], mixed + (size_t)b0 * c->F * T, lips + (size_t)b0 * N * H * W,

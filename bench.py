@@ -11,6 +11,10 @@ only, fp32.  A "step" is one forward over one resident batch: inputs are in HBM 
 outputs stay in HBM.  Clips are independent in eval mode, so N GPUs = N independent
 shards of the clip stream, no data-path collective; scaling is weak.
 
+`--mode train` (not the headline) times one training step per "step" instead: train-mode forward
+(dropout 0.1, BatchNorm batch statistics) + SeparationLoss + backward + gradient all-reduce (N > 1) + clip + Adam on
+BASELINE configs[3]'s model (d=512, 6+4 layers, 3 speakers, 16 clips per GPU).
+
 One JSON line on rank 0:
   value          whole-job clips/s (all ranks' clips / max-over-ranks wall time of the K timed steps)
   roofline       dominant kernel of the path, priced live with HIP events on its own stream
