@@ -1,0 +1,193 @@
+"""Op-level parity of the TRAINING ops (include/avsep.h "training ops") at production-like shapes against plain
+PyTorch fp32 autograd on the same device: the end-to-end gradient goldens (test_train_gpu.py) only reach tiny
+shapes, these reach the split-K weight gradient, ragged column reductions, long-sequence attention backward and
+the 300k-row BatchNorm of the conv layers.  Tolerances are relative to the largest reference entry."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref):
+    return float((got - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (4016, 512, 512, 0, False), (4016, 2048, 512, 1, False), (2016, 256, 1024, 0, True),
+    (19200, 64, 288, 0, False), (307200, 32, 32, 0, False), (1200, 512, 128, 0, False), (37, 771, 1024, 0, False),
+])
+def test_linear_fn_forward_backward(dev, M, N, K, act, res):
+    """LinearFn: y, dX = dY W, dW = dY^T X (split over rows when N*K is small), db -- vs torch."""
+    from av_separation import _train as tr
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).requires_grad_()
+    b = torch.randn(N, generator=g).to(dev).requires_grad_()
+    r = torch.randn(M, N, generator=g).to(dev).requires_grad_() if res else None
+    dy = torch.randn(M, N, generator=g).to(dev)
+    y = tr.LinearFn.apply(x, w, b, tr.ACT_RELU if act else tr.ACT_NONE, r, 0)
+    y.backward(dy)
+    got = [y.detach(), x.grad, w.grad, b.grad] + ([r.grad] if res else [])
+    x2, w2, b2 = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    r2 = r.detach().clone().requires_grad_() if res else None
+    y2 = F.linear(x2, w2, b2)
+    if act:
+        y2 = torch.relu(y2)
+    if res:
+        y2 = y2 + r2
+    y2.backward(dy)
+    ref = [y2.detach(), x2.grad, w2.grad, b2.grad] + ([r2.grad] if res else [])
+    for name, a_, b_ in zip(("y", "dx", "dw", "db", "dres"), got, ref):
+        assert _rel(a_, b_) < 2e-5, (name, _rel(a_, b_))
+
+
+@pytest.mark.parametrize("M,C", [(307200, 32), (4016, 2048), (4016, 771), (5, 7), (1, 1), (70000, 128), (257, 300)])
+def test_column_reductions(dev, M, C):
+    from av_separation import _train as tr
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + C)
+    a = torch.randn(M, C, generator=g).to(dev)
+    b = torch.randn(M, C, generator=g).to(dev)
+    s0, _ = tr._colsum(a)
+    t0, t1 = tr._colsum(a, b)
+    ref0 = a.double().sum(0)
+    ref1 = (a.double() * b.double()).sum(0)
+    scale = math.sqrt(M)
+    assert float((s0.double() - ref0).abs().max()) < 2e-5 * scale
+    assert torch.equal(s0, t0)                                     # same stage-1 partition either way
+    assert float((t1.double() - ref1).abs().max()) < 2e-5 * scale
+    again, _ = tr._colsum(a)
+    assert torch.equal(s0, again)                                  # deterministic (no atomics)
+
+
+@pytest.mark.parametrize("M,C", [(307200, 32), (76800, 64), (19200, 128), (40, 32)])
+def test_batchnorm_relu_fn(dev, M, C):
+    """BatchNormReluFn (batch statistics, running-stat update, backward) vs F.batch_norm(training=True)+relu."""
+    from av_separation import _train as tr
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(dev)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dev).requires_grad_()
+    bet = torch.randn(C, generator=g).to(dev).requires_grad_()
+    # keep every pre-activation away from the ReLU kink: with 10^7 elements one of them lands within rounding of 0,
+    # and the two implementations may then legitimately disagree on its mask bit (an O(1) error at that element)
+    for _ in range(2):
+        xd = x.double()
+        pre = (xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + 1e-5) * gam.detach().double() + bet.detach().double()
+        x = torch.where(pre.abs() < 1e-3, x + 0.02 * torch.sign(pre).float() + 0.02 * (pre == 0).float(), x)
+    x.requires_grad_()
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    dy = torch.randn(M, C, generator=g).to(dev)
+    y = tr.BatchNormReluFn.apply(x, gam, bet, rm, rv, 1e-5, 0.1)
+    y.backward(dy)
+    x2, g2, b2 = (t.detach().clone().requires_grad_() for t in (x, gam, bet))
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y2 = torch.relu(F.batch_norm(x2, rm2, rv2, g2, b2, True, 0.1, 1e-5))
+    y2.backward(dy)
+    for name, a_, b_ in (("y", y.detach(), y2.detach()), ("dx", x.grad, x2.grad), ("dgamma", gam.grad, g2.grad),
+                         ("dbeta", bet.grad, b2.grad), ("running_mean", rm, rm2), ("running_var", rv, rv2)):
+        assert _rel(a_, b_) < 5e-5, (name, _rel(a_, b_))
+
+
+@pytest.mark.parametrize("B,h,dh,Lq,Lk,cross", [(2, 8, 64, 251, 251, False), (1, 8, 64, 501, 501, True),
+                                                 (3, 2, 32, 19, 50, True), (2, 4, 16, 32, 32, False), (1, 4, 16, 1, 1, False)])
+def test_attention_fn_forward_backward(dev, B, h, dh, Lq, Lk, cross):
+    """AttentionFn on the packed in_proj layout vs torch scaled_dot_product_attention autograd."""
+    from av_separation import _train as tr
+    d = h * dh
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Lq + Lk)
+    if cross:
+        q = torch.randn(B * Lq, d, generator=g).to(dev).requires_grad_()
+        kv = torch.randn(B * Lk, 2 * d, generator=g).to(dev).requires_grad_()
+        o = tr.AttentionFn.apply(q, kv, 0, 0, d, B, h, dh, Lq, Lk, 1.0 / math.sqrt(dh))
+    else:
+        qkv = torch.randn(B * Lq, 3 * d, generator=g).to(dev).requires_grad_()
+        o = tr.AttentionFn.apply(qkv, qkv, 0, d, 2 * d, B, h, dh, Lq, Lk, 1.0 / math.sqrt(dh))
+    do = torch.randn(B * Lq, d, generator=g).to(dev)
+    o.backward(do)
+
+    def heads(t, L):
+        return t.reshape(B, L, h, dh).permute(0, 2, 1, 3)
+
+    if cross:
+        q2, kv2 = q.detach().clone().requires_grad_(), kv.detach().clone().requires_grad_()
+        qq, kk, vv = heads(q2, Lq), heads(kv2[:, :d], Lk), heads(kv2[:, d:], Lk)
+    else:
+        qkv2 = qkv.detach().clone().requires_grad_()
+        qq, kk, vv = heads(qkv2[:, :d], Lq), heads(qkv2[:, d:2 * d], Lk), heads(qkv2[:, 2 * d:], Lk)
+    p = torch.softmax((qq @ kk.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    o2 = (p @ vv).permute(0, 2, 1, 3).reshape(B * Lq, d)
+    o2.backward(do)
+    assert _rel(o.detach(), o2.detach()) < 2e-5
+    if cross:
+        assert _rel(q.grad, q2.grad) < 5e-5 and _rel(kv.grad, kv2.grad) < 5e-5
+    else:
+        assert _rel(qkv.grad, qkv2.grad) < 5e-5
+
+
+@pytest.mark.parametrize("M,d", [(4016, 512), (2016, 256), (70, 96), (3, 64)])
+def test_layernorm_fn(dev, M, d):
+    from av_separation import _train as tr
+    g = torch.Generator(device="cpu").manual_seed(M + d)
+    x = (torch.randn(M, d, generator=g) * 3 + 1).to(dev).requires_grad_()
+    gam = (torch.rand(d, generator=g) + 0.5).to(dev).requires_grad_()
+    bet = torch.randn(d, generator=g).to(dev).requires_grad_()
+    dy = torch.randn(M, d, generator=g).to(dev)
+    y = tr.LayerNormFn.apply(x, gam, bet, 1e-5)
+    y.backward(dy)
+    x2, g2, b2 = (t.detach().clone().requires_grad_() for t in (x, gam, bet))
+    y2 = F.layer_norm(x2, (d,), g2, b2, 1e-5)
+    y2.backward(dy)
+    for name, a_, b_ in (("y", y.detach(), y2.detach()), ("dx", x.grad, x2.grad), ("dg", gam.grad, g2.grad),
+                         ("db", bet.grad, b2.grad)):
+        assert _rel(a_, b_) < 3e-5, (name, _rel(a_, b_))
+
+
+def test_conv_layers_as_im2col_gemm(dev):
+    """Conv1d(k3,p1) and Conv2d(k3,s2,p1) forward/backward through Im2col*Fn + LinearFn vs torch convolutions
+    (the layout conventions of train_forward: channels-last rows, weights permuted tap-major)."""
+    from av_separation import _train as tr
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, T, Ci, Co = 3, 37, 64, 96
+    x = torch.randn(B * T, Ci, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(Co, Ci, 3, generator=g) * 0.1).to(dev).requires_grad_()
+    b = torch.randn(Co, generator=g).to(dev).requires_grad_()
+    dy = torch.randn(B * T, Co, generator=g).to(dev)
+    y = tr.LinearFn.apply(tr.Im2col1dFn.apply(x, T), w.permute(0, 2, 1).reshape(Co, 3 * Ci), b, tr.ACT_NONE, None, 0)
+    y.backward(dy)
+    x2, w2, b2 = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    y2 = F.conv1d(x2.reshape(B, T, Ci).permute(0, 2, 1), w2, b2, padding=1).permute(0, 2, 1).reshape(B * T, Co)
+    y2.backward(dy)
+    for a_, b_ in ((y.detach(), y2.detach()), (x.grad, x2.grad), (w.grad, w2.grad), (b.grad, b2.grad)):
+        assert _rel(a_, b_) < 3e-5
+    I, H, W, Ci, Co = 5, 15, 13, 32, 64
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = torch.randn(I * H * W, Ci, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1).to(dev).requires_grad_()
+    b = torch.randn(Co, generator=g).to(dev).requires_grad_()
+    dy = torch.randn(I * Ho * Wo, Co, generator=g).to(dev)
+    y = tr.LinearFn.apply(tr.Im2col2dFn.apply(x, I, H, W, 9 * Ci), w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci), b,
+                          tr.ACT_NONE, None, 0)
+    y.backward(dy)
+    x2, w2, b2 = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    y2 = F.conv2d(x2.reshape(I, H, W, Ci).permute(0, 3, 1, 2), w2, b2, stride=2, padding=1)
+    y2 = y2.permute(0, 2, 3, 1).reshape(I * Ho * Wo, Co)
+    y2.backward(dy)
+    for a_, b_ in ((y.detach(), y2.detach()), (x.grad, x2.grad), (w.grad, w2.grad), (b.grad, b2.grad)):
+        assert _rel(a_, b_) < 3e-5
+
+
+def test_attention_backward_rejects_unsupported_head_dim(dev):
+    """The backward kernels tile the head dimension in 16-wide MFMA blocks: dh % 16 != 0 (legal for the forward, which
+    takes any dh % 4 == 0) must fail loudly, not silently compute something else."""
+    from av_separation import _train as tr
+    qkv = torch.randn(4, 3 * 32, device=dev, requires_grad=True)
+    o = tr.AttentionFn.apply(qkv, qkv, 0, 32, 64, 1, 4, 8, 4, 4, 1.0 / math.sqrt(8))
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        o.sum().backward()
