@@ -79,6 +79,15 @@ def shard_range(rank, world, batch):
     return range(rank * batch, (rank + 1) * batch)
 
 
+def max_over_ranks(dist, seconds, dev):
+    """The slowest rank defines the step time (one scalar all-reduce outside the timed region)."""
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,13 +113,18 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", local)
+    # rehearsal hook for the one-GPU test box (tests/test_bench_gpu.py): all ranks on device 0, gloo instead of RCCL
+    rehearsal = os.environ.get("AVSEP_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import av_separation as av
     if a.mode == "train":
@@ -147,11 +161,7 @@ def main():
         t1 = time.perf_counter()
         if dist is not None:
             dist.barrier()
-        elapsed = t1 - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = max_over_ranks(dist, t1 - t0, dev)
 
         # ---- per-kernel roofline, live: eager forwards with every launch bracketed by HIP events
         prof_iters = 3
@@ -280,11 +290,7 @@ def train_main(a, av, dev, dist, rank, world):
     t1 = time.perf_counter()
     if dist is not None:
         dist.barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, t1 - t0, dev)
     gflop_clip = 3 * flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
     value = world * B * a.steps / elapsed
     tf = value / world * gflop_clip / 1e3
