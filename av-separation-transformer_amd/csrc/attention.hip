@@ -286,160 +286,7 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const float* __res
   }
 }
 
-// Short-sequence attention FUSED with the output projection and the residual add (d_model = 256 = 4 heads x 64,
-// 49 <= Lk <= 64: BASELINE configs 1/2).  x[q] += Wo . concat_h(softmax(q_h k_h^T) v_h) + bo for one clip's 16-query
-// tile per workgroup: waves 0-3 each run one head exactly like attention_short_kernel and park their normalised
-// 16 x 64 output slice in LDS; after one barrier all 8 waves take 32 output columns each of the 16 x 256 x 256
-// projection (A fragments = Wo rows straight from L2, two float4 per k-step; B fragments = ds_read_b128 of the
-// parked attention output; same k-permutation as the GEMM kernels) and store bias + residual in place.
-// One launch instead of attention + GEMM, and the attention output never leaves the CU.  Waves 4-7 fetch their
-// whole Wo slice (32 float4 per lane) while the heads are still running.
-template <int NKT>
-__global__ __launch_bounds__(512) void attn_outproj_short_kernel(const float* __restrict__ q, int ldq,
-                                                                 const float* __restrict__ k, int ldk,
-                                                                 const float* __restrict__ v, int ldv,
-                                                                 const float* __restrict__ wo,
-                                                                 const float* __restrict__ bo, float* __restrict__ x,
-                                                                 int ldx, int Lq, int Lk, int nqt) {
-  constexpr int NB = 4, DH = 64, D = 256, LDO = D + 4;
-  __shared__ __attribute__((aligned(16))) float ol[16 * LDO];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int c = lane & 15;
-  const int g = lane >> 4;
-  const int b = blockIdx.x / nqt, qt = blockIdx.x - b * nqt;
-
-  // projection weights of this wave: rows n0 + 16 i + c (i = 0, 1), k = 16 s + 4 g .. + 3
-  const int n0 = 32 * wave;
-  const float* w0 = wo + (size_t)(n0 + c) * D + 4 * g;
-  const float* w1 = w0 + (size_t)16 * D;
-  f32x4 wa[16], wb[16];
-  if (wave >= 4) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      wa[s] = *reinterpret_cast<const f32x4*>(w0 + 16 * s);
-      wb[s] = *reinterpret_cast<const f32x4*>(w1 + 16 * s);
-    }
-  } else {
-    const int h = wave;
-    const float* qb = q + (size_t)b * Lq * ldq + h * DH;
-    const float* kb = k + (size_t)b * Lk * ldk + h * DH;
-    const float* vb = v + (size_t)b * Lk * ldv + h * DH;
-    const int qrow = min(qt * 16 + c, Lq - 1);
-    f32x4 qf[NB], kf[NKT][NB], vf[NKT][4];
-#pragma unroll
-    for (int s = 0; s < NB; ++s) qf[s] = *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g);
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const int krow = min(kt * 16 + c, Lk - 1);
-#pragma unroll
-      for (int s = 0; s < NB; ++s) kf[kt][s] = *reinterpret_cast<const f32x4*>(kb + (size_t)krow * ldk + 16 * s + 4 * g);
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int vrow = min(kt * 16 + 4 * g + r, Lk - 1);
-        vf[kt][r] = *reinterpret_cast<const f32x4*>(vb + (size_t)vrow * ldv + NB * c);
-      }
-    f32x4 st[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NB; ++s)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-          st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][s][j], qf[s][j], st[kt], 0, 0, 0);
-    float mrow = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        st[kt][r] = key < Lk ? st[kt][r] : -INFINITY;
-        mrow = fmaxf(mrow, st[kt][r]);
-      }
-    mrow = fmaxf(mrow, __shfl_xor(mrow, 16));
-    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
-    float lrun = 0.0f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        st[kt][r] = exp_neg(st[kt][r] - mrow);
-        lrun += st[kt][r];
-      }
-    f32x4 acc[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
-          acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][blk], st[kt][r], acc[blk], 0, 0, 0);
-    lrun += __shfl_xor(lrun, 16);
-    lrun += __shfl_xor(lrun, 32);
-    const float inv = 1.0f / lrun;
-    // lane (c, g) holds O[query c][head h, dh 16 g + 4 r + blk]
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<f32x4*>(ol + c * LDO + h * DH + 16 * g + 4 * r) =
-          f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
-    // the heads' own projection weights: issued now, consumed after the barrier
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      wa[s] = *reinterpret_cast<const f32x4*>(w0 + 16 * s);
-      wb[s] = *reinterpret_cast<const f32x4*>(w1 + 16 * s);
-    }
-  }
-  __syncthreads();
-
-  f32x4 y0 = f32x4{0.f, 0.f, 0.f, 0.f}, y1 = y0;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const f32x4 of = *reinterpret_cast<const f32x4*>(ol + c * LDO + 16 * s + 4 * g);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s][j], of[j], y0, 0, 0, 0);
-      y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s][j], of[j], y1, 0, 0, 0);
-    }
-  }
-  // C/D layout: col = c -> query, row = 4 g + r -> output column n0 + 16 i + 4 g + r: one float4 per tile
-  const int qo = qt * 16 + c;
-  if (qo < Lq) {
-    float* xr = x + ((size_t)b * Lq + qo) * ldx + n0 + 4 * g;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bo + n0 + 4 * g);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bo + n0 + 16 + 4 * g);
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(xr);
-    const f32x4 r1 = *reinterpret_cast<const f32x4*>(xr + 16);
-    *reinterpret_cast<f32x4*>(xr) = f32x4{y0[0] + b0[0] + r0[0], y0[1] + b0[1] + r0[1], y0[2] + b0[2] + r0[2], y0[3] + b0[3] + r0[3]};
-    *reinterpret_cast<f32x4*>(xr + 16) =
-        f32x4{y1[0] + b1[0] + r1[0], y1[1] + b1[1] + r1[1], y1[2] + b1[2] + r1[2], y1[3] + b1[3] + r1[3]};
-  }
-}
-
 }  // namespace
-
-bool attention_outproj_fusable(int nhead, int dh, int Lk) {
-  static const bool off = getenv("AVSEP_NO_ATTN_FUSE") != nullptr;   // developer A/B switch
-  return !off && nhead == 4 && dh == 64 && Lk > 48 && Lk <= 64;
-}
-
-// x[b, q, :] += Wo . attention(q, k, v)[b, q, :] + bo  (in place); only for attention_outproj_fusable() shapes.
-hipError_t launch_attention_outproj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                                    const float* wo, const float* bo, float* x, int ldx, int B, int nhead, int dh,
-                                    int Lq, int Lk, hipStream_t s) {
-  if (B <= 0 || Lq <= 0 || !attention_outproj_fusable(nhead, dh, Lk)) return hipErrorInvalidValue;
-  if ((ldq | ldk | ldv | ldx) & 3) return hipErrorInvalidValue;
-  const int nqt = (Lq + 15) / 16;
-  hipLaunchKernelGGL((attn_outproj_short_kernel<4>), dim3((unsigned)(B * nqt)), dim3(512), 0, s, q, ldq, k, ldk, v, ldv,
-                     wo, bo, x, ldx, Lq, Lk, nqt);
-  return hipGetLastError();
-}
 
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                             int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s) {

@@ -388,30 +388,15 @@ GemmParams linear_params(const float* A, int lda, const float* W, int K, const f
   return p;
 }
 
-// x += Wo attention(q, k, v) + bo: one fused launch for the short-sequence d = 256 shapes (attention.hip), else the
-// attention kernel into `att` followed by the out-projection GEMM with the residual epilogue.
-int run_attention_outproj(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                          float* att, const float* wo, const float* bo, float* x, int B, int Lq, int Lk, hipStream_t s) {
-  const int d = c->d, M = B * Lq;
-  if (attention_outproj_fusable(c->h, c->dh, Lk) && d == 256) {
-    const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh + 2.0 * M * (double)d * d;
-    const double bytes = 4.0 * (B * d * (2.0 * Lq + 2.0 * Lk) + (double)d * d + 2.0 * M * d);
-    return profiled(c, "attn_outproj_short_kernel", flops, bytes, s, [&] {
-      return launch_attention_outproj(q, ldq, k, ldk, v, ldv, wo, bo, x, d, B, c->h, c->dh, Lq, Lk, s);
-    });
-  }
-  RCK(run_attention(c, q, ldq, k, ldk, v, ldv, att, d, B, Lq, Lk, s));
-  GemmParams po = linear_params(att, d, wo, d, bo, x, d, M, d, ACT_NONE);
-  po.R = x; po.ldr = d; po.rperiod = 0;
-  return run_gemm(c, po, s);
-}
-
 // one pre-norm encoder layer: x += Wo*Attn(LN1 x); x += W2*relu(W1*LN2 x)   (model.py:48-52, norm_first)
 int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
                   int Lseq, hipStream_t s) {
   const int d = c->d, M = B * Lseq;
   RCK(run_ln_linear(c, x, L.g1, L.be1, ln, L.wqkv, L.bqkv, qkv, M, 3 * d, ACT_NONE, s));   // norm1 -> in_proj
-  RCK(run_attention_outproj(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, L.wo, L.bo, x, B, Lseq, Lseq, s));
+  RCK(run_attention(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, d, B, Lseq, Lseq, s));
+  GemmParams po = linear_params(att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
+  po.R = x; po.ldr = d; po.rperiod = 0;
+  RCK(run_gemm(c, po, s));
   RCK(run_ln_linear(c, x, L.g2, L.be2, ln, L.w1, L.b1, ffn, M, 4 * d, ACT_RELU, s));        // norm2 -> linear1
   GemmParams p2 = linear_params(ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
   p2.R = x; p2.ldr = d; p2.rperiod = 0;
@@ -524,7 +509,10 @@ int fusion_layers(avsep_ctx* c, const Workspace& w, float* x, int B, int T, hipS
     const FusLayerW& L = c->f_layers[i];
     RCK(run_ln_linear(c, x, L.g1, L.be1, w.ln, L.wq, L.bq, w.f_q, M, d, ACT_NONE, s));       // norm1 -> q proj
     const float* kk = w.kv_all + (size_t)i * 2 * d;
-    RCK(run_attention_outproj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s));
+    RCK(run_attention(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, d, B, T, T, s));
+    GemmParams po = linear_params(w.att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
+    po.R = x; po.ldr = d;
+    RCK(run_gemm(c, po, s));
     RCK(run_ln_linear(c, x, L.g2, L.be2, w.ln, L.w1, L.b1, w.ffn, M, 4 * d, ACT_GELU, s));   // norm2 -> ff.0
     GemmParams p2 = linear_params(w.ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
     p2.R = x; p2.ldr = d;

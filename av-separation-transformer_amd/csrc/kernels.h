@@ -61,10 +61,6 @@ hipError_t launch_layernorm(const float* x, const float* g, const float* b, floa
                             hipStream_t s);
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                             float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s);
-bool attention_outproj_fusable(int nhead, int dh, int Lk);
-hipError_t launch_attention_outproj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                                    const float* wo, const float* bo, float* x, int ldx, int B, int nhead, int dh,
-                                    int Lq, int Lk, hipStream_t s);
 hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, float qscale, float* lse,
                                float drop_p, unsigned long long drop_seed, hipStream_t s);
