@@ -231,7 +231,8 @@ def main():
     }
 
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(model, mixed, lips, masks, mk, B, a.cpu_seconds)
+        clean = torch.stack([it["clean_specs"] for it in items])
+        out["cpu_baseline"] = cpu_baseline(model, mixed, lips, masks, sep, clean, mk, B, a.cpu_seconds)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -319,8 +320,18 @@ def train_main(a, av, dev, dist, rank, world):
         print(json.dumps(out))
 
 
-def cpu_baseline(model, mixed, lips, masks_gpu, mk, B, budget_s):
-    """Reference CPU path (port) on this box's host cores + the parity of this run's GPU masks against it."""
+def si_snr_improvement(separated, mixed, clean):
+    """SI-SNRi in dB (BASELINE.json's quality metric): best-permutation SI-SNR of the separated spectrograms against the
+    clean ones minus the SI-SNR of the unprocessed mixture, batch mean (losses.si_snr semantics)."""
+    from itertools import permutations
+    from av_separation.losses import si_snr
+    S = clean.shape[1]
+    best = max(float(si_snr(separated[:, list(p)], clean)) for p in permutations(range(S)))
+    return best - float(si_snr(mixed.unsqueeze(1).expand_as(clean), clean))
+
+
+def cpu_baseline(model, mixed, lips, masks_gpu, sep_gpu, clean, mk, B, budget_s):
+    """Reference CPU path (port) on this box's host cores + the parity of this run's GPU outputs against it."""
     import numpy as np
     from oracle import torch_cpu
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -349,11 +360,16 @@ def cpu_baseline(model, mixed, lips, masks_gpu, mk, B, budget_s):
     torch.set_num_threads(avail)
     med = float(np.median(times))
     got = masks_gpu.permute(0, 2, 3, 1).cpu()
+    got_sep = sep_gpu.permute(0, 2, 3, 1).cpu()
+    quality = {"si_snr_i_db_gpu": round(si_snr_improvement(got_sep, mx, clean), 4),
+               "si_snr_i_db_cpu": round(si_snr_improvement(ref_sep, mx, clean), 4),
+               "weights": "random init (torch.manual_seed(0)): the pair shows parity of the metric, not separation quality"}
     return {"value": round(B / med, 2), "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": f"{len(times)} forwards of the same {B}-clip batch, median {med * 1e3:.1f} ms "
                       f"(torch {torch.__version__} CPU, eval/no_grad/fp32, fused encoder fast path; best of "
                       f"8/16/32/64/{avail} threads)",
-            "gpu_masks_max_abs_err_vs_cpu": float((got - ref_masks).abs().max())}
+            "gpu_masks_max_abs_err_vs_cpu": float((got - ref_masks).abs().max()),
+            "gpu_separated_max_abs_err_vs_cpu": float((got_sep - ref_sep).abs().max()), **quality}
 
 
 if __name__ == "__main__":
