@@ -14,6 +14,9 @@ torch supplies only what BASELINE.json's north star leaves to it: tensor allocat
 parameters (layout plumbing whose adjoints autograd replays), the graph bookkeeping, and the SI-SNR/L1 loss.
 Gradient parity against the reference is pinned by tests/golden/train_*.npz (tests/test_train_gpu.py).
 
+The same composition also serves the autograd path of EVAL-mode modules (the reference's modules stay
+differentiable after ``.eval()``): dropout off, BatchNorm on running statistics (``BatchNormEvalReluFn``).
+
 Round-1 scope: correctness; every op is its own launch (no fusion, no graph).  Dropout (the reference's default
 0.1: PositionalEncoding, the attention probabilities, the residual branches and FFN/decoder hidden layers) uses a
 stateless counter-based mask generated in the kernels from (seed, element index), so the backward regenerates it;
@@ -469,24 +472,76 @@ class MulMixedFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------- model composition
-class _Drop:
-    """Dropout bookkeeping of one forward: probability per module and a fresh seed per site."""
+class BatchNormEvalReluFn(torch.autograd.Function):
+    """BatchNorm2d in EVAL mode (running statistics) + ReLU on rows [M, C], differentiable: the autograd path of an
+    eval-mode module (reference modules stay differentiable after .eval()).  dx = gamma*rstd*dy_masked; the affine
+    gradients are the usual column sums."""
 
-    def __init__(self, seed):
+    @staticmethod
+    def forward(ctx, x, g, b, rmean, rvar, eps):
+        x = _c(x)
+        M, Cc = x.shape
+        xh, y = torch.empty_like(x), torch.empty_like(x)
+        rm, rv = _c(rmean.detach()), _c(rvar.detach())
+        _ck(_lib().avsep_op_bn_apply(x.data_ptr(), rm.data_ptr(), rv.data_ptr(), g.data_ptr(), b.data_ptr(),
+                                     xh.data_ptr(), y.data_ptr(), M, Cc, eps, 1, _st(x)), "bn_apply")
+        ctx.eps = eps
+        ctx.save_for_backward(y, xh, g, rv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, xh, g, rv = ctx.saved_tensors
+        dy = _c(dy)
+        M, Cc = y.shape
+        lib = _lib()
+        dx, dyr = torch.empty_like(y), torch.empty_like(y)
+        sums = torch.empty(2 * Cc, device=y.device)
+        s = _scratch(M, Cc, y)
+        _ck(lib.avsep_op_bn_bwd_sums(dy.data_ptr(), y.data_ptr(), xh.data_ptr(), dyr.data_ptr(), sums.data_ptr(),
+                                     sums[Cc:].data_ptr(), s.data_ptr(), M, Cc, 1, _st(y)), "bn_bwd_sums")
+        zero = torch.zeros(2 * Cc, device=y.device)           # no batch-statistics terms in eval mode
+        _ck(lib.avsep_op_bn_bwd_dx(dyr.data_ptr(), xh.data_ptr(), g.data_ptr(), rv.data_ptr(), zero.data_ptr(),
+                                   zero[Cc:].data_ptr(), dx.data_ptr(), M, Cc, 1.0, ctx.eps, _st(y)), "bn_bwd_dx")
+        return dx, sums[Cc:].clone(), sums[:Cc].clone(), None, None, None
+
+
+class _Drop:
+    """Dropout bookkeeping of one forward: a fresh seed per site; inactive (identity) when the module is in eval mode."""
+
+    def __init__(self, seed, active=True):
         self.base = int(seed) & 0x3FFFFFFFFFFFFFFF
         self.site = 0
+        self.active = active
 
     def seed(self):
         self.site += 1
         return (self.base + 0x9E3779B97F4A7C15 * self.site) & 0xFFFFFFFFFFFFFFFF
 
+    def p(self, p):
+        return float(p) if self.active else 0.0
+
     def __call__(self, x, p):
+        p = self.p(p)
         return DropoutFn.apply(x, p, self.seed()) if p > 0 else x
+
+
+def make_drop(module, probs, seed=None, group=None):
+    """Dropout state for one forward of ``module``: active in train mode only; the base seed comes from torch's CPU
+    generator (``torch.manual_seed`` makes runs repeatable); ranks of a data-parallel group draw different masks."""
+    active = module.training and max(probs) > 0
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if active else 0
+    if group is not None:
+        import torch.distributed as dist
+        if dist.get_world_size(group) > 1:
+            seed = int(seed) + 0x632BE59BD9B4E019 * (dist.get_rank(group) + 1)
+    return _Drop(seed, active)
 
 
 def _residual_linear(x_res, inp, w, b, p, drop):
     """x_res + dropout(inp w^T + b): the residual rides the GEMM epilogue unless dropout sits in between."""
-    if p > 0:
+    if drop.p(p) > 0:
         return AddFn.apply(x_res, drop(LinearFn.apply(inp, w, b, ACT_NONE, None, 0), p))
     return LinearFn.apply(inp, w, b, ACT_NONE, x_res, 0)
 
@@ -496,9 +551,10 @@ def _encoder_layer(x, P, pre, B, L, h, p, drop):
     dropout1 on the attention branch, dropout after the ReLU and dropout2 on the FFN branch."""
     d = x.shape[1]
     dh = d // h
+    pa = drop.p(p)
     n = LayerNormFn.apply(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5)
     qkv = LinearFn.apply(n, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"], ACT_NONE, None, 0)
-    o = AttentionFn.apply(qkv, qkv, 0, d, 2 * d, B, h, dh, L, L, 1.0 / math.sqrt(dh), p, drop.seed() if p > 0 else 0)
+    o = AttentionFn.apply(qkv, qkv, 0, d, 2 * d, B, h, dh, L, L, 1.0 / math.sqrt(dh), pa, drop.seed() if pa > 0 else 0)
     x = _residual_linear(x, o, P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], p, drop)
     n = LayerNormFn.apply(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)
     f = drop(LinearFn.apply(n, P[pre + "linear1.weight"], P[pre + "linear1.bias"], ACT_RELU, None, 0), p)
@@ -512,96 +568,150 @@ def _count(P, prefix):
     return n
 
 
+def _rows_of_mixed(mixed, Fp):
+    """(B, F, T) -> mixed^T rows [B*T, Fp] (zero padded); differentiable when the caller wants d/d mixed (the
+    transposition itself is tensor plumbing)."""
+    B, Fq, T = mixed.shape
+    if mixed.requires_grad and torch.is_grad_enabled():
+        return F.pad(mixed.permute(0, 2, 1).reshape(B * T, Fq), (0, Fp - Fq)).contiguous()
+    xt = torch.empty(B * T, Fp, device=mixed.device)
+    _ck(_lib().avsep_op_transpose_pad(mixed.data_ptr(), xt.data_ptr(), B, Fq, T, Fp, _st(mixed)), "transpose_pad")
+    return xt
+
+
+def audio_stage(P, Bf, pre, xt, B, T, Fq, d, h, p, drop):
+    """AudioEncoder (model.py:54-60) on mixed^T rows xt [B*T, Fp] -> [B*T, d]."""
+    Fp = xt.shape[1]
+    col = Im2col1dFn.apply(xt, T)                                                     # [M, 3*Fp]
+    w1 = F.pad(P[pre + "input_proj.0.weight"].permute(0, 2, 1), (0, Fp - Fq)).reshape(d, 3 * Fp)
+    hcur = LinearFn.apply(col, w1, P[pre + "input_proj.0.bias"], ACT_RELU, None, 0)
+    w2 = P[pre + "input_proj.2.weight"].permute(0, 2, 1).reshape(d, 3 * d)
+    pe_a = _c(Bf[pre + "pos_enc.pe"][0, :T])
+    a = LinearFn.apply(Im2col1dFn.apply(hcur, T), w2, P[pre + "input_proj.2.bias"], ACT_RELU, None, 0)
+    a = drop(AddRowsFn.apply(a, pe_a, T), p)
+    for i in range(_count(P, pre + "transformer.layers.")):
+        a = _encoder_layer(a, P, f"{pre}transformer.layers.{i}.", B, T, h, p, drop)
+    return a
+
+
+def visual_stage(P, Bf, pre, lips, T, d, h, p, drop, training, group=None):
+    """VisualEncoder (model.py:103-117) on (B, N, H, W) frames -> [B*T, d].  BatchNorm uses batch statistics (spanning
+    the ranks of ``group``) when ``training``, running statistics otherwise."""
+    B, N, H, W = lips.shape
+    world = 1
+    if group is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+    Mv = B * N
+    x = _c(lips).reshape(Mv * H * W, 1)
+    hh, ww, cin = H, W, 1
+    for conv_i, bn_i, cout in ((0, 1, 32), (3, 4, 64), (6, 7, 128)):
+        cw = P[f"{pre}conv.{conv_i}.weight"].permute(0, 2, 3, 1).reshape(cout, 9 * cin)   # [Co, tap*Ci + ci]
+        Kp = _up32(9 * cin)
+        if Kp != 9 * cin:
+            cw = F.pad(cw, (0, Kp - 9 * cin))
+        colv = Im2col2dFn.apply(x, Mv, hh, ww, Kp)
+        y = LinearFn.apply(colv, cw, P[f"{pre}conv.{conv_i}.bias"], ACT_NONE, None, 0)
+        bn = f"{pre}conv.{bn_i}."
+        args = (y, P[bn + "weight"], P[bn + "bias"], Bf[bn + "running_mean"], Bf[bn + "running_var"], 1e-5)
+        if not training:
+            x = BatchNormEvalReluFn.apply(*args)
+        else:
+            x = SyncBatchNormReluFn.apply(*args, 0.1, group) if world > 1 else BatchNormReluFn.apply(*args, 0.1)
+            Bf[bn + "num_batches_tracked"].add_(1)
+        hh, ww, cin = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1, cout
+    pooled = AvgPoolFn.apply(x, Mv, hh * ww)
+    pe_v = _c(Bf[pre + "pos_enc.pe"][0, :N])
+    v = drop(LinearFn.apply(pooled, P[pre + "frame_proj.weight"], P[pre + "frame_proj.bias"], ACT_NONE, pe_v, N), p)
+    for i in range(_count(P, pre + "transformer.layers.")):
+        v = _encoder_layer(v, P, f"{pre}transformer.layers.{i}.", B, N, h, p, drop)
+    return InterpFn.apply(v, B, N, T)
+
+
+def fusion_stage(P, pre, a, v, B, T, d, h, p, drop):
+    """CrossModalFusion (model.py:145-173) on rows a, v [B*T, d]: visual is not normalised and feeds every layer."""
+    dh = d // h
+    pa = drop.p(p)
+    i = 0
+    while f"{pre}layers.{i}.norm1.weight" in P:
+        q_ = f"{pre}layers.{i}."
+        win, bin_ = P[q_ + "cross_attn.in_proj_weight"], P[q_ + "cross_attn.in_proj_bias"]
+        n = LayerNormFn.apply(a, P[q_ + "norm1.weight"], P[q_ + "norm1.bias"], 1e-5)
+        q = LinearFn.apply(n, win[:d], bin_[:d], ACT_NONE, None, 0)
+        kv = LinearFn.apply(v, win[d:], bin_[d:], ACT_NONE, None, 0)
+        o = AttentionFn.apply(q, kv, 0, 0, d, B, h, dh, T, T, 1.0 / math.sqrt(dh), pa, drop.seed() if pa > 0 else 0)
+        a = _residual_linear(a, o, P[q_ + "cross_attn.out_proj.weight"], P[q_ + "cross_attn.out_proj.bias"], p, drop)
+        n = LayerNormFn.apply(a, P[q_ + "norm2.weight"], P[q_ + "norm2.bias"], 1e-5)
+        f = drop(ActFn.apply(LinearFn.apply(n, P[q_ + "ff.0.weight"], P[q_ + "ff.0.bias"], ACT_NONE, None, 0), ACT_GELU), p)
+        a = _residual_linear(a, f, P[q_ + "ff.3.weight"], P[q_ + "ff.3.bias"], p, drop)
+        i += 1
+    return LayerNormFn.apply(a, P[pre + "norm.weight"], P[pre + "norm.bias"], 1e-5)
+
+
+def decoder_stage(P, pre, a, p, drop):
+    """SeparationDecoder.forward (model.py:201-208) on rows [B*T, d] -> masks rows [B*T, S*F] (channel = s*F + f)."""
+    hmid = drop(ActFn.apply(LinearFn.apply(a, P[pre + "decoder.0.weight"], P[pre + "decoder.0.bias"], ACT_NONE, None, 0),
+                            ACT_GELU), p)
+    logits = LinearFn.apply(hmid, P[pre + "decoder.3.weight"], P[pre + "decoder.3.bias"], ACT_NONE, None, 0)
+    return ActFn.apply(logits, ACT_SIGMOID)
+
+
+def _tensors(module):
+    return dict(module.named_parameters()), dict(module.named_buffers())
+
+
 def train_forward(model, mixed, lips, seed=None, group=None):
-    """Train-mode AVSeparationTransformer.forward (model.py:268-276) with autograd through the HIP ops.
+    """AVSeparationTransformer.forward (model.py:268-276) with autograd through the HIP ops: train-mode semantics
+    (dropout, BatchNorm batch statistics) when ``model.training``, eval semantics otherwise.
     Returns (separated, masks) as (B,S,F,T) views of (B,T,S,F) tensors, like the inference path.
     ``seed``: base seed of this forward's dropout masks (default: drawn from torch's CPU generator).
     ``group``: process group of a data-parallel job (default: ``model._dp_group`` set by ``parallel.DataParallel``):
     BatchNorm statistics then span all ranks and every rank draws different dropout masks."""
     if group is None:
         group = getattr(model, "_dp_group", None)
-    world = 1
-    if group is not None:
-        import torch.distributed as dist
-        world = dist.get_world_size(group)
     pa, pv = model.audio_encoder.dropout_p, model.visual_encoder.dropout_p
     pf, pd = model.fusion.dropout_p, model.decoder.dropout_p
-    if seed is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if max(pa, pv, pf, pd) > 0 else 0
-    if world > 1:
-        import torch.distributed as dist
-        seed = int(seed) + 0x632BE59BD9B4E019 * (dist.get_rank(group) + 1)
-    drop = _Drop(seed)
-    P = dict(model.named_parameters())
-    Bf = dict(model.named_buffers())
+    drop = make_drop(model, (pa, pv, pf, pd), seed, group)
+    P, Bf = _tensors(model)
     B, Fq, T = mixed.shape
-    _, N, H, W = lips.shape
     d, h, S = model.d_model, model.nhead, model.num_speakers
-    dev = mixed.device
-    lib = _lib()
-    Fp = _up32(Fq)
-    M = B * T
-
-    # ---- audio encoder (model.py:54-60)
-    xt = torch.empty(M, Fp, device=dev)
-    _ck(lib.avsep_op_transpose_pad(mixed.data_ptr(), xt.data_ptr(), B, Fq, T, Fp, _st(mixed)), "transpose_pad")
-    col = Im2col1dFn.apply(xt, T)                                                     # [M, 3*Fp]
-    w1 = F.pad(P["audio_encoder.input_proj.0.weight"].permute(0, 2, 1), (0, Fp - Fq)).reshape(d, 3 * Fp)
-    hcur = LinearFn.apply(col, w1, P["audio_encoder.input_proj.0.bias"], ACT_RELU, None, 0)
-    w2 = P["audio_encoder.input_proj.2.weight"].permute(0, 2, 1).reshape(d, 3 * d)
-    pe_a = _c(Bf["audio_encoder.pos_enc.pe"][0, :T])
-    a = LinearFn.apply(Im2col1dFn.apply(hcur, T), w2, P["audio_encoder.input_proj.2.bias"], ACT_RELU, None, 0)
-    a = drop(AddRowsFn.apply(a, pe_a, T), pa)
-    for i in range(_count(P, "audio_encoder.transformer.layers.")):
-        a = _encoder_layer(a, P, f"audio_encoder.transformer.layers.{i}.", B, T, h, pa, drop)
-
-    # ---- visual encoder (model.py:103-117), BatchNorm in training mode
-    Mv = B * N
-    x = _c(lips).reshape(Mv * H * W, 1)
-    hh, ww, cin = H, W, 1
-    for conv_i, bn_i, cout in ((0, 1, 32), (3, 4, 64), (6, 7, 128)):
-        cw = P[f"visual_encoder.conv.{conv_i}.weight"].permute(0, 2, 3, 1).reshape(cout, 9 * cin)   # [Co, tap*Ci + ci]
-        Kp = _up32(9 * cin)
-        if Kp != 9 * cin:
-            cw = F.pad(cw, (0, Kp - 9 * cin))
-        colv = Im2col2dFn.apply(x, Mv, hh, ww, Kp)
-        y = LinearFn.apply(colv, cw, P[f"visual_encoder.conv.{conv_i}.bias"], ACT_NONE, None, 0)
-        bn = f"visual_encoder.conv.{bn_i}."
-        if world > 1:
-            x = SyncBatchNormReluFn.apply(y, P[bn + "weight"], P[bn + "bias"], Bf[bn + "running_mean"],
-                                          Bf[bn + "running_var"], 1e-5, 0.1, group)
-        else:
-            x = BatchNormReluFn.apply(y, P[bn + "weight"], P[bn + "bias"], Bf[bn + "running_mean"],
-                                      Bf[bn + "running_var"], 1e-5, 0.1)
-        Bf[bn + "num_batches_tracked"].add_(1)
-        hh, ww, cin = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1, cout
-    pooled = AvgPoolFn.apply(x, Mv, hh * ww)
-    pe_v = _c(Bf["visual_encoder.pos_enc.pe"][0, :N])
-    v = drop(LinearFn.apply(pooled, P["visual_encoder.frame_proj.weight"], P["visual_encoder.frame_proj.bias"], ACT_NONE,
-                            pe_v, N), pv)
-    for i in range(_count(P, "visual_encoder.transformer.layers.")):
-        v = _encoder_layer(v, P, f"visual_encoder.transformer.layers.{i}.", B, N, h, pv, drop)
-    v = InterpFn.apply(v, B, N, T)
-
-    # ---- cross-modal fusion (model.py:145-173): visual is not normalised and feeds every layer
-    dh = d // h
-    for i in range(_count(P, "fusion.layers.")):
-        p = f"fusion.layers.{i}."
-        win, bin_ = P[p + "cross_attn.in_proj_weight"], P[p + "cross_attn.in_proj_bias"]
-        n = LayerNormFn.apply(a, P[p + "norm1.weight"], P[p + "norm1.bias"], 1e-5)
-        q = LinearFn.apply(n, win[:d], bin_[:d], ACT_NONE, None, 0)
-        kv = LinearFn.apply(v, win[d:], bin_[d:], ACT_NONE, None, 0)
-        o = AttentionFn.apply(q, kv, 0, 0, d, B, h, dh, T, T, 1.0 / math.sqrt(dh), pf, drop.seed() if pf > 0 else 0)
-        a = _residual_linear(a, o, P[p + "cross_attn.out_proj.weight"], P[p + "cross_attn.out_proj.bias"], pf, drop)
-        n = LayerNormFn.apply(a, P[p + "norm2.weight"], P[p + "norm2.bias"], 1e-5)
-        f = drop(ActFn.apply(LinearFn.apply(n, P[p + "ff.0.weight"], P[p + "ff.0.bias"], ACT_NONE, None, 0), ACT_GELU), pf)
-        a = _residual_linear(a, f, P[p + "ff.3.weight"], P[p + "ff.3.bias"], pf, drop)
-    a = LayerNormFn.apply(a, P["fusion.norm.weight"], P["fusion.norm.bias"], 1e-5)
-
-    # ---- decoder (model.py:201-220)
-    hmid = drop(ActFn.apply(LinearFn.apply(a, P["decoder.decoder.0.weight"], P["decoder.decoder.0.bias"], ACT_NONE, None, 0),
-                            ACT_GELU), pd)
-    logits = LinearFn.apply(hmid, P["decoder.decoder.3.weight"], P["decoder.decoder.3.bias"], ACT_NONE, None, 0)
-    masks = ActFn.apply(logits, ACT_SIGMOID)                                           # [M, S*F]
+    xt = _rows_of_mixed(mixed, _up32(Fq))
+    a = audio_stage(P, Bf, "audio_encoder.", xt, B, T, Fq, d, h, pa, drop)
+    v = visual_stage(P, Bf, "visual_encoder.", lips, T, d, h, pv, drop, model.training, group)
+    a = fusion_stage(P, "fusion.", a, v, B, T, d, h, pf, drop)
+    masks = decoder_stage(P, "decoder.", a, pd, drop)                                  # [M, S*F]
     sep = MulMixedFn.apply(masks, xt, S, Fq)
     return sep.view(B, T, S, Fq).permute(0, 2, 3, 1), masks.view(B, T, S, Fq).permute(0, 2, 3, 1)
+
+
+# ---- the stand-alone stage modules (the reference's tests and users call them directly, in train mode by default)
+def audio_encoder_forward(mod, x, seed=None):
+    P, Bf = _tensors(mod)
+    B, Fq, T = x.shape
+    drop = make_drop(mod, (mod.dropout_p,), seed)
+    a = audio_stage(P, Bf, "", _rows_of_mixed(x, _up32(Fq)), B, T, Fq, mod.d_model, mod.nhead, mod.dropout_p, drop)
+    return a.view(B, T, mod.d_model)
+
+
+def visual_encoder_forward(mod, frames, T, seed=None):
+    P, Bf = _tensors(mod)
+    drop = make_drop(mod, (mod.dropout_p,), seed)
+    v = visual_stage(P, Bf, "", frames, T, mod.d_model, mod.nhead, mod.dropout_p, drop, mod.training)
+    return v.view(frames.shape[0], T, mod.d_model)
+
+
+def fusion_forward(mod, audio, visual, seed=None):
+    P, _ = _tensors(mod)
+    B, T, d = audio.shape
+    drop = make_drop(mod, (mod.dropout_p,), seed)
+    out = fusion_stage(P, "", _c(audio).reshape(B * T, d), _c(visual).reshape(B * T, d), B, T, d, mod.nhead,
+                       mod.dropout_p, drop)
+    return out.view(B, T, d)
+
+
+def decoder_forward(mod, fused, seed=None):
+    P, _ = _tensors(mod)
+    B, T, d = fused.shape
+    drop = make_drop(mod, (mod.dropout_p,), seed)
+    masks = decoder_stage(P, "", _c(fused).reshape(B * T, d), mod.dropout_p, drop)
+    return masks.view(B, T, mod.num_speakers, mod.freq_bins).permute(0, 2, 3, 1)

@@ -18,8 +18,8 @@ for Conv/Linear, xavier-uniform for MultiheadAttention.in_proj_weight, zeros for
 
 Training: ``AVSeparationTransformer.forward`` in ``.train()`` mode runs the op-by-op
 HIP training path of ``_train.py`` (autograd wrappers whose forward and backward are HIP kernels, BatchNorm batch
-statistics, stateless-mask dropout).  The stand-alone stage modules are inference-only and raise in
-train mode instead of silently running eval semantics.
+statistics, stateless-mask dropout); the stand-alone stage modules do the same for their stage, and an eval-mode
+module called while autograd is recording takes the same differentiable path with eval semantics.
 """
 from __future__ import annotations
 
@@ -250,25 +250,34 @@ def _prep(x: torch.Tensor, what: str, ndim: int) -> torch.Tensor:
         raise RuntimeError(
             f"{what} is on {x.device}: the MI355X path needs tensors and module on a ROCm device "
             "(`.to('cuda')`); there is no CPU fallback in this package")
-    x = x.detach()
     if x.dtype != torch.float32:
         x = x.float()
-    return x.contiguous()
+    return x.contiguous()             # both differentiable: an input that requires grad keeps its graph
 
 
 _warned_grad = False
 
 
-def _guard_mode(module: nn.Module):
+def _wants_autograd(module: nn.Module, *inputs) -> bool:
+    """The reference's modules are plain torch.nn: in train mode they apply dropout and BatchNorm batch statistics,
+    and whenever autograd is recording they build a graph (tests/test_model.py:90-97, 116-122, 210-217 backprop
+    through freshly constructed modules).  Mirror that: the op-by-op HIP autograd path (``_train.py``) runs when the
+    module is in train mode, or when grad mode is on and a parameter or an input requires grad; the fused inference
+    path (one C-ABI call, hipGraph-able) runs otherwise -- i.e. under ``torch.no_grad()`` as demo.py:42 does."""
     global _warned_grad
     if module.training:
-        raise NotImplementedError(
-            "the stand-alone stage modules are inference-only on the HIP path; train through "
-            "AVSeparationTransformer.forward (SURVEY.md §8(f) N1) or call .eval()")
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()) and not _warned_grad:
-        _warned_grad = True
-        warnings.warn("av_separation (MI355X): outputs of the HIP forward carry no autograd graph; "
-                      "wrap inference in torch.no_grad()", stacklevel=3)
+        return True
+    if not torch.is_grad_enabled():
+        return False
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs) or \
+            any(p.requires_grad for p in module.parameters()):
+        if not _warned_grad:
+            _warned_grad = True
+            warnings.warn("av_separation (MI355X): autograd is recording, so this eval-mode call runs the op-by-op "
+                          "differentiable path; wrap inference in torch.no_grad() for the fused forward",
+                          stacklevel=3)
+        return True
+    return False
 
 
 def _stream(device):
@@ -306,13 +315,15 @@ class AudioEncoder(nn.Module):
         self._engine = _Engine(self, "audio_encoder.", freq_bins, d_model, nhead, num_layers, 0, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _guard_mode(self)
         x = _prep(x, "mixed_spec", 3)
         B, F, T = x.shape
         if F != self.freq_bins:
             raise RuntimeError(f"expected input with {self.freq_bins} channels (freq_bins), got {F}")
         if T > _MAX_LEN:
             raise RuntimeError(f"sequence length {T} exceeds PositionalEncoding max_len {_MAX_LEN}")
+        if _wants_autograd(self, x):
+            from ._train import audio_encoder_forward
+            return audio_encoder_forward(self, x)
         eng, dev = self._engine, x.device
         with torch.cuda.device(dev):
             st = _stream(dev)
@@ -335,12 +346,16 @@ class VisualEncoder(nn.Module):
         self._engine = _Engine(self, "visual_encoder.", 1, d_model, nhead, num_layers, 0, 1)
 
     def forward(self, frames: torch.Tensor, target_len: int) -> torch.Tensor:
-        _guard_mode(self)
         frames = _prep(frames, "lip_frames", 4)
         B, N, H, W = frames.shape
         T = int(target_len)
         if T <= 0:
             raise RuntimeError("target_len must be positive")
+        if N > _MAX_LEN:
+            raise RuntimeError(f"sequence length {N} exceeds PositionalEncoding max_len {_MAX_LEN}")
+        if _wants_autograd(self, frames):
+            from ._train import visual_encoder_forward
+            return visual_encoder_forward(self, frames, T)
         eng, dev = self._engine, frames.device
         with torch.cuda.device(dev):
             st = _stream(dev)
@@ -364,11 +379,13 @@ class CrossModalFusion(nn.Module):
         self._engine = _Engine(self, "fusion.", 1, d_model, nhead, 0, num_layers, 1)
 
     def forward(self, audio: torch.Tensor, visual: torch.Tensor) -> torch.Tensor:
-        _guard_mode(self)
         audio = _prep(audio, "audio", 3)
         visual = _prep(visual, "visual", 3)
         if audio.shape != visual.shape or audio.shape[2] != self.d_model:
             raise RuntimeError(f"audio {tuple(audio.shape)} / visual {tuple(visual.shape)} must both be (B,T,{self.d_model})")
+        if _wants_autograd(self, audio, visual):
+            from ._train import fusion_forward
+            return fusion_forward(self, audio, visual)
         B, T, _ = audio.shape
         eng, dev = self._engine, audio.device
         with torch.cuda.device(dev):
@@ -393,11 +410,13 @@ class SeparationDecoder(nn.Module):
         self._engine = _Engine(self, "decoder.", freq_bins, d_model, max(1, d_model // 32), 0, 0, num_speakers)
 
     def forward(self, fused: torch.Tensor) -> torch.Tensor:
-        _guard_mode(self)
         fused = _prep(fused, "fused", 3)
         B, T, d = fused.shape
         if d != self.d_model:
             raise RuntimeError(f"expected last dim {self.d_model}, got {d}")
+        if _wants_autograd(self, fused):
+            from ._train import decoder_forward
+            return decoder_forward(self, fused)
         eng, dev = self._engine, fused.device
         with torch.cuda.device(dev):
             st = _stream(dev)
@@ -488,19 +507,6 @@ class AVSeparationTransformer(nn.Module):
         return json.loads(buf.value.decode())
 
     def forward(self, mixed_spec: torch.Tensor, lip_frames: torch.Tensor):
-        if self.training:
-            # training path: same HIP library, op by op under autograd (av_separation/_train.py)
-            from ._train import train_forward
-            mixed = _prep(mixed_spec, "mixed_spec", 3)
-            lips = _prep(lip_frames, "lip_frames", 4)
-            if mixed.shape[1] != self.freq_bins:
-                raise RuntimeError(f"expected input with {self.freq_bins} channels (freq_bins), got {mixed.shape[1]}")
-            if lips.shape[0] != mixed.shape[0]:
-                raise RuntimeError(f"batch mismatch: mixed_spec {mixed.shape[0]}, lip_frames {lips.shape[0]}")
-            if mixed.shape[2] > _MAX_LEN or lips.shape[1] > _MAX_LEN:
-                raise RuntimeError(f"sequence length exceeds PositionalEncoding max_len {_MAX_LEN}")
-            return train_forward(self, mixed, lips)
-        _guard_mode(self)
         mixed = _prep(mixed_spec, "mixed_spec", 3)
         lips = _prep(lip_frames, "lip_frames", 4)
         B, F, T = mixed.shape
@@ -510,6 +516,10 @@ class AVSeparationTransformer(nn.Module):
             raise RuntimeError(f"batch mismatch: mixed_spec {B}, lip_frames {lips.shape[0]}")
         if T > _MAX_LEN or lips.shape[1] > _MAX_LEN:
             raise RuntimeError(f"sequence length exceeds PositionalEncoding max_len {_MAX_LEN}")
+        if _wants_autograd(self, mixed, lips) and (self.training or not self._engine.taps):
+            # training / autograd path: same HIP library, op by op (av_separation/_train.py)
+            from ._train import train_forward
+            return train_forward(self, mixed, lips)
         S, dev = self.num_speakers, mixed.device
         eng = self._engine
         if self._graph and not eng.taps:

@@ -157,8 +157,8 @@ def test_error_behaviour_on_device(dev):
         m(torch.zeros(1, 65, 5001, device=dev), torch.zeros(1, 4, 16, 16, device=dev))
     with pytest.raises(RuntimeError):
         m(torch.zeros(2, 65, 32, device=dev), torch.zeros(3, 10, 16, 16, device=dev))
-    with pytest.raises(NotImplementedError):          # stage modules are inference-only
-        m.train().audio_encoder(torch.zeros(2, 65, 32, device=dev))
+    out = m.train().audio_encoder(torch.zeros(2, 65, 32, device=dev))   # stages train too (tests/test_reference_suite_gpu.py)
+    assert out.requires_grad and out.shape == (2, 32, 64)
 
 
 # ------------------------------------------------------------------------------------------ stage modules

@@ -117,7 +117,7 @@ def test_train_mode_never_fakes_eval_semantics():
     m = AVSeparationTransformer(freq_bins=65, d_model=64).train()
     with pytest.raises(RuntimeError, match="no CPU fallback"):      # the training path is HIP-only as well
         m(torch.zeros(2, 65, 32), torch.zeros(2, 10, 16, 16))
-    with pytest.raises(NotImplementedError):                         # stage modules are inference-only
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # ... and so are the stand-alone stages
         m.audio_encoder(torch.zeros(2, 65, 32))
 
 
