@@ -313,11 +313,52 @@ def train_main(a, av, dev, dist, rank, world):
                      "traffic": None},
         "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
     }
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_train_baseline(model, mixed, lips, targets, mk, B, a.dropout, a.cpu_seconds)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def cpu_train_baseline(model, mixed, lips, targets, mk, B, dropout, budget_s):
+    """The reference's training step on this box's host cores through oracle/torch_cpu.forward_train (pinned against
+    the reference's gradients in tests/test_oracle.py): forward + SeparationLoss + backward + clip + Adam, same batch."""
+    from oracle import torch_cpu
+    from av_separation.losses import SeparationLoss
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    params = []
+    for k, t in state.items():
+        if t.is_floating_point() and "running_" not in k and not k.endswith(".pe"):
+            t.requires_grad_()
+            params.append(t)
+    opt = torch.optim.Adam(params, lr=3e-4)
+    crit = SeparationLoss(0.5)
+    mx, lp, tg = mixed.cpu(), lips.cpu(), targets.cpu()
+    avail = torch.get_num_threads()
+    threads = min(avail, 32)                       # the forward baseline's sweep lands on 16-32 threads on this host
+    torch.set_num_threads(threads)
+
+    def step():
+        opt.zero_grad()
+        sep, _ = torch_cpu.forward_train(state, mx, lp, mk["nhead"], mk["num_speakers"], dropout)
+        loss = crit(sep, tg)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+
+    times = []
+    t_end = time.perf_counter() + max(budget_s, 1.0) * 2.5
+    while len(times) < 3 and (not times or time.perf_counter() < t_end):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    torch.set_num_threads(avail)
+    best = min(times)
+    return {"value": round(B / best, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} training steps of the same {B}-clip batch, best {best:.2f} s "
+                      f"(torch {torch.__version__} CPU autograd, fp32, dropout {dropout})"}
 
 
 def si_snr_improvement(separated, mixed, clean):

@@ -9,6 +9,12 @@ _transformer_encoder_layer_fwd (the eval fast path of nn.TransformerEncoderLayer
 nn/modules/transformer.py:842-921), the explicit bmm/softmax/bmm cross-attention of
 F.multi_head_attention_forward with need_weights=True (torch nn/functional.py:6576-6594), exact-erf GELU,
 upsample_linear1d, sigmoid.  Pinned against tests/golden/ in tests/test_oracle.py.
+
+`forward_train` is the same restatement with autograd recording and TRAIN-mode semantics (BatchNorm batch statistics
+with the running-stat update, dropout at the reference's sites: PositionalEncoding model.py:301, the encoder layers'
+attention/dropout1/dropout/dropout2, fusion 159/164 + attention dropout 155, decoder 197); pinned against the
+reference's own gradients (tests/golden/train_*.npz) in tests/test_oracle.py and timed as the CPU baseline of
+`bench.py --mode train`.
 """
 from __future__ import annotations
 
@@ -33,9 +39,9 @@ def _count(state, prefix):
     return n
 
 
-def _encoder_layer(x, W, p, nhead, fast):
-    """pre-norm TransformerEncoderLayer, relu, ff=4d  (model.py:48-52)."""
-    if fast and hasattr(torch, "_transformer_encoder_layer_fwd") and x.dtype == torch.float32:
+def _encoder_layer(x, W, p, nhead, fast, drop=0.0):
+    """pre-norm TransformerEncoderLayer, relu, ff=4d  (model.py:48-52); `drop` > 0 = train-mode dropout."""
+    if fast and drop == 0.0 and not torch.is_grad_enabled() and hasattr(torch, "_transformer_encoder_layer_fwd") and x.dtype == torch.float32:
         return torch._transformer_encoder_layer_fwd(
             x, x.shape[-1], nhead, W[p + "self_attn.in_proj_weight"], W[p + "self_attn.in_proj_bias"],
             W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"], False, True, 1e-5,
@@ -45,14 +51,14 @@ def _encoder_layer(x, W, p, nhead, fast):
     d = x.shape[-1]
     n = F.layer_norm(x, (d,), W[p + "norm1.weight"], W[p + "norm1.bias"], 1e-5)
     a = _mha(n, n, W[p + "self_attn.in_proj_weight"], W[p + "self_attn.in_proj_bias"],
-             W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"], nhead)
-    x = x + a
+             W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"], nhead, drop)
+    x = x + F.dropout(a, drop, drop > 0)
     n = F.layer_norm(x, (d,), W[p + "norm2.weight"], W[p + "norm2.bias"], 1e-5)
-    return x + F.linear(F.relu(F.linear(n, W[p + "linear1.weight"], W[p + "linear1.bias"])),
-                        W[p + "linear2.weight"], W[p + "linear2.bias"])
+    f = F.dropout(F.relu(F.linear(n, W[p + "linear1.weight"], W[p + "linear1.bias"])), drop, drop > 0)
+    return x + F.dropout(F.linear(f, W[p + "linear2.weight"], W[p + "linear2.bias"]), drop, drop > 0)
 
 
-def _mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead):
+def _mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead, drop=0.0):
     B, Lq, d = q_in.shape
     Lk = kv_in.shape[1]
     dh = d // nhead
@@ -62,51 +68,64 @@ def _mha(q_in, kv_in, w_in, b_in, w_out, b_out, nhead):
     q = q.view(B, Lq, nhead, dh).transpose(1, 2).reshape(B * nhead, Lq, dh)
     k = k.view(B, Lk, nhead, dh).transpose(1, 2).reshape(B * nhead, Lk, dh)
     v = v.view(B, Lk, nhead, dh).transpose(1, 2).reshape(B * nhead, Lk, dh)
-    p = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
+    p = F.dropout(torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1), drop, drop > 0)
     o = torch.bmm(p, v).view(B, nhead, Lq, dh).transpose(1, 2).reshape(B, Lq, d)
     return F.linear(o, w_out, b_out)
 
 
 @torch.no_grad()
 def forward(state, mixed, lips, nhead, num_speakers, fast=True):
-    """(separated, masks), logical (B,S,F,T) like AVSeparationTransformer.forward (model.py:268-276).
+    """(separated, masks), logical (B,S,F,T) like AVSeparationTransformer.forward (model.py:268-276) in eval mode.
     `state`: reference state_dict (torch tensors or numpy arrays); pe buffers optional."""
     W = state if all(isinstance(v, torch.Tensor) for v in state.values()) else _to_torch(state, mixed.dtype)
+    return _forward(W, mixed, lips, nhead, num_speakers, fast, False, 0.0)
+
+
+def forward_train(state, mixed, lips, nhead, num_speakers, dropout=0.0):
+    """Train-mode forward with autograd recording: `state` must hold torch tensors (parameters with requires_grad as
+    the caller wishes; BatchNorm running statistics are updated in place, num_batches_tracked incremented)."""
+    return _forward(state, mixed, lips, nhead, num_speakers, False, True, float(dropout))
+
+
+def _forward(W, mixed, lips, nhead, num_speakers, fast, train, drop):
     B, Fq, T = mixed.shape
     # ---- AudioEncoder (model.py:54-60)
     h = F.relu(F.conv1d(mixed, W["audio_encoder.input_proj.0.weight"], W["audio_encoder.input_proj.0.bias"], padding=1))
     h = F.relu(F.conv1d(h, W["audio_encoder.input_proj.2.weight"], W["audio_encoder.input_proj.2.bias"], padding=1))
     a = h.permute(0, 2, 1)
     d = a.shape[-1]
-    a = a + _pe(W, "audio_encoder.pos_enc.pe", T, d, a.dtype)
+    a = F.dropout(a + _pe(W, "audio_encoder.pos_enc.pe", T, d, a.dtype), drop, drop > 0)
     for i in range(_count(W, "audio_encoder.transformer.layers.")):
-        a = _encoder_layer(a, W, f"audio_encoder.transformer.layers.{i}.", nhead, fast)
+        a = _encoder_layer(a, W, f"audio_encoder.transformer.layers.{i}.", nhead, fast, drop)
     # ---- VisualEncoder (model.py:103-117)
     _, N, H, Wd = lips.shape
     x = lips.reshape(B * N, 1, H, Wd)
     for ci, bi in ((0, 1), (3, 4), (6, 7)):
         c, b = f"visual_encoder.conv.{ci}.", f"visual_encoder.conv.{bi}."
         x = F.conv2d(x, W[c + "weight"], W[c + "bias"], stride=2, padding=1)
-        x = F.batch_norm(x, W[b + "running_mean"], W[b + "running_var"], W[b + "weight"], W[b + "bias"], False, 0.1, 1e-5)
+        x = F.batch_norm(x, W[b + "running_mean"], W[b + "running_var"], W[b + "weight"], W[b + "bias"], train, 0.1, 1e-5)
+        if train and b + "num_batches_tracked" in W:
+            W[b + "num_batches_tracked"] += 1
         x = F.relu(x)
     v = F.adaptive_avg_pool2d(x, 1).flatten(1)
     v = F.linear(v, W["visual_encoder.frame_proj.weight"], W["visual_encoder.frame_proj.bias"]).view(B, N, d)
-    v = v + _pe(W, "visual_encoder.pos_enc.pe", N, d, v.dtype)
+    v = F.dropout(v + _pe(W, "visual_encoder.pos_enc.pe", N, d, v.dtype), drop, drop > 0)
     for i in range(_count(W, "visual_encoder.transformer.layers.")):
-        v = _encoder_layer(v, W, f"visual_encoder.transformer.layers.{i}.", nhead, fast)
+        v = _encoder_layer(v, W, f"visual_encoder.transformer.layers.{i}.", nhead, fast, drop)
     v = F.interpolate(v.permute(0, 2, 1), size=T, mode="linear", align_corners=False).permute(0, 2, 1)
     # ---- CrossModalFusion (model.py:145-173)
     for i in range(_count(W, "fusion.layers.")):
         p = f"fusion.layers.{i}."
         n = F.layer_norm(a, (d,), W[p + "norm1.weight"], W[p + "norm1.bias"], 1e-5)
-        a = a + _mha(n, v, W[p + "cross_attn.in_proj_weight"], W[p + "cross_attn.in_proj_bias"],
-                     W[p + "cross_attn.out_proj.weight"], W[p + "cross_attn.out_proj.bias"], nhead)
+        a = a + F.dropout(_mha(n, v, W[p + "cross_attn.in_proj_weight"], W[p + "cross_attn.in_proj_bias"],
+                               W[p + "cross_attn.out_proj.weight"], W[p + "cross_attn.out_proj.bias"], nhead, drop),
+                          drop, drop > 0)
         n = F.layer_norm(a, (d,), W[p + "norm2.weight"], W[p + "norm2.bias"], 1e-5)
-        a = a + F.linear(F.gelu(F.linear(n, W[p + "ff.0.weight"], W[p + "ff.0.bias"])),
-                         W[p + "ff.3.weight"], W[p + "ff.3.bias"])
+        f = F.dropout(F.gelu(F.linear(n, W[p + "ff.0.weight"], W[p + "ff.0.bias"])), drop, drop > 0)
+        a = a + F.dropout(F.linear(f, W[p + "ff.3.weight"], W[p + "ff.3.bias"]), drop, drop > 0)
     a = F.layer_norm(a, (d,), W["fusion.norm.weight"], W["fusion.norm.bias"], 1e-5)
     # ---- SeparationDecoder (model.py:201-220)
-    z = F.linear(F.gelu(F.linear(a, W["decoder.decoder.0.weight"], W["decoder.decoder.0.bias"])),
+    z = F.linear(F.dropout(F.gelu(F.linear(a, W["decoder.decoder.0.weight"], W["decoder.decoder.0.bias"])), drop, drop > 0),
                  W["decoder.decoder.3.weight"], W["decoder.decoder.3.bias"])
     masks = torch.sigmoid(z.view(B, T, num_speakers, Fq).permute(0, 2, 3, 1))
     return masks * mixed.unsqueeze(1), masks

@@ -2,6 +2,9 @@
 (tests/golden/make_golden.py).  Tolerances: the reference's own fp32 noise floor is ~2e-7 on masks
 (SURVEY.md §8(c)); the oracle must sit within 2e-6 of the fp32 goldens and 1e-6 of the fp64 goldens
 (float64 mode), far inside the 1e-4 hard gate of BASELINE.json."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -95,3 +98,62 @@ def test_interp_index_is_fma(N, T):
     want = torch.nn.functional.interpolate(torch.from_numpy(x).permute(0, 2, 1), size=T, mode="linear",
                                            align_corners=False).permute(0, 2, 1).numpy()
     assert maxabs(onp.interp_linear(x, T), want) < 5e-7
+
+
+@pytest.mark.parametrize("name", ["train_tiny", "train_odd"])
+def test_torch_cpu_train_port_matches_reference_gradients(golden, name):
+    """oracle/torch_cpu.forward_train (the CPU baseline of `bench.py --mode train`) against the reference's own
+    train-mode forward/backward: loss, outputs, every parameter gradient, updated BatchNorm buffers."""
+    import json
+    import torch
+    from oracle import seeded, torch_cpu
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "av-separation-transformer_amd"))
+    from av_separation.losses import SeparationLoss
+    g = golden(name)
+    c = g["config"]
+    shapes = seeded.model_shapes(c["F"], c["d"], c["h"], c["Le"], c["Lf"], c["S"])
+    state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in
+             seeded.fill_state(shapes, c["seed"], gain=float(g["gain"])).items()}
+    for k, t in state.items():
+        if t.is_floating_point() and "running_" not in k and not k.endswith(".pe"):
+            t.requires_grad_()
+    mx, lp = seeded.inputs(c["seed"], c["B"], c["F"], c["T"], c["N"], c["H"], c["W"])
+    sep, masks = torch_cpu.forward_train(state, torch.from_numpy(mx), torch.from_numpy(lp), c["h"], c["S"])
+    loss = SeparationLoss(0.5)(sep, torch.from_numpy(g["targets"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    assert maxabs(masks.detach().numpy(), g["masks"]) < 1e-6
+    for k, t in state.items():
+        if t.requires_grad:
+            got = t.grad.numpy()
+            if "g." + k in g:
+                ref = g["g." + k]
+                assert maxabs(got, ref) < 1e-5 * max(1e-3, float(np.abs(ref).max())) + 1e-7, k
+            else:
+                ref = g["g." + k + ".slice"]
+                assert maxabs(got.reshape(-1)[::5], ref) < 1e-5 * max(1e-3, float(np.abs(ref).max())) + 1e-7, k
+        elif "running_" in k:
+            assert maxabs(t.numpy(), g["buf." + k]) < 1e-6, k
+
+
+@pytest.mark.parametrize("name", FULL + ["fwd_cfg1"])
+def test_torch_cpu_port_matches_reference_outputs(golden, name):
+    """oracle/torch_cpu.forward (bench.py's cpu_baseline, kind "port") reproduces the reference's eval forward: it
+    issues the same ATen kernels, so it sits at the reference's own noise floor."""
+    import torch
+    from oracle import torch_cpu
+    g = golden(name)
+    c = g["config"]
+    state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in golden_state(g).items()}
+    mixed, lips = golden_inputs(g)
+    for fast in (True, False):
+        sep, masks = torch_cpu.forward(state, torch.from_numpy(mixed), torch.from_numpy(lips), c["h"], c["S"], fast=fast)
+        sep, masks = sep.contiguous().numpy(), masks.contiguous().numpy()
+        scale = max(1.0, float(np.abs(mixed).max()))
+        if "masks" in g:
+            assert maxabs(masks, g["masks"]) < 2e-6, (name, fast)
+            assert maxabs(sep, g["separated"]) < 2e-6 * scale, (name, fast)
+        else:
+            assert maxabs(sliced(masks, 7), g["masks.slice"]) < 2e-6, (name, fast)
+            assert maxabs(sliced(sep, 7), g["separated.slice"]) < 2e-6 * scale, (name, fast)
