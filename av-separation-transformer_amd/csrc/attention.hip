@@ -36,7 +36,10 @@ __device__ __forceinline__ float exp_neg(float x) {
 
 // NB = ceil(dh / 16).  REG = (dh == 16*NB): the fast path with unpredicated vector loads; otherwise the head
 // is zero-extended to 16*NB (k >= dh contributes 0 to S, rows dv >= dh of O^T are never stored).
-template <int NB, bool REG>
+// QT = 16-query tiles per wave.  With QT = 2 every K / V fragment fetched from L2 feeds two score tiles and two
+// output tiles (half the L1/L2 traffic per flop: at Lk = 501 a wave streams 256 KB of K and V) and the two score
+// accumulators interleave, hiding the 40-cycle dependent latency of back-to-back MFMAs on one accumulator.
+template <int NB, bool REG, int QT>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int ldq,
                                                         const float* __restrict__ k, int ldk,
                                                         const float* __restrict__ v, int ldv,
@@ -48,10 +51,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const int wave = threadIdx.x >> 6;
   const int c = lane & 15;    // query column (as B operand / C column); key row (as A operand of S^T)
   const int g = lane >> 4;    // k-quarter of the MFMA
-  const int wg_per_head = (nqt + 3) >> 2;
+  const int nqw = (nqt + QT - 1) / QT;          // wave-units (QT tiles each) per head
+  const int wg_per_head = (nqw + 3) >> 2;
   const int bh = blockIdx.x / wg_per_head;
-  const int qt = (blockIdx.x - bh * wg_per_head) * 4 + wave;
-  if (qt >= nqt) return;      // no barriers in this kernel: a wave may leave early
+  const int qw = (blockIdx.x - bh * wg_per_head) * 4 + wave;
+  if (qw >= nqw) return;      // no barriers in this kernel: a wave may leave early
   const int b = bh / nhead, h = bh - b * nhead;
 
   const float* qb = q + (size_t)b * Lq * ldq + h * DH;
@@ -60,17 +64,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   float* ob = o + (size_t)b * Lq * ldo + h * DH;
 
   // Q^T fragments: lane (c,g) holds Q[q0+c][16s+4g .. +3], s < NB   (k-permuted, same as K below)
-  const int qrow = min(qt * 16 + c, Lq - 1);
-  f32x4 qf[NB];
+  f32x4 qf[QT][NB];
 #pragma unroll
-  for (int s = 0; s < NB; ++s)
-    qf[s] = ((REG || 16 * s + 4 * g < DH) ? *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g)
-                                          : f32x4{0.f, 0.f, 0.f, 0.f}) * qscale;
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = min((qw * QT + t) * 16 + c, Lq - 1);
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+      qf[t][s] = ((REG || 16 * s + 4 * g < DH) ? *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f}) * qscale;
+  }
 
-  f32x4 acc[NB];
+  f32x4 acc[QT][NB];
+  float mrun[QT], lrun[QT];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float mrun = -INFINITY, lrun = 0.0f;
+  for (int t = 0; t < QT; ++t) {
+    mrun[t] = -INFINITY;
+    lrun[t] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int nkt = (Lk + 15) >> 4;
   // software prefetch of the next key tile's K and V fragments
@@ -116,73 +128,88 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
       for (int e = 0; e < NB; ++e) vc[r][e] = vf[r][e];
     if (kt + 1 < nkt) load_tile(kt + 1);
 
-    // S^T tile: 16 keys x 16 queries, contraction over dh
-    f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+    // S^T tiles: 16 keys x 16 queries each, contraction over dh; the QT accumulators interleave
+    f32x4 st[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NB; ++s)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[s][j], qf[s][j], st, 0, 0, 0);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[s][j], qf[t][s][j], st[t], 0, 0, 0);
 
-    // mask keys beyond Lk, online softmax over this tile's 16 keys of query c
-    float tmax = -INFINITY;
+    float pr[QT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kt * 16 + 4 * g + r;
-      st[r] = key < Lk ? st[r] : -INFINITY;
-      tmax = fmaxf(tmax, st[r]);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float mnew = fmaxf(mrun, tmax);          // finite: tile 0 always holds key 0
-    const float alpha = exp_neg(mrun - mnew);       // 0 on the first tile (mrun = -inf)
-    float psum = 0.0f;
-    float pr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pr[r] = exp_neg(st[r] - mnew);
-      psum += pr[r];
-    }
-    lrun = lrun * alpha + psum;                    // per-lane partial (own 4 keys per tile); reduced at the end
-    mrun = mnew;
-    if (drop_p > 0.0f) {   // training: dropout on the attention probabilities (nn.MultiheadAttention dropout=p);
-                           // the normaliser keeps the undropped sum, kept entries are scaled by 1/(1-p)
-      const float keep_scale = 1.0f / (1.0f - drop_p);
+    for (int t = 0; t < QT; ++t) {
+      // mask keys beyond Lk, online softmax over this tile's 16 keys of query c
+      float tmax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const unsigned long long e = ((unsigned long long)bh * Lq + (qt * 16 + c)) * Lk + (kt * 16 + 4 * g + r);
-        pr[r] = dropout_keep(drop_seed, e, drop_p) ? pr[r] * keep_scale : 0.0f;
+        const int key = kt * 16 + 4 * g + r;
+        st[t][r] = key < Lk ? st[t][r] : -INFINITY;
+        tmax = fmaxf(tmax, st[t][r]);
       }
-    }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float mnew = fmaxf(mrun[t], tmax);        // finite: tile 0 always holds key 0
+      const float alpha = exp_neg(mrun[t] - mnew);     // 0 on the first tile (mrun = -inf)
+      float psum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) acc[i] *= alpha;
+      for (int r = 0; r < 4; ++r) {
+        pr[t][r] = exp_neg(st[t][r] - mnew);
+        psum += pr[t][r];
+      }
+      lrun[t] = lrun[t] * alpha + psum;                // per-lane partial (own 4 keys per tile); reduced at the end
+      mrun[t] = mnew;
+      if (drop_p > 0.0f) {   // training: dropout on the attention probabilities (nn.MultiheadAttention dropout=p);
+                             // the normaliser keeps the undropped sum, kept entries are scaled by 1/(1-p)
+        const float keep_scale = 1.0f / (1.0f - drop_p);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned long long e =
+              ((unsigned long long)bh * Lq + ((qw * QT + t) * 16 + c)) * Lk + (kt * 16 + 4 * g + r);
+          pr[t][r] = dropout_keep(drop_seed, e, drop_p) ? pr[t][r] * keep_scale : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) acc[t][i] *= alpha;
+    }
 
     // O^T += V^T P^T : step r contracts keys {4g'+r}, A row i <-> dv = NB*i + blk
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
-        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[r][blk], pr[r], acc[blk], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          acc[t][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[r][blk], pr[t][r], acc[t][blk], 0, 0, 0);
   }
 
-  lrun += __shfl_xor(lrun, 16);
-  lrun += __shfl_xor(lrun, 32);
-  const float inv = 1.0f / lrun;
-  const int qo = qt * 16 + c;
-  if (lse && g == 0 && qo < Lq) lse[(size_t)bh * Lq + qo] = mrun + logf(lrun);   // training: softmax statistics
-  if (qo < Lq) {
-    // lane (c, g) holds O[qo][dv = NB*(4g+reg) + blk]; for a fixed reg the NB blks are contiguous
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float* dst = ob + (size_t)qo * ldo + NB * (4 * g + r);
-      if constexpr (!REG) {
+  for (int t = 0; t < QT; ++t) {
+    float l = lrun[t];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int qo = (qw * QT + t) * 16 + c;
+    if (lse && g == 0 && qo < Lq) lse[(size_t)bh * Lq + qo] = mrun[t] + logf(l);   // training: softmax statistics
+    if (qo < Lq) {
+      // lane (c, g) holds O[qo][dv = NB*(4g+reg) + blk]; for a fixed reg the NB blks are contiguous
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
-          if (NB * (4 * g + r) + blk < DH) dst[blk] = acc[blk][r] * inv;
-      } else if constexpr (NB == 4) {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
-      } else {
+      for (int r = 0; r < 4; ++r) {
+        float* dst = ob + (size_t)qo * ldo + NB * (4 * g + r);
+        if constexpr (!REG) {
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) dst[blk] = acc[blk][r] * inv;
+          for (int blk = 0; blk < NB; ++blk)
+            if (NB * (4 * g + r) + blk < DH) dst[blk] = acc[t][blk][r] * inv;
+        } else if constexpr (NB == 4) {
+          *reinterpret_cast<f32x4*>(dst) =
+              f32x4{acc[t][0][r] * inv, acc[t][1][r] * inv, acc[t][2][r] * inv, acc[t][3][r] * inv};
+        } else {
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk) dst[blk] = acc[t][blk][r] * inv;
+        }
       }
     }
   }
@@ -312,12 +339,22 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
   }
   const int nb = (dh + 15) / 16;
   const bool reg = (dh == 16 * nb);
+  // two query tiles per wave once the sequence is long enough to keep >= 2 workgroups per CU that way
+  static const int qt_env = getenv("AVSEP_ATTN_QT") ? atoi(getenv("AVSEP_ATTN_QT")) : 0;   // developer A/B switch
+  const long wgs2 = (long)B * nhead * (((nqt + 1) / 2 + 3) / 4);
+  const bool two = qt_env ? qt_env == 2 : (reg && nb == 4 && wgs2 >= 512);
 #define AVSEP_ATT(NB_)                                                                                              \
   if (nb == NB_) {                                                                                                  \
-    if (reg) hipLaunchKernelGGL((attention_kernel<NB_, true>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,   \
+    if (reg) hipLaunchKernelGGL((attention_kernel<NB_, true, 1>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, \
                                 nhead, Lq, Lk, nqt, dh, qscale, lse, drop_p, drop_seed);                            \
-    else hipLaunchKernelGGL((attention_kernel<NB_, false>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,      \
+    else hipLaunchKernelGGL((attention_kernel<NB_, false, 1>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,   \
                             nhead, Lq, Lk, nqt, dh, qscale, lse, drop_p, drop_seed);                                \
+  }
+  if (two && reg && nb == 4) {
+    const dim3 grid2((unsigned)wgs2);
+    hipLaunchKernelGGL((attention_kernel<4, true, 2>), grid2, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk,
+                       nqt, dh, qscale, lse, drop_p, drop_seed);
+    return hipGetLastError();
   }
   AVSEP_ATT(1) AVSEP_ATT(2) AVSEP_ATT(3) AVSEP_ATT(4) AVSEP_ATT(5) AVSEP_ATT(6) AVSEP_ATT(7) AVSEP_ATT(8)
 #undef AVSEP_ATT
