@@ -25,6 +25,18 @@ int fail_hip(hipError_t e, const char* what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
   return AVSEP_EHIP;
 }
+// Entry points that touch STL containers are function-try-blocks ending in this: no C++ exception ever crosses the
+// C ABI (the caller may be ctypes / cgo / JNI, where an escaping exception is an abort).
+int on_exception() noexcept {
+  try {
+    try { throw; }
+    catch (const std::bad_alloc&) { return fail(AVSEP_ENOMEM, "host memory allocation failed"); }
+    catch (const std::exception& e) { return fail(AVSEP_EINTERNAL, std::string("internal error: ") + e.what()); }
+    catch (...) { return fail(AVSEP_EINTERNAL, "internal error: unknown C++ exception"); }
+  } catch (...) {
+    return AVSEP_EINTERNAL;   // even recording the message failed
+  }
+}
 #define HCK(x)                                         \
   do {                                                 \
     hipError_t e_ = (x);                               \
@@ -693,7 +705,7 @@ extern "C" {
 int avsep_abi_version(void) { return AVSEP_ABI_VERSION; }
 const char* avsep_last_error(void) { return g_err.c_str(); }
 
-int avsep_create(const avsep_config* cfg, avsep_ctx** out) {
+int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   if (!cfg || !out) return fail(AVSEP_EINVAL, "null argument");
   *out = nullptr;
   if (cfg->freq_bins <= 0 || cfg->d_model <= 0 || cfg->nhead <= 0 || cfg->num_encoder_layers < 0 ||
@@ -741,6 +753,8 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) {
   if (!ok) { avsep_destroy(c); return fail(AVSEP_EHIP, "stream/event creation failed"); }
   *out = c;
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 void avsep_destroy(avsep_ctx* c) {
@@ -766,18 +780,20 @@ void avsep_destroy(avsep_ctx* c) {
   delete c;
 }
 
-int avsep_profile_begin(avsep_ctx* c) {
+int avsep_profile_begin(avsep_ctx* c) try {
   if (!c) return fail(AVSEP_EINVAL, "null context");
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   c->prof.clear();
   c->prof_on = true;
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 // Stops profiling, waits for the recorded events and writes one JSON array, aggregated per kernel name in
 // first-launch order: [{"name":..,"calls":n,"ms":total,"flops":total,"bytes":total}, ...].
 // Returns the number of bytes written (excluding the NUL) or a negative error.
-int64_t avsep_profile_end(avsep_ctx* c, char* json, size_t cap) {
+int64_t avsep_profile_end(avsep_ctx* c, char* json, size_t cap) try {
   if (!c || !json || cap < 3) return fail(AVSEP_EINVAL, "bad argument");
   c->prof_on = false;
   struct Agg { std::string name; long calls; double ms, flops, bytes; };
@@ -808,23 +824,29 @@ int64_t avsep_profile_end(avsep_ctx* c, char* json, size_t cap) {
   if (out.size() + 1 > cap) return fail(AVSEP_ENOMEM, "profile buffer too small");
   memcpy(json, out.c_str(), out.size() + 1);
   return (int64_t)out.size();
+} catch (...) {
+  return on_exception();
 }
 
-int avsep_read_stamps(avsep_ctx* c, uint64_t* out, int n) {
+int avsep_read_stamps(avsep_ctx* c, uint64_t* out, int n) try {
   if (!c || !out || n <= 0) return fail(AVSEP_EINVAL, "bad argument");
   if (!c->stamps) return fail(AVSEP_EINVAL, "stamps are off: set AVSEP_STAMPS=1 before avsep_create()");
   if (n > 16) n = 16;
   HCK(hipMemcpy(out, c->stamps, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return n;
+} catch (...) {
+  return on_exception();
 }
 
-int avsep_set_debug_taps(avsep_ctx* c, int on) {
+int avsep_set_debug_taps(avsep_ctx* c, int on) try {
   if (!c) return fail(AVSEP_EINVAL, "null context");
   c->keep_taps = on != 0;
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
-int avsep_set_weight(avsep_ctx* c, const char* key, const float* dev_ptr, const int64_t* shape, int ndim) {
+int avsep_set_weight(avsep_ctx* c, const char* key, const float* dev_ptr, const int64_t* shape, int ndim) try {
   if (!c || !key || !dev_ptr || ndim < 0 || ndim > 4 || (ndim > 0 && !shape)) return fail(AVSEP_EINVAL, "bad argument");
   RawW w;
   w.ptr = dev_ptr;
@@ -832,9 +854,11 @@ int avsep_set_weight(avsep_ctx* c, const char* key, const float* dev_ptr, const 
   c->raw[key] = std::move(w);
   c->finalized = false;
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
-int avsep_finalize_weights(avsep_ctx* c, void* stream) {
+int avsep_finalize_weights(avsep_ctx* c, void* stream) try {
   if (!c) return fail(AVSEP_EINVAL, "null context");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int d = c->d, F = c->F, S = c->S;
@@ -920,6 +944,8 @@ int avsep_finalize_weights(avsep_ctx* c, void* stream) {
     return fail(AVSEP_ENOWEIGHT, "no stage has a complete set of weights");
   c->finalized = true;
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 size_t avsep_workspace_bytes(const avsep_ctx* c, int B, int T, int N, int H, int W) {
@@ -933,12 +959,14 @@ size_t avsep_workspace_bytes(const avsep_ctx* c, int B, int T, int N, int H, int
 }
 
 int avsep_forward(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
-                  size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) {
+                  size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) try {
   return forward_impl(c, mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, reinterpret_cast<hipStream_t>(stream));
+} catch (...) {
+  return on_exception();
 }
 
 int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
-                        size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) {
+                        size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) try {
   RCK(check_common(c, B, T));
   if (c->keep_taps || c->prof_on) return fail(AVSEP_EINVAL, "debug taps / profiler are not available under graph replay");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -967,10 +995,12 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
   // capture stream left a ~40-60 us bubble per step).  Only capture needs a non-legacy stream, launch does not.
   HCK(hipGraphLaunch(hit->exec, s));
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 int avsep_audio_encoder(avsep_ctx* c, const float* mixed, float* out, void* ws, size_t ws_bytes, int B, int T,
-                        void* stream) {
+                        void* stream) try {
   RCK(check_common(c, B, T));
   if (!mixed || !out || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -981,10 +1011,12 @@ int avsep_audio_encoder(avsep_ctx* c, const float* mixed, float* out, void* ws, 
   RCK(audio_branch(c, w, mixed, B, T, s));
   HCK(hipMemcpyAsync(out, w.a_x, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 int avsep_visual_encoder(avsep_ctx* c, const float* lips, float* out, void* ws, size_t ws_bytes, int B, int N, int H,
-                         int W, int T, void* stream) {
+                         int W, int T, void* stream) try {
   RCK(check_common(c, B, T));
   if (!lips || !out || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -995,10 +1027,12 @@ int avsep_visual_encoder(avsep_ctx* c, const float* lips, float* out, void* ws, 
   RCK(visual_branch(c, w, lips, B, N, H, W, T, s));
   HCK(hipMemcpyAsync(out, w.v_up, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 int avsep_fusion(avsep_ctx* c, const float* audio, const float* visual, float* out, void* ws, size_t ws_bytes, int B,
-                 int T, void* stream) {
+                 int T, void* stream) try {
   RCK(check_common(c, B, T));
   if (!audio || !visual || !out || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1011,10 +1045,12 @@ int avsep_fusion(avsep_ctx* c, const float* audio, const float* visual, float* o
   RCK(fusion_layers(c, w, w.a_x, B, T, s, /*final_norm=*/true));
   HCK(hipMemcpyAsync(out, w.ln, (size_t)B * T * c->d * sizeof(float), hipMemcpyDeviceToDevice, s));
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 int avsep_decoder(avsep_ctx* c, const float* fused, const float* mixed, float* masks, float* sep, void* ws,
-                  size_t ws_bytes, int B, int T, void* stream) {
+                  size_t ws_bytes, int B, int T, void* stream) try {
   RCK(check_common(c, B, T));
   if (!fused || !masks || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
   if ((mixed == nullptr) != (sep == nullptr)) return fail(AVSEP_EINVAL, "mixed and separated must be given together");
@@ -1025,10 +1061,12 @@ int avsep_decoder(avsep_ctx* c, const float* fused, const float* mixed, float* m
   if (mixed) HCK(launch_transpose_pad(mixed, w.xt, B, c->F, T, c->Fp, s));
   RCK(decoder_stage(c, w, fused, masks, sep, B, T, s, /*fuse_norm=*/false));
   return AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 int64_t avsep_read_tap(avsep_ctx* c, const char* name, float* dst, int64_t max_floats, void* ws, int B, int T,
-                          int N, int H, int W, void* stream) {
+                          int N, int H, int W, void* stream) try {
   if (!c || !name || !dst || !ws) return fail(AVSEP_EINVAL, "bad argument");
   if (!c->keep_taps) return fail(AVSEP_ESTATE, "debug taps are off (avsep_set_debug_taps)");
   Workspace w;
@@ -1042,6 +1080,8 @@ int64_t avsep_read_tap(avsep_ctx* c, const char* name, float* dst, int64_t max_f
       return (int64_t)t.n;
     }
   return fail(AVSEP_EINVAL, std::string("unknown tap: ") + name);
+} catch (...) {
+  return on_exception();
 }
 
 // ---------------------------------------------------------------------------------- single-kernel entry points

@@ -33,7 +33,8 @@ enum {
   AVSEP_ENOWEIGHT = -2,  /* a weight needed by the called stage is unset */
   AVSEP_EHIP = -3,       /* a HIP runtime call failed                   */
   AVSEP_ENOMEM = -4,     /* workspace too small / allocation failed     */
-  AVSEP_ESTATE = -5      /* weights not finalized                       */
+  AVSEP_ESTATE = -5,     /* weights not finalized                       */
+  AVSEP_EINTERNAL = -6   /* unexpected internal error (a C++ exception was caught at the boundary) */
 };
 
 /* Constructor arguments of AVSeparationTransformer (model.py:240-249).  dropout is not part of the
