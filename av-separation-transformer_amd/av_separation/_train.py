@@ -105,6 +105,19 @@ def _wgrad(dyt, xt):
     return dw
 
 
+def _wgrad_direct(dy, x):
+    """dW [N, K] = dY^T X from the row-major tensors themselves (k-major wgrad kernel; N, K multiples of 4)."""
+    R, N = dy.shape
+    K = x.shape[1]
+    lib = _lib()
+    dw = torch.empty(N, K, device=dy.device)
+    ns = lib.avsep_op_wgrad_direct_scratch_floats(N, K, R)
+    scratch = torch.empty(ns, device=dy.device) if ns else None
+    _ck(lib.avsep_op_wgrad_direct(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), scratch.data_ptr() if ns else None,
+                                  N, K, R, _st(dy)), "wgrad_direct")
+    return dw
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x w^T + b) + res;  act in {none, relu}; res: same-shape residual (grad flows) or constant rows with
     period `rperiod` (positional encoding, no grad)."""
@@ -138,8 +151,11 @@ class LinearFn(torch.autograd.Function):
             wt = _transpose(w, Np)                                         # [K, Np] = w^T
             dx = _gemm(dpp, wt, None, None, 0, ACT_NONE)                   # dY W
         if ctx.needs_input_grad[1]:
-            Mp = (M + 63) // 64 * 64                                                      # zero rows: layout only
-            dw = _wgrad(_transpose(dpre, Mp), _transpose(x, Mp))                          # dY^T X  [N, K]
+            if N % 4 == 0:
+                dw = _wgrad_direct(dpre, x)                                                # dY^T X  [N, K], no copies
+            else:                                                                          # e.g. 3 x 257 mask channels
+                Mp = (M + 63) // 64 * 64                                                  # zero rows: layout only
+                dw = _wgrad(_transpose(dpre, Mp), _transpose(x, Mp))
         if ctx.has_b and ctx.needs_input_grad[2]:
             db, _ = _colsum(dpre)
         dres = dy if (ctx.res_grad and ctx.needs_input_grad[4]) else None

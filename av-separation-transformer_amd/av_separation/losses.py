@@ -33,25 +33,43 @@ class SeparationLoss(nn.Module):
         super().__init__()
         self.l1_weight = l1_weight
 
+    def _order_table(self, n_spk: int, device) -> torch.Tensor:
+        """All speaker orders as an (S!, S) index tensor resident on ``device`` (built once: a host-to-device copy in
+        the step would queue behind the forward kernels and stall the host like the comparison it replaces)."""
+        key = (n_spk, str(device))
+        cache = self.__dict__.setdefault("_orders", {})
+        if key not in cache:
+            cache[key] = torch.tensor(list(permutations(range(n_spk))), device=device)
+        return cache[key]
+
+    def _value(self, cand: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        return self.l1_weight * (cand - targets).abs().mean() - si_snr(cand, targets)
+
     def forward(self, separated: torch.Tensor, targets: torch.Tensor, group=None) -> torch.Tensor:
         """``group``: data-parallel process group (equal shards).  The reference picks the permutation from the mean
         over the WHOLE batch, so the candidates' values are averaged over ranks before comparing; the returned
         (differentiable) loss is this rank's term of the chosen permutation -- its mean over ranks is the
-        reference's batch loss."""
+        reference's batch loss.
+
+        The reference compares the candidates on the host (``loss < best_loss``, losses.py:70: one device sync per
+        step).  Here the choice stays on the device: the candidates are evaluated without a graph, ``argmin`` returns
+        the FIRST minimum (= the strict-"<" scan, ties keep the earlier permutation), the winning speaker order is
+        gathered with ``index_select`` and only that candidate is evaluated with a graph -- same value, same
+        gradient, no host round trip in the training step."""
         n_spk = separated.shape[1]
-        cands = []
-        for order in permutations(range(n_spk)):
-            cand = separated[:, list(order)]
-            cands.append(self.l1_weight * (cand - targets).abs().mean() - si_snr(cand, targets))
-        ranking = cands
-        if group is not None:
-            import torch.distributed as dist
-            from .parallel import all_reduce_sum_
-            if dist.get_world_size(group) > 1:
-                ranking = all_reduce_sum_(torch.stack([c.detach() for c in cands]), group) / dist.get_world_size(group)
-        best = 0
-        for i in range(1, len(cands)):
-            # strict "<" like the reference (losses.py:70): ties keep the earlier permutation
-            if ranking[i] < ranking[best]:
-                best = i
-        return cands[best]
+        table = self._order_table(n_spk, separated.device)
+        with torch.no_grad():
+            # index_select with device-resident rows: indexing with a Python list would upload an index tensor per
+            # candidate, and that copy waits for the forward like any other stream-ordered transfer
+            ranking = torch.stack([self._value(separated.index_select(1, table[i]), targets)
+                                   for i in range(table.shape[0])])
+            if group is not None:
+                import torch.distributed as dist
+                from .parallel import all_reduce_sum_
+                if dist.get_world_size(group) > 1:
+                    ranking = all_reduce_sum_(ranking, group) / dist.get_world_size(group)
+            # NaN never wins a "<" comparison, but a NaN FIRST candidate is never replaced either
+            finite = torch.where(torch.isnan(ranking), torch.full_like(ranking, float("inf")), ranking)
+            best = torch.where(torch.isnan(ranking[0]), torch.zeros_like(torch.argmin(finite)), torch.argmin(finite))
+            order = table.index_select(0, best.reshape(1)).reshape(-1)
+        return self._value(separated.index_select(1, order), targets)

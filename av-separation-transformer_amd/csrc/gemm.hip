@@ -24,6 +24,7 @@
 //     sigmoid-mask * mixed product of SeparationDecoder (model.py:207,220) with both outputs written
 //     in the reference's (B,T,S,F) memory order.
 #include "kernels.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -282,6 +283,148 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   }
 
   gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient without transposes:  dW[n][k] = sum_r dY[r][n] * X[r][k]  (nn.Linear / conv-as-GEMM backward).
+// Both operands are "k-major" for this contraction (the contracted index r is the slow one), so a tile's chunk of
+// 32 r-rows is fetched as float4s ALONG m / n (coalesced rows of dY and X as they sit in memory) and scattered into
+// the same swizzled [row][k] LDS image the other kernels use (4 ds_write_b32 per float4 instead of one b128); the
+// MFMA side is mfma_chunk unchanged.  gridDim.y slices the r range (split-K, partial tiles summed by the caller in a
+// fixed order).  Rows r >= R contribute zeros; N and K must be multiples of 4 (float4 columns).
+struct WgradParams {
+  const float* dy;   // [R][ldy]
+  const float* x;    // [R][ldx]
+  float* dw;         // [N][K] (+ z * N*K per slice)
+  int R, N, K, ldy, ldx;
+  int rchunk;        // rows per slice (multiple of 32), gridDim.y slices
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int BK = 32, SLOTS = BK / 4;
+  constexpr int AV = BM / 4, BV = BN / 4;          // float4 columns per r-row of each operand tile
+  constexpr int AL = (BK * AV) / 256, BL = (BK * BV) / 256;   // float4 loads per thread per chunk
+  constexpr int WBM = BM / 32, WBN = BN / 32;
+  static_assert(AL >= 1 && BL >= 1, "tile too small for 256 threads");
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.K + BN - 1) / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int r_begin = blockIdx.y * p.rchunk;
+  const int r_end = min(p.R, r_begin + p.rchunk);
+  const int nk = (r_end - r_begin + BK - 1) / BK;
+  float* out = p.dw + (size_t)blockIdx.y * p.N * p.K;
+
+  // staging: load l of this thread covers r-row kr and float4 column cv of the tile
+  int a_kr[AL], a_col[AL], b_kr[BL], b_col[BL];
+#pragma unroll
+  for (int l = 0; l < AL; ++l) {
+    const int idx = tid + 256 * l;
+    a_kr[l] = idx / AV;
+    a_col[l] = min(m0 + 4 * (idx % AV), p.N - 4);      // clamp: duplicated columns are never stored
+  }
+#pragma unroll
+  for (int l = 0; l < BL; ++l) {
+    const int idx = tid + 256 * l;
+    b_kr[l] = idx / BV;
+    b_col[l] = min(n0 + 4 * (idx % BV), p.K - 4);
+  }
+  f32x4 ra[2][AL], rb[2][BL];
+  auto load_chunk = [&](int kc, int slot) {
+    const int r0 = r_begin + kc * BK;
+#pragma unroll
+    for (int l = 0; l < AL; ++l) {
+      const int r = r0 + a_kr[l];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)min(r, p.R - 1) * p.ldy + a_col[l]);
+      ra[slot][l] = r < r_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int l = 0; l < BL; ++l) {
+      const int r = r0 + b_kr[l];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)min(r, p.R - 1) * p.ldx + b_col[l]);
+      rb[slot][l] = r < r_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_chunk = [&](int slot, int buf) {
+    float* a = As + buf * BM * BK;
+    float* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int l = 0; l < AL; ++l) {
+      const int idx = tid + 256 * l, kr = idx / AV, mrow = 4 * (idx % AV);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = mrow + e;
+        a[row * BK + ((((kr >> 2) ^ swz<SLOTS>(row)) << 2) | (kr & 3))] = ra[slot][l][e];
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < BL; ++l) {
+      const int idx = tid + 256 * l, kr = idx / BV, nrow = 4 * (idx % BV);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = nrow + e;
+        b[row * BK + ((((kr >> 2) ^ swz<SLOTS>(row)) << 2) | (kr & 3))] = rb[slot][l][e];
+      }
+    }
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    const int r = wm * (BM / 2) + 16 * i + fr;
+    a_off[i] = r * BK;
+    a_swz[i] = swz<SLOTS>(r);
+  }
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int r = wn * (BN / 2) + 16 * j + fr;
+    b_off[j] = r * BK;
+    b_swz[j] = swz<SLOTS>(r);
+  }
+  f32x4 acc[WBM][WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_chunk(0, 0);
+    store_chunk(0, 0);
+    if (nk > 1) load_chunk(1, 1);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+      // even chunk: LDS buffer 0, ring slot 0 free -> prefetch chunk kc+2
+      if (kc + 2 < nk) load_chunk(kc + 2, 0);
+      mfma_chunk<BK, WBM, WBN>(As, Bs, a_off, a_swz, b_off, b_swz, fq, acc);
+      if (kc + 1 < nk) store_chunk(1, 1);
+      __syncthreads();
+      if (kc + 1 < nk) {
+        if (kc + 3 < nk) load_chunk(kc + 3, 1);
+        mfma_chunk<BK, WBM, WBN>(As + BM * BK, Bs + BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+        if (kc + 2 < nk) store_chunk(0, 0);
+        __syncthreads();
+      }
+    }
+  }
+  // C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+reg
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int n = n0 + wn * (BN / 2) + 16 * j + fr;
+    if (n >= p.K) continue;
+#pragma unroll
+    for (int i = 0; i < WBM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * (BM / 2) + 16 * i + 4 * fq + r;
+        if (m < p.N) out[(size_t)m * p.K + n] = acc[i][j][r];
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -587,4 +730,31 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
 #undef AVSEP_MODES
 #undef AVSEP_CASE
   return hipErrorInvalidValue;
+}
+
+// dW = dY^T X straight from the row-major activations (no transposes).  Returns the number of r-slices used through
+// *slices (1 = dw written directly; > 1 = `partial` holds the slices, the caller sums them).
+int wgrad_slices(int N, int K, int R) {
+  const long tiles64 = (long)((N + 63) / 64) * ((K + 63) / 64);
+  const long tiles = tiles64 >= 256 ? tiles64 : (long)((N + 31) / 32) * ((K + 31) / 32);
+  if (tiles >= 512 || R < 1024) return 1;
+  long want = std::min<long>((1024 + tiles - 1) / tiles, R / 256);
+  if (want < 2) return 1;
+  const int rchunk = (int)(((R + want - 1) / want + 31) / 32 * 32);
+  return (R + rchunk - 1) / rchunk;
+}
+
+hipError_t launch_wgrad(const float* dy, int ldy, const float* x, int ldx, float* out, int N, int K, int R, int slices,
+                        hipStream_t s) {
+  if (N <= 0 || K <= 0 || R <= 0 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || slices < 1) return hipErrorInvalidValue;
+  WgradParams p{dy, x, out, R, N, K, ldy, ldx, 0};
+  p.rchunk = slices > 1 ? (((R + slices - 1) / slices + 31) / 32 * 32) : ((R + 31) / 32 * 32);
+  const long tiles64 = (long)((N + 63) / 64) * ((K + 63) / 64);
+  if (tiles64 >= 256) {
+    hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3((unsigned)tiles64, slices), dim3(256), 0, s, p);
+  } else {
+    const long tiles = (long)((N + 31) / 32) * ((K + 31) / 32);
+    hipLaunchKernelGGL((wgrad_kernel<32, 32>), dim3((unsigned)tiles, slices), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
 }

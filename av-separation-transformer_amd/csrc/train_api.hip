@@ -92,6 +92,27 @@ int avsep_op_wgrad(const float* dyt, const float* xt, float* dw, float* scratch,
   return AVSEP_OK;
 }
 
+int64_t avsep_op_wgrad_direct_scratch_floats(int N, int K, int R) {
+  const int sl = wgrad_slices(N, K, R);
+  return sl > 1 ? (int64_t)sl * N * K : 0;
+}
+
+int avsep_op_wgrad_direct(const float* dy, int ldy, const float* x, int ldx, float* dw, float* scratch, int N, int K,
+                          int R, void* stream) {
+  if (!dy || !x || !dw || N <= 0 || K <= 0 || R <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if ((N & 3) || (K & 3) || (ldy & 3) || (ldx & 3))
+    return fail(AVSEP_EINVAL, "wgrad_direct needs N, K and both row strides to be multiples of 4 (use avsep_op_wgrad)");
+  const int sl = wgrad_slices(N, K, R);
+  if (sl > 1) {
+    if (!scratch) return fail(AVSEP_EINVAL, "wgrad_direct needs avsep_op_wgrad_direct_scratch_floats() floats of scratch");
+    TCK(launch_wgrad(dy, ldy, x, ldx, scratch, N, K, R, sl, S(stream)));
+    TCK(launch_sum_slices(scratch, dw, sl, (size_t)N * K, S(stream)));
+  } else {
+    TCK(launch_wgrad(dy, ldy, x, ldx, dw, N, K, R, 1, S(stream)));
+  }
+  return AVSEP_OK;
+}
+
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                              int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,
                              uint64_t drop_seed, void* stream) {

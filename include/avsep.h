@@ -155,6 +155,12 @@ int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const f
  * nn.Linear / nn.Conv1d / nn.Conv2d weights (model.py:38-40, 82-93, ...). */
 int64_t avsep_op_wgrad_scratch_floats(int N, int K, int R);
 int avsep_op_wgrad(const float* dyt, const float* xt, float* dw, float* scratch, int N, int K, int R, void* stream);
+/* The same weight gradient straight from the row-major tensors autograd holds: dy [R][ldy] (N columns used),
+ * x [R][ldx] (K columns used) -- no transposed copies; rows are the contraction and may be any count.  Needs N, K,
+ * ldy, ldx to be multiples of 4 (float4 columns); otherwise use avsep_op_wgrad on padded transposes. */
+int64_t avsep_op_wgrad_direct_scratch_floats(int N, int K, int R);
+int avsep_op_wgrad_direct(const float* dy, int ldy, const float* x, int ldx, float* dw, float* scratch, int N, int K,
+                          int R, void* stream);
 
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                              int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,
