@@ -759,6 +759,7 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
 
 void avsep_destroy(avsep_ctx* c) {
   if (!c) return;
+  (void)hipDeviceSynchronize();   // work of this context may still be in flight on the caller's and the side streams
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -987,7 +988,12 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
     e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HCK(e);
-    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    if (c->graphs.size() >= 8) {
+      // the evicted graph may still be replaying on the caller's stream: let it drain before its nodes are freed
+      (void)hipStreamSynchronize(s);
+      (void)hipGraphExecDestroy(c->graphs.front().exec);
+      c->graphs.erase(c->graphs.begin());
+    }
     c->graphs.push_back(g);
     hit = &c->graphs.back();
   }
