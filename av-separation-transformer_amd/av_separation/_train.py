@@ -232,8 +232,13 @@ class AttentionFn(torch.autograd.Function):
         qoff, koff, voff, B, h, dh, Lq, Lk, scale, same, drop_p, drop_seed = ctx.meta
         do = _c(do)
         d = h * dh
-        dqt = torch.zeros_like(qt)
-        dkvt = dqt if same else torch.zeros_like(kvt)
+        # every column of the packed projections is one of q / k / v, and the kernels write all rows of each
+        if qt.shape[1] != (3 * d if same else d) or (not same and kvt.shape[1] != 2 * d):
+            dqt = torch.zeros_like(qt)
+            dkvt = dqt if same else torch.zeros_like(kvt)
+        else:
+            dqt = torch.empty_like(qt)
+            dkvt = dqt if same else torch.empty_like(kvt)
         dvec = torch.empty(B * h * Lq, device=qt.device)
         ldq, ldk = qt.shape[1], kvt.shape[1]
         _ck(_lib().avsep_op_attention_bwd(qt.data_ptr() + 4 * qoff, ldq, kvt.data_ptr() + 4 * koff, ldk,

@@ -140,6 +140,12 @@ class GradBuckets:
             b["flat"].zero_()
         self._begin()
 
+    def close(self):
+        """Detach from the parameters (remove the hooks; ``.grad`` tensors stay as they are)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
     @property
     def bucket_sizes(self):
         return [b["flat"].numel() * 4 for b in self.buckets]
@@ -174,7 +180,11 @@ class DataParallel(nn.Module):
                 else:
                     dist.broadcast(t.data, src, group=group)
         object.__setattr__(module, "_dp_group", group if (sync_bn and self.world > 1) else None)
+        old = getattr(module, "_dp_buckets", None)
+        if old is not None:               # re-wrapping the same module: the previous hooks would count arrivals twice
+            old.close()
         self.buckets = GradBuckets(module.parameters(), bucket_mb, first_bucket_mb, group)
+        object.__setattr__(module, "_dp_buckets", self.buckets)
 
     def forward(self, mixed_spec, lip_frames):
         return self.module(mixed_spec, lip_frames)
