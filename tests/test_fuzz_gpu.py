@@ -1,0 +1,99 @@
+"""Seeded shape fuzzing of the drop-in on the GPU: random (freq_bins, d_model, heads, layers, speakers, T, N, H, W, B)
+within the ABI's stated limits, (1) the fused inference path against the numpy oracle, (2) the train-mode autograd
+path (outputs, loss and every parameter gradient, dropout 0) against oracle/torch_cpu.forward_train -- both pinned on the
+reference's own outputs/gradients in tests/test_oracle.py.  Catches what hand-picked edge cases miss: ragged tiles,
+odd frame sizes on either conv path, head dims between the specialised ones, T < N, single-frame clips."""
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import maxabs
+from oracle import numpy_forward as onp
+from oracle import seeded, torch_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(rng, train):
+    while True:
+        h = rng.choice([1, 2, 4, 8])
+        dh = rng.choice([16, 32, 48, 64] if train else [4, 8, 12, 16, 24, 32, 64, 128])
+        d = h * dh
+        if d % 32 == 0 and d <= (128 if train else 256):
+            break
+    cfg = dict(freq_bins=rng.randint(3, 70), d_model=d, nhead=h, num_encoder_layers=rng.randint(0, 2),
+               num_fusion_layers=rng.randint(0, 2), num_speakers=rng.randint(1, 3))
+    dims = dict(B=rng.randint(1, 5), T=rng.randint(1, 70), N=rng.randint(1, 12), H=rng.randint(3, 40), W=rng.randint(3, 40))
+    return cfg, dims
+
+
+def _model(dev, cfg, seed, dropout=0.0):
+    import av_separation as av
+    torch.manual_seed(seed)
+    m = av.AVSeparationTransformer(dropout=dropout, **cfg)
+    g = torch.Generator().manual_seed(seed + 1)
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            v.copy_(torch.rand(v.shape, generator=g) * 0.6 - 0.3)
+        elif k.endswith("running_var"):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("AVSEP_FUZZ_INFER", "24"))))     # more with the env knob
+def test_fuzz_inference_against_numpy_oracle(case):
+    rng = random.Random(1000 + case)
+    cfg, dm = _draw(rng, train=False)
+    dev = torch.device("cuda:0")
+    m = _model(dev, cfg, case).eval()
+    mixed, lips = seeded.inputs(500 + case, dm["B"], cfg["freq_bins"], dm["T"], dm["N"], dm["H"], dm["W"])
+    with torch.no_grad():
+        sep, masks = m(torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev))
+    state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    rs, rm = onp.forward(state, mixed, lips, cfg["nhead"], cfg["num_speakers"])
+    assert masks.shape == (dm["B"], cfg["num_speakers"], cfg["freq_bins"], dm["T"]), (cfg, dm)
+    assert maxabs(masks.cpu().numpy(), rm) < 1e-5, (cfg, dm)
+    assert maxabs(sep.cpu().numpy(), rs) < 1e-5 * max(1.0, float(np.abs(mixed).max())), (cfg, dm)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("AVSEP_FUZZ_TRAIN", "10"))))
+def test_fuzz_training_gradients_against_torch_cpu_port(case):
+    from av_separation.losses import SeparationLoss
+    rng = random.Random(7000 + case)
+    cfg, dm = _draw(rng, train=True)
+    dm["B"] = max(dm["B"], 2)                      # BatchNorm batch statistics need more than one value per channel
+    dev = torch.device("cuda:0")
+    m = _model(dev, cfg, 100 + case).train()
+    mixed, lips = seeded.inputs(900 + case, dm["B"], cfg["freq_bins"], dm["T"], dm["N"], dm["H"], dm["W"])
+    tg = torch.rand(dm["B"], cfg["num_speakers"], cfg["freq_bins"], dm["T"], generator=torch.Generator().manual_seed(case))
+    tg = tg * torch.from_numpy(mixed).unsqueeze(1)
+    state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k, v in state.items():
+        if v.is_floating_point() and "running_" not in k and not k.endswith(".pe"):
+            v.requires_grad_()
+    rsep, _ = torch_cpu.forward_train(state, torch.from_numpy(mixed), torch.from_numpy(lips), cfg["nhead"],
+                                      cfg["num_speakers"])
+    rloss = SeparationLoss(0.5)(rsep, tg)
+    rloss.backward()
+    sep, _ = m(torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev))
+    loss = SeparationLoss(0.5)(sep, tg.to(dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(rloss.detach())) < 1e-4 * max(1.0, abs(float(rloss.detach()))), (cfg, dm)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = state[k].grad
+        if ref is None:                             # e.g. no layers -> parameter unused on both sides
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        err = maxabs(p.grad.cpu().numpy(), ref.numpy()) / max(1e-3, float(ref.abs().max()))
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err, cfg, dm)
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            assert maxabs(v.cpu().numpy(), state[k].numpy()) < 1e-4, (k, cfg, dm)
+    assert math.isfinite(worst)
