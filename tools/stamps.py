@@ -18,6 +18,10 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+wl = dict(wl, model=dict(wl["model"]))
+for key, env in (("num_encoder_layers", "AVSEP_LE"), ("num_fusion_layers", "AVSEP_LF")):   # ablation knobs
+    if env in os.environ:
+        wl["model"][key] = int(os.environ[env])
 B = wl["batch"]
 torch.manual_seed(0)
 m = av.AVSeparationTransformer(dropout=0.0, **wl["model"]).to(dev).eval()
