@@ -593,145 +593,6 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
   gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// LayerNorm-fused GEMM, A-stationary stripe form (K = 4 x 64 = 256, 32x32 tiles): a workgroup normalises its 32-row A
-// panel ONCE, parks it in LDS (32 KB, the swizzled chunk images mfma_chunk reads) and walks `tpb` consecutive column
-// tiles of W past it.  Against gemm_ln_kernel, which re-loads and re-normalises the panel for every column tile:
-// tpb x less A traffic and LayerNorm work, half the LDS writes per chunk, and W chunks of the NEXT tile are already
-// in flight (4-chunk register ring) while the current tile computes, so the load / compute phases of a workgroup
-// overlap instead of alternating.  Same per-element summation order as gemm_ln_kernel (bit-identical results).
-__global__ __launch_bounds__(256) void gemm_ln_stripe_kernel(const GemmParams p, int tpb) {
-  constexpr int BM = 32, BN = 32, BK = 64, NK = 4, SLOTS = BK / 4, RPP = 256 / SLOTS, APASS = BM / RPP, BPASS = BN / RPP;
-  __shared__ __attribute__((aligned(16))) float lds[NK * BM * BK + 2 * BN * BK];
-  float* Ap = lds;                      // NK chunk images of the normalised panel
-  float* Bs = lds + NK * BM * BK;       // two W chunk buffers
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nct = (p.N + BN - 1) / BN;
-  const int ngrp = (nct + tpb - 1) / tpb;
-  const int tile = xcd_tile(p);
-  const int bm = tile / ngrp, grp = tile - bm * ngrp;
-  const int m0 = bm * BM;
-  const int ct0 = grp * tpb;
-  const int ntile = min(tpb, nct - ct0);
-
-  const int srow = tid / SLOTS, sslot = tid % SLOTS;
-  int st[APASS];                        // swizzled float offset of this thread's slot in a [32][64] chunk image
-#pragma unroll
-  for (int i = 0; i < APASS; ++i) {
-    const int r = srow + RPP * i;
-    st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
-  }
-  // W ring: rb[kc][i] = chunk kc of the tile being fetched
-  f32x4 rb[NK][BPASS];
-  auto load_w = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      int n = (ct0 + t) * BN + srow + RPP * i;
-      n = n < p.N ? n : p.N - 1;
-      const float* src = p.W + (size_t)n * p.ldw + 4 * sslot;
-#pragma unroll
-      for (int kc = 0; kc < NK; ++kc) rb[kc][i] = *reinterpret_cast<const f32x4*>(src + kc * BK);
-    }
-  };
-  {
-    // ---- A panel: load, row statistics from registers, normalise, park in LDS -----------------------
-    f32x4 ra[NK][APASS], rg[NK], rbe[NK];
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      int m = m0 + srow + RPP * i;
-      m = m < p.M ? m : p.M - 1;
-      const float* src = p.A + (size_t)m * p.lda + 4 * sslot;
-#pragma unroll
-      for (int kc = 0; kc < NK; ++kc) ra[kc][i] = *reinterpret_cast<const f32x4*>(src + kc * BK);
-    }
-#pragma unroll
-    for (int kc = 0; kc < NK; ++kc) {
-      rg[kc] = *reinterpret_cast<const f32x4*>(p.ln_gamma + kc * BK + 4 * sslot);
-      rbe[kc] = *reinterpret_cast<const f32x4*>(p.ln_beta + kc * BK + 4 * sslot);
-    }
-    load_w(0);                          // first W tile rides the same memory round trip
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      const float c = __shfl(ra[0][i][0], lane & ~(SLOTS - 1));
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int kc = 0; kc < NK; ++kc)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float dlt = ra[kc][i][e] - c;
-          s1 += dlt;
-          s2 = fmaf(dlt, dlt, s2);
-        }
-#pragma unroll
-      for (int off = SLOTS / 2; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off);
-        s2 += __shfl_xor(s2, off);
-      }
-      const float inv = 1.0f / (float)p.K;
-      const float m1 = s1 * inv;
-      const float var = fmaxf(s2 * inv - m1 * m1, 0.0f);
-      const float mu = c + m1;
-      const float rs = 1.0f / sqrtf(var + p.ln_eps);
-#pragma unroll
-      for (int kc = 0; kc < NK; ++kc) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (ra[kc][i][e] - mu) * rs * rg[kc][e] + rbe[kc][e];
-        *reinterpret_cast<f32x4*>(Ap + kc * BM * BK + st[i]) = v;
-      }
-    }
-  }
-  const int fr = lane & 15, fq = lane >> 4;
-  int a_off[1], a_swz[1], b_off[1], b_swz[1];
-  {
-    const int ra_ = wm * 16 + fr, rb_ = wn * 16 + fr;
-    a_off[0] = ra_ * BK; a_swz[0] = swz<SLOTS>(ra_);
-    b_off[0] = rb_ * BK; b_swz[0] = swz<SLOTS>(rb_);
-  }
-  // chunk 0 of tile 0 -> buffer 0
-#pragma unroll
-  for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(Bs + st[i]) = rb[0][i];
-  __syncthreads();
-
-  for (int t = 0; t < ntile; ++t) {
-    f32x4 acc[1][1];
-    acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool more = t + 1 < ntile;     // block-uniform
-#pragma unroll
-    for (int kc = 0; kc < NK; ++kc) {
-      // ring slot kc went to LDS one step ago (kc > 0) or at the end of the previous tile (kc == 0): refill it with the
-      // same chunk of the next tile; slot 0 is refilled at kc == 1 so that it is free again
-      if (more && kc >= 1) {
-        const int rk = kc - 1;
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-          int n = (ct0 + t + 1) * BN + srow + RPP * i;
-          n = n < p.N ? n : p.N - 1;
-          rb[rk][i] = *reinterpret_cast<const f32x4*>(p.W + (size_t)n * p.ldw + 4 * sslot + rk * BK);
-        }
-      }
-      mfma_chunk<BK, 1, 1>(Ap + kc * BM * BK, Bs + (kc & 1) * BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
-      if (kc + 1 < NK) {
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(Bs + ((kc + 1) & 1) * BN * BK + st[i]) = rb[kc + 1][i];
-      } else if (more) {
-        // last chunk of the tile: fetch the next tile's chunk 3 (its slot was just consumed), stage its chunk 0
-#pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-          int n = (ct0 + t + 1) * BN + srow + RPP * i;
-          n = n < p.N ? n : p.N - 1;
-          const f32x4 nxt3 = *reinterpret_cast<const f32x4*>(p.W + (size_t)n * p.ldw + 4 * sslot + 3 * BK);
-          *reinterpret_cast<f32x4*>(Bs + st[i]) = rb[0][i];
-          rb[3][i] = nxt3;
-        }
-      }
-      __syncthreads();
-    }
-    gemm_epilogue<BM, BN, 1, 1>(p, acc, m0, (ct0 + t) * BN, wm, wn, fr, fq);
-  }
-}
-
 template <int BM, int BN, int BK, int AMODE, bool PF = false>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -821,23 +682,7 @@ hipError_t launch_ln_nk(const GemmParams& p, int nk, hipStream_t s) {
   }
 }
 
-// column tiles per workgroup of the stripe kernel: as many as still leave ~2 workgroups per CU
-int ln_stripe_tpb(const GemmParams& p) {
-  static const int forced = getenv("AVSEP_LN_STRIPE") ? atoi(getenv("AVSEP_LN_STRIPE")) : -1;   // developer: 0 = off, n = tpb
-  if (forced == 0 || p.K != 256 || getenv("AVSEP_LN_TILE")) return 0;
-  const long nbm = (p.M + 31) / 32, nct = (p.N + 31) / 32;
-  if (forced > 0) return forced;
-  long tpb = nbm * nct / 500;
-  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
-  return (int)tpb;
-}
-
 hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
-  if (const int tpb = ln_stripe_tpb(p); tpb >= 2) {
-    const int nbm = (p.M + 31) / 32, nct = (p.N + 31) / 32, ngrp = (nct + tpb - 1) / tpb;
-    hipLaunchKernelGGL(gemm_ln_stripe_kernel, dim3(nbm * ngrp), dim3(256), 0, s, p, tpb);
-    return hipGetLastError();
-  }
   const Tile t = pick_ln_tile(p);
   const int nk = p.K / t.bk;
   if (t.bk == 64) {
@@ -868,7 +713,6 @@ bool fragment_prefetch(const Tile& t, const GemmParams& p) {
 const char* gemm_instance_name(const GemmParams& p) {
   static thread_local char buf[64];
   if (p.ln_gamma) {
-    if (ln_stripe_tpb(p) >= 2) return "gemm_ln_stripe_kernel";
     const Tile t = pick_ln_tile(p);
     snprintf(buf, sizeof buf, "gemm_ln_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.K / t.bk);
     return buf;
