@@ -82,6 +82,54 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
   }
 }
 
+// Vectorised epilogue: the C/D layout gives every lane 4 consecutive ROWS of one column, so storing straight from the
+// accumulators costs one 4-byte store instruction per element with 64-byte row pieces -- store-ISSUE bound: measured
+// ~3.6 us per 64x64 tile, 15 us of every 45 us "round" of tiles at K = 512 (tools/gemm_anatomy.hip has the loop at
+// 137 TFLOP/s, the kernel ran at 100).  Here the tile is transposed through LDS (free after the last chunk) and
+// leaves as float4 rows: 4x fewer store instructions, full 128-byte lines, bias / residual read as float4 too.
+// Values and rounding are those of gemm_epilogue (bit-identical outputs).  `mw`, `nw`: the wave's offset inside the
+// tile; NT threads; the caller guarantees a barrier between the last LDS read of the main loop and this call.
+template <int BM, int BN, int WBM, int WBN, int NT, int LDS_FLOATS>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], float* ct, int m0,
+                                                   int n0, int mw, int nw, int fr, int fq) {
+  // padded rows (2-way instead of 4-way bank conflicts on the transposing writes) where the tile image still fits
+  constexpr int LDT = (BM * (BN + 4) <= LDS_FLOATS) ? BN + 4 : BN;
+  static_assert(BM * LDT <= LDS_FLOATS, "tile image does not fit the kernel's LDS");
+#pragma unroll
+  for (int j = 0; j < WBN; ++j)
+#pragma unroll
+    for (int i = 0; i < WBM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ct[(mw + 16 * i + 4 * fq + r) * LDT + nw + 16 * j + fr] = acc[i][j][r];
+  __syncthreads();
+  constexpr int V = BN / 4;                      // float4 per tile row
+  for (int idx = threadIdx.x; idx < BM * V; idx += NT) {
+    const int row = idx / V, c4 = idx - row * V;
+    const int m = m0 + row, n = n0 + 4 * c4;
+    if (m >= p.M || n >= p.N) continue;          // N % 4 == 0 on this path: a float4 is inside or outside as a whole
+    f32x4 v = *reinterpret_cast<const f32x4*>(ct + row * LDT + 4 * c4);
+    if (p.bias) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += b[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+    if (p.R) {
+      const int rr = p.rperiod > 0 ? (m % p.rperiod) : m;
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rv[e];
+    }
+    *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+  }
+}
+
+// float4 rows are possible when every row of C / R / bias starts 16-byte aligned and N is a multiple of 4
+__device__ __forceinline__ bool epilogue_rows_ok(const GemmParams& p) {
+  return !p.C2 && !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
+}
+
 // One K-chunk of MFMAs from the LDS image (shared by the GEMM kernels).
 // PF = false: fragments of a k-step are read right before its MFMAs (what the compiler schedules best for occupancy).
 // PF = true : all fragment reads of step s+1 are issued BEFORE the MFMAs of step s (second register set, pinned with a
@@ -285,12 +333,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   store_chunk(0, 0);
   __syncthreads();
 
-  for (int kc0 = 0; kc0 < nk; kc0 += D) {
+  // Steady state: groups of D chunks in which EVERY refill exists, so the loads are unconditional.  With a
+  // conditional load in the loop body the compiler cannot know how many loads are outstanding at the ds_write that
+  // consumes the OLDER ring slot and waits for all of them (s_waitcnt vmcnt(3..0) instead of vmcnt(4+)), which
+  // collapses the prefetch distance (tools/gemm_anatomy.hip: 105 vs 137 TFLOP/s on the bare loop).  The last
+  // groups run the guarded copy of the body.
+  int kc0 = 0;
+  for (; kc0 + 2 * D <= nk; kc0 += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      load_chunk(j);                       // slot j (chunk kc0+j) went to LDS one step ago: refill with chunk kc0+j+D
+      mfma_chunk<BK, WBM, WBN, PF>(As + (j & 1) * BM * BK, Bs + (j & 1) * BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+      store_chunk((j + 1) % D, (j + 1) & 1);
+      __syncthreads();
+    }
+  }
+  for (; kc0 < nk; kc0 += D) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const int kc = kc0 + j;
       if (kc < nk) {                       // block-uniform
-        if (kc + D < nk) load_chunk(j);    // slot j (chunk kc) went to LDS one iteration ago: refill with chunk kc+D
+        if (kc + D < nk) load_chunk(j);
         // D is even: (kc & 1) == (j & 1)
         mfma_chunk<BK, WBM, WBN, PF>(As + (j & 1) * BM * BK, Bs + (j & 1) * BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
         // chunk kc+1 (ring slot j+1, loaded D-1 iterations ago) -> the other LDS buffer
@@ -300,7 +363,116 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     }
   }
 
-  gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+  if (epilogue_rows_ok(p))   // block-uniform; the main loop ended on a barrier, so the LDS images are free
+    gemm_epilogue_rows<BM, BN, WBM, WBN, 256, 2 * (BM + BN) * BK>(p, acc, lds, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  else
+    gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Large-problem GEMM: 8 wavefronts per workgroup (WM x WN = 4 x 2) on a 128 x 128 x 32 tile, PLAIN operands only.
+// Each wave owns 32 x 64 of the tile (2 x 4 MFMA blocks).  Why a bigger tile: with one tile per workgroup all resident
+// workgroups start and finish together, so every "round" of tiles pays its cold first loads and its output stores
+// with idle matrix pipes -- about 8 us of a 40 us round for the 64x64 tile at K = 512 (101-112 TFLOP/s there against
+// 118-123 at K = 2048 with the same loop); a tile four times larger amortises that four times better, re-reads A and
+// W half as often, and one k-step's six fragment reads feed 32 MFMAs instead of four feeding 16.  Two such
+// workgroups share a CU (64 KB LDS, <= 128 VGPRs: four waves per SIMD).  Same staging / swizzle / k-permutation /
+// epilogue as gemm_kernel; steady-state loads unconditional (see there).  Reference point: the vendor BLAS reaches
+// 127-143 TFLOP/s on these shapes (tools/blas_reference.py).
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int SLOTS = BK / 4, RPP = NT / SLOTS, APASS = BM / RPP, BPASS = BN / RPP;
+  constexpr int WBM = BM / WM / 16, WBN = BN / WN / 16;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && APASS >= 1 && BPASS >= 1, "tile / thread-count mismatch");
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int nbn = (p.N + BN - 1) / BN;
+  const int tile = xcd_tile(p);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const int srow = tid / SLOTS, sslot = tid % SLOTS;
+  const float* a_src[APASS];
+  const float* b_src[BPASS];
+  int a_st[APASS], b_st[BPASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int r = srow + RPP * i;
+    a_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + 4 * sslot;
+  }
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int r = srow + RPP * i;
+    b_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    b_src[i] = p.W + (size_t)min(n0 + r, p.N - 1) * p.ldw + 4 * sslot;
+  }
+  const int nk = p.K / BK;
+  f32x4 ra[2][APASS], rb[2][BPASS];
+  auto load_chunk = [&](int kc, int slot) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + kc * BK);
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + kc * BK);
+  };
+  auto store_chunk = [&](int slot, int buf) {
+    float* a = As + buf * BM * BK;
+    float* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + a_st[i]) = ra[slot][i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + b_st[i]) = rb[slot][i];
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    const int r = wm * (BM / WM) + 16 * i + fr;
+    a_off[i] = r * BK;
+    a_swz[i] = swz<SLOTS>(r);
+  }
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int r = wn * (BN / WN) + 16 * j + fr;
+    b_off[j] = r * BK;
+    b_swz[j] = swz<SLOTS>(r);
+  }
+  f32x4 acc[WBM][WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // nk is even and >= 4 (launcher): chunk kc lives in ring slot / LDS buffer kc & 1
+  load_chunk(0, 0);
+  load_chunk(1, 1);
+  store_chunk(0, 0);
+  __syncthreads();
+  int kc = 0;
+  for (; kc + 4 <= nk; kc += 2) {            // steady state: every load and store exists
+    load_chunk(kc + 2, 0);
+    mfma_chunk<BK, WBM, WBN>(As, Bs, a_off, a_swz, b_off, b_swz, fq, acc);
+    store_chunk(1, 1);
+    __syncthreads();
+    load_chunk(kc + 3, 1);
+    mfma_chunk<BK, WBM, WBN>(As + BM * BK, Bs + BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+    store_chunk(0, 0);
+    __syncthreads();
+  }
+  mfma_chunk<BK, WBM, WBN>(As, Bs, a_off, a_swz, b_off, b_swz, fq, acc);
+  store_chunk(1, 1);
+  __syncthreads();
+  mfma_chunk<BK, WBM, WBN>(As + BM * BK, Bs + BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+  if (epilogue_rows_ok(p)) {
+    __syncthreads();
+    gemm_epilogue_rows<BM, BN, WBM, WBN, NT, 2 * (BM + BN) * BK>(p, acc, lds, m0, n0, wm * (BM / WM), wn * (BN / WN), fr, fq);
+  } else {
+    gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), 0, 0, fr, fq);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -590,7 +762,10 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
     }
   }
 
-  gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+  if (epilogue_rows_ok(p))   // the chunk loop ended on a barrier
+    gemm_epilogue_rows<BM, BN, WBM, WBN, 256, 2 * (BM + BN) * BK>(p, acc, lds, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  else
+    gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
 }
 
 template <int BM, int BN, int BK, int AMODE, bool PF = false>
@@ -704,6 +879,14 @@ bool gemm_ln_supported(int K) {
   return ln_fusable(p);
 }
 
+// 8-wave 128x128 tile once it still gives ~1.5 workgroups per CU (developer switch AVSEP_BIG_MIN: threshold, 0 = off)
+bool big_tile(const GemmParams& p) {
+  static const long tmin = getenv("AVSEP_BIG_MIN") ? atol(getenv("AVSEP_BIG_MIN")) : 384;
+  if (tmin <= 0 || p.amode != AMODE_PLAIN || p.ksplit > 1 || p.ln_gamma || getenv("AVSEP_GEMM_TILE")) return false;
+  if ((p.K & 63) || p.K < 128) return false;
+  return (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= tmin;
+}
+
 // long contractions on the 64x64 tile: see mfma_chunk
 bool fragment_prefetch(const Tile& t, const GemmParams& p) {
   static const int kmin = getenv("AVSEP_PF_KMIN") ? atoi(getenv("AVSEP_PF_KMIN")) : 1024;   // developer sweep
@@ -718,6 +901,7 @@ const char* gemm_instance_name(const GemmParams& p) {
     return buf;
   }
   const Tile t = pick_tile(p);
+  if (big_tile(p)) return "gemm_big_kernel<128, 128, 32, 4, 2>";
   if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true>");
   else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.amode);
   return buf;
@@ -739,6 +923,11 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   }
   const Tile t = pick_tile(p);
   if (p.K % t.bk) return hipErrorInvalidValue;
+  if (big_tile(p)) {
+    const int nb = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+    hipLaunchKernelGGL((gemm_big_kernel<128, 128, 32, 4, 2>), dim3(nb), dim3(512), 0, s, p);
+    return hipGetLastError();
+  }
   if (fragment_prefetch(t, p)) return launch_t<64, 64, 32, AMODE_PLAIN, true>(p, s);
 #define AVSEP_CASE(BM_, BN_, BK_, AM_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
