@@ -102,33 +102,57 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const f3
 #pragma unroll
       for (int r = 0; r < 4; ++r) ct[(mw + 16 * i + 4 * fq + r) * LDT + nw + 16 * j + fr] = acc[i][j][r];
   __syncthreads();
-  constexpr int V = BN / 4;                      // float4 per tile row
-  for (int idx = threadIdx.x; idx < BM * V; idx += NT) {
-    const int row = idx / V, c4 = idx - row * V;
-    const int m = m0 + row, n = n0 + 4 * c4;
-    if (m >= p.M || n >= p.N) continue;          // N % 4 == 0 on this path: a float4 is inside or outside as a whole
-    f32x4 v = *reinterpret_cast<const f32x4*>(ct + row * LDT + 4 * c4);
-    if (p.bias) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (!(p.N & 3) && !(p.ldc & 3) && !p.C2 && (!p.R || !(p.ldr & 3))) {
+    constexpr int V = BN / 4;                    // float4 per tile row
+    for (int idx = threadIdx.x; idx < BM * V; idx += NT) {
+      const int row = idx / V, c4 = idx - row * V;
+      const int m = m0 + row, n = n0 + 4 * c4;
+      if (m >= p.M || n >= p.N) continue;        // N % 4 == 0: a float4 is inside or outside as a whole
+      f32x4 v = *reinterpret_cast<const f32x4*>(ct + row * LDT + 4 * c4);
+      if (p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += b[e];
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      if (p.R) {
+        const int rr = p.rperiod > 0 ? (m % p.rperiod) : m;
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+      }
+      *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
     }
+  } else {
+    // 8-byte rows: N and the row strides even (the mask head: N = S * 257 with S even), incl. the mask * mixed output
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int V = BN / 2;
+    for (int idx = threadIdx.x; idx < BM * V; idx += NT) {
+      const int row = idx / V, c2 = idx - row * V;
+      const int m = m0 + row, n = n0 + 2 * c2;
+      if (m >= p.M || n >= p.N) continue;
+      f32x2 v = *reinterpret_cast<const f32x2*>(ct + row * LDT + 2 * c2);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-    if (p.R) {
-      const int rr = p.rperiod > 0 ? (m % p.rperiod) : m;
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + n);
+      for (int e = 0; e < 2; ++e) {
+        float x = v[e] + (p.bias ? p.bias[n + e] : 0.0f);
+        x = apply_act(x, p.act);
+        if (p.R) x += p.R[(size_t)(p.rperiod > 0 ? (m % p.rperiod) : m) * p.ldr + n + e];
+        v[e] = x;
+      }
+      *reinterpret_cast<f32x2*>(p.C + (size_t)m * p.ldc + n) = v;
+      if (p.C2) {
+        f32x2 w;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        for (int e = 0; e < 2; ++e) w[e] = v[e] * p.X[(size_t)m * p.ldx + (n + e) % p.F];
+        *reinterpret_cast<f32x2*>(p.C2 + (size_t)m * p.ldc + n) = w;
+      }
     }
-    *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
   }
 }
 
-// float4 rows are possible when every row of C / R / bias starts 16-byte aligned and N is a multiple of 4
-__device__ __forceinline__ bool epilogue_rows_ok(const GemmParams& p) {
-  return !p.C2 && !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
-}
+// vector rows need every row of C (and C2) to start 8-byte aligned and N even; float4 when 16-byte / multiple of 4
+__device__ __forceinline__ bool epilogue_rows_ok(const GemmParams& p) { return !(p.N & 1) && !(p.ldc & 1); }
 
 // One K-chunk of MFMAs from the LDS image (shared by the GEMM kernels).
 // PF = false: fragments of a k-step are read right before its MFMAs (what the compiler schedules best for occupancy).
