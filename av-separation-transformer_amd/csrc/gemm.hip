@@ -626,19 +626,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       }
     }
   }
-  // C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+reg
-#pragma unroll
-  for (int j = 0; j < WBN; ++j) {
-    const int n = n0 + wn * (BN / 2) + 16 * j + fr;
-    if (n >= p.K) continue;
-#pragma unroll
-    for (int i = 0; i < WBM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * (BM / 2) + 16 * i + 4 * fq + r;
-        if (m < p.N) out[(size_t)m * p.K + n] = acc[i][j][r];
-      }
-  }
+  // float4 rows through LDS (every path above ended on a barrier; K % 4 == 0 is a precondition of this kernel)
+  GemmParams q{};
+  q.C = out; q.M = p.N; q.N = p.K; q.ldc = p.K; q.act = ACT_NONE;
+  gemm_epilogue_rows<BM, BN, WBM, WBN, 256, 2 * (BM + BN) * BK>(q, acc, lds, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdint>
 
 namespace {
 
@@ -269,32 +270,54 @@ __global__ void bn_running_kernel(float* __restrict__ rmean, float* __restrict__
 
 // ------------------------------------------------------------------------------------------ elementwise
 // act: 1 relu (aux = y), 2 gelu (aux = pre-activation), 3 sigmoid (aux = y)
-__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
-                                                      int act) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
-  const float v = x[idx];
-  float r = v;
-  if (act == ACT_RELU) r = fmaxf(v, 0.0f);
-  else if (act == ACT_GELU) r = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-  else if (act == ACT_SIGMOID) r = 1.0f / (1.0f + expf(-v));
-  y[idx] = r;
-}
+// The elementwise kernels move V = 4 floats per thread (one 16-byte access each way) when the element count allows:
+// with 4-byte accesses they were bound by the number of memory instructions, not by HBM.
+template <int V> struct VecT { typedef float type; };
+template <> struct VecT<4> { typedef f32x4 type; };
+template <int V> __device__ __forceinline__ float& lane_of(typename VecT<V>::type& v, int e);
+template <> __device__ __forceinline__ float& lane_of<1>(float& v, int) { return v; }
+template <> __device__ __forceinline__ float& lane_of<4>(f32x4& v, int e) { return reinterpret_cast<float*>(&v)[e]; }
 
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ aux,
-                                                      float* __restrict__ dx, size_t n, int act) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
-  const float g = dy[idx], a = aux[idx];
-  float r = g;
-  if (act == ACT_RELU) r = a > 0.0f ? g : 0.0f;
-  else if (act == ACT_GELU) {
+__device__ __forceinline__ float act_value(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+__device__ __forceinline__ float act_grad(float g, float a, int act) {
+  if (act == ACT_RELU) return a > 0.0f ? g : 0.0f;
+  if (act == ACT_GELU) {
     // d/dx [ x Phi(x) ] = Phi(x) + x phi(x)
     const float cdf = 0.5f * (1.0f + erff(a * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * expf(-0.5f * a * a);
-    r = g * (cdf + a * pdf);
-  } else if (act == ACT_SIGMOID) r = g * a * (1.0f - a);
-  dx[idx] = r;
+    return g * (cdf + a * pdf);
+  }
+  if (act == ACT_SIGMOID) return g * a * (1.0f - a);
+  return g;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t nv,
+                                                      int act) {
+  typedef typename VecT<V>::type T;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nv) return;
+  T v = reinterpret_cast<const T*>(x)[idx];
+#pragma unroll
+  for (int e = 0; e < V; ++e) lane_of<V>(v, e) = act_value(lane_of<V>(v, e), act);
+  reinterpret_cast<T*>(y)[idx] = v;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ aux,
+                                                      float* __restrict__ dx, size_t nv, int act) {
+  typedef typename VecT<V>::type T;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nv) return;
+  T g = reinterpret_cast<const T*>(dy)[idx], a = reinterpret_cast<const T*>(aux)[idx];
+#pragma unroll
+  for (int e = 0; e < V; ++e) lane_of<V>(g, e) = act_grad(lane_of<V>(g, e), lane_of<V>(a, e), act);
+  reinterpret_cast<T*>(dx)[idx] = g;
 }
 
 // out[m][s*F + f] = a[m][s*F + f] * xt[m][f]   (SeparationDecoder.separate and its adjoint w.r.t. the masks)
@@ -308,21 +331,32 @@ __global__ __launch_bounds__(256) void mul_mixed_kernel(const float* __restrict_
 }
 
 // inverted dropout: y = keep ? x / (1-p) : 0 with the stateless mask of kernels.h (the backward applies the same op
-// to the gradient with the same seed)
-__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+// to the gradient with the same seed); the mask is a function of the ELEMENT index, whatever the vector width
+template <int V>
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t nv,
                                                       float p, unsigned long long seed) {
+  typedef typename VecT<V>::type T;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
-  y[idx] = dropout_keep(seed, idx, p) ? x[idx] / (1.0f - p) : 0.0f;
+  if (idx >= nv) return;
+  T v = reinterpret_cast<const T*>(x)[idx];
+#pragma unroll
+  for (int e = 0; e < V; ++e) lane_of<V>(v, e) = dropout_keep(seed, idx * V + e, p) ? lane_of<V>(v, e) / (1.0f - p) : 0.0f;
+  reinterpret_cast<T*>(y)[idx] = v;
 }
 
-// y[m][c] = x[m][c] + r[m % period][c]   (x + pe[:, :L], model.py:300, when it cannot ride a GEMM epilogue)
+// y[m][c] = x[m][c] + r[m % period][c]   (x + pe[:, :L], model.py:300, when it cannot ride a GEMM epilogue); C % V == 0
+template <int V>
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x, const float* __restrict__ r,
-                                                       float* __restrict__ y, size_t n, int C, int period) {
+                                                       float* __restrict__ y, size_t nv, int Cv, int period) {
+  typedef typename VecT<V>::type T;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n) return;
-  const size_t m = idx / C;
-  y[idx] = x[idx] + r[(m % period) * C + idx % C];
+  if (idx >= nv) return;
+  const size_t m = idx / Cv;
+  T v = reinterpret_cast<const T*>(x)[idx];
+  const T w = reinterpret_cast<const T*>(r)[(m % period) * Cv + idx % Cv];
+#pragma unroll
+  for (int e = 0; e < V; ++e) lane_of<V>(v, e) += lane_of<V>(const_cast<T&>(w), e);
+  reinterpret_cast<T*>(y)[idx] = v;
 }
 
 // AdaptiveAvgPool2d(1) adjoint: dx[m][p][c] = dy[m][c] / P
@@ -502,12 +536,21 @@ hipError_t launch_bn_running(float* rmean, float* rvar, const float* mean, const
   hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rmean, rvar, mean, var, C, momentum, unbias);
   return hipGetLastError();
 }
+namespace {
+inline bool vec4_ok(size_t n, const void* a, const void* b = nullptr, const void* c = nullptr) {
+  auto al = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return (n & 3) == 0 && al(a) && al(b) && al(c);
+}
+}  // namespace
 hipError_t launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t s) {
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(nblk(n)), dim3(256), 0, s, x, y, n, act);
+  if (vec4_ok(n, x, y)) hipLaunchKernelGGL((act_fwd_kernel<4>), dim3(nblk(n / 4)), dim3(256), 0, s, x, y, n / 4, act);
+  else hipLaunchKernelGGL((act_fwd_kernel<1>), dim3(nblk(n)), dim3(256), 0, s, x, y, n, act);
   return hipGetLastError();
 }
 hipError_t launch_act_bwd(const float* dy, const float* aux, float* dx, size_t n, int act, hipStream_t s) {
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(n)), dim3(256), 0, s, dy, aux, dx, n, act);
+  if (vec4_ok(n, dy, aux, dx))
+    hipLaunchKernelGGL((act_bwd_kernel<4>), dim3(nblk(n / 4)), dim3(256), 0, s, dy, aux, dx, n / 4, act);
+  else hipLaunchKernelGGL((act_bwd_kernel<1>), dim3(nblk(n)), dim3(256), 0, s, dy, aux, dx, n, act);
   return hipGetLastError();
 }
 hipError_t launch_mul_mixed(const float* a, const float* xt, float* out, size_t M, int S, int F, int ldx,
@@ -516,11 +559,14 @@ hipError_t launch_mul_mixed(const float* a, const float* xt, float* out, size_t 
   return hipGetLastError();
 }
 hipError_t launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s) {
-  hipLaunchKernelGGL(dropout_kernel, dim3(nblk(n)), dim3(256), 0, s, x, y, n, p, seed);
+  if (vec4_ok(n, x, y)) hipLaunchKernelGGL((dropout_kernel<4>), dim3(nblk(n / 4)), dim3(256), 0, s, x, y, n / 4, p, seed);
+  else hipLaunchKernelGGL((dropout_kernel<1>), dim3(nblk(n)), dim3(256), 0, s, x, y, n, p, seed);
   return hipGetLastError();
 }
 hipError_t launch_add_rows(const float* x, const float* r, float* y, size_t M, int C, int period, hipStream_t s) {
-  hipLaunchKernelGGL(add_rows_kernel, dim3(nblk(M * C)), dim3(256), 0, s, x, r, y, M * C, C, period);
+  if ((C & 3) == 0 && vec4_ok(4, x, r, y))
+    hipLaunchKernelGGL((add_rows_kernel<4>), dim3(nblk(M * C / 4)), dim3(256), 0, s, x, r, y, M * C / 4, C / 4, period);
+  else hipLaunchKernelGGL((add_rows_kernel<1>), dim3(nblk(M * C)), dim3(256), 0, s, x, r, y, M * C, C, period);
   return hipGetLastError();
 }
 hipError_t launch_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, hipStream_t s) {
