@@ -394,112 +394,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Large-problem GEMM: 8 wavefronts per workgroup (WM x WN = 4 x 2) on a 128 x 128 x 32 tile, PLAIN operands only.
-// Each wave owns 32 x 64 of the tile (2 x 4 MFMA blocks).  Why a bigger tile: with one tile per workgroup all resident
-// workgroups start and finish together, so every "round" of tiles pays its cold first loads and its output stores
-// with idle matrix pipes -- about 8 us of a 40 us round for the 64x64 tile at K = 512 (101-112 TFLOP/s there against
-// 118-123 at K = 2048 with the same loop); a tile four times larger amortises that four times better, re-reads A and
-// W half as often, and one k-step's six fragment reads feed 32 MFMAs instead of four feeding 16.  Two such
-// workgroups share a CU (64 KB LDS, <= 128 VGPRs: four waves per SIMD).  Same staging / swizzle / k-permutation /
-// epilogue as gemm_kernel; steady-state loads unconditional (see there).  Reference point: the vendor BLAS reaches
-// 127-143 TFLOP/s on these shapes (tools/blas_reference.py).
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_big_kernel(const GemmParams p) {
-  constexpr int NT = 64 * WM * WN;
-  constexpr int SLOTS = BK / 4, RPP = NT / SLOTS, APASS = BM / RPP, BPASS = BN / RPP;
-  constexpr int WBM = BM / WM / 16, WBN = BN / WN / 16;
-  static_assert(BM % RPP == 0 && BN % RPP == 0 && APASS >= 1 && BPASS >= 1, "tile / thread-count mismatch");
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
-  float* As = lds;
-  float* Bs = lds + 2 * BM * BK;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int nbn = (p.N + BN - 1) / BN;
-  const int tile = xcd_tile(p);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int m0 = bm * BM, n0 = bn * BN;
-
-  const int srow = tid / SLOTS, sslot = tid % SLOTS;
-  const float* a_src[APASS];
-  const float* b_src[BPASS];
-  int a_st[APASS], b_st[BPASS];
-#pragma unroll
-  for (int i = 0; i < APASS; ++i) {
-    const int r = srow + RPP * i;
-    a_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
-    a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + 4 * sslot;
-  }
-#pragma unroll
-  for (int i = 0; i < BPASS; ++i) {
-    const int r = srow + RPP * i;
-    b_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
-    b_src[i] = p.W + (size_t)min(n0 + r, p.N - 1) * p.ldw + 4 * sslot;
-  }
-  const int nk = p.K / BK;
-  f32x4 ra[2][APASS], rb[2][BPASS];
-  auto load_chunk = [&](int kc, int slot) {
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + kc * BK);
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + kc * BK);
-  };
-  auto store_chunk = [&](int slot, int buf) {
-    float* a = As + buf * BM * BK;
-    float* b = Bs + buf * BN * BK;
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) *reinterpret_cast<f32x4*>(a + a_st[i]) = ra[slot][i];
-#pragma unroll
-    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + b_st[i]) = rb[slot][i];
-  };
-  const int fr = lane & 15, fq = lane >> 4;
-  int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
-#pragma unroll
-  for (int i = 0; i < WBM; ++i) {
-    const int r = wm * (BM / WM) + 16 * i + fr;
-    a_off[i] = r * BK;
-    a_swz[i] = swz<SLOTS>(r);
-  }
-#pragma unroll
-  for (int j = 0; j < WBN; ++j) {
-    const int r = wn * (BN / WN) + 16 * j + fr;
-    b_off[j] = r * BK;
-    b_swz[j] = swz<SLOTS>(r);
-  }
-  f32x4 acc[WBM][WBN];
-#pragma unroll
-  for (int i = 0; i < WBM; ++i)
-#pragma unroll
-    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // nk is even and >= 4 (launcher): chunk kc lives in ring slot / LDS buffer kc & 1
-  load_chunk(0, 0);
-  load_chunk(1, 1);
-  store_chunk(0, 0);
-  __syncthreads();
-  int kc = 0;
-  for (; kc + 4 <= nk; kc += 2) {            // steady state: every load and store exists
-    load_chunk(kc + 2, 0);
-    mfma_chunk<BK, WBM, WBN>(As, Bs, a_off, a_swz, b_off, b_swz, fq, acc);
-    store_chunk(1, 1);
-    __syncthreads();
-    load_chunk(kc + 3, 1);
-    mfma_chunk<BK, WBM, WBN>(As + BM * BK, Bs + BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
-    store_chunk(0, 0);
-    __syncthreads();
-  }
-  mfma_chunk<BK, WBM, WBN>(As, Bs, a_off, a_swz, b_off, b_swz, fq, acc);
-  store_chunk(1, 1);
-  __syncthreads();
-  mfma_chunk<BK, WBM, WBN>(As + BM * BK, Bs + BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
-  if (epilogue_rows_ok(p)) {
-    __syncthreads();
-    gemm_epilogue_rows<BM, BN, WBM, WBN, NT, 2 * (BM + BN) * BK>(p, acc, lds, m0, n0, wm * (BM / WM), wn * (BN / WN), fr, fq);
-  } else {
-    gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), 0, 0, fr, fq);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Weight gradient without transposes:  dW[n][k] = sum_r dY[r][n] * X[r][k]  (nn.Linear / conv-as-GEMM backward).
 // Both operands are "k-major" for this contraction (the contracted index r is the slow one), so a tile's chunk of
 // 32 r-rows is fetched as float4s ALONG m / n (coalesced rows of dY and X as they sit in memory) and scattered into
@@ -894,14 +788,6 @@ bool gemm_ln_supported(int K) {
   return ln_fusable(p);
 }
 
-// 8-wave 128x128 tile once it still gives ~1.5 workgroups per CU (developer switch AVSEP_BIG_MIN: threshold, 0 = off)
-bool big_tile(const GemmParams& p) {
-  static const long tmin = getenv("AVSEP_BIG_MIN") ? atol(getenv("AVSEP_BIG_MIN")) : 384;
-  if (tmin <= 0 || p.amode != AMODE_PLAIN || p.ksplit > 1 || p.ln_gamma || getenv("AVSEP_GEMM_TILE")) return false;
-  if ((p.K & 63) || p.K < 128) return false;
-  return (long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= tmin;
-}
-
 // long contractions on the 64x64 tile: see mfma_chunk
 bool fragment_prefetch(const Tile& t, const GemmParams& p) {
   static const int kmin = getenv("AVSEP_PF_KMIN") ? atoi(getenv("AVSEP_PF_KMIN")) : 1024;   // developer sweep
@@ -916,7 +802,6 @@ const char* gemm_instance_name(const GemmParams& p) {
     return buf;
   }
   const Tile t = pick_tile(p);
-  if (big_tile(p)) return "gemm_big_kernel<128, 128, 32, 4, 2>";
   if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true>");
   else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.amode);
   return buf;
@@ -938,11 +823,6 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   }
   const Tile t = pick_tile(p);
   if (p.K % t.bk) return hipErrorInvalidValue;
-  if (big_tile(p)) {
-    const int nb = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    hipLaunchKernelGGL((gemm_big_kernel<128, 128, 32, 4, 2>), dim3(nb), dim3(512), 0, s, p);
-    return hipGetLastError();
-  }
   if (fragment_prefetch(t, p)) return launch_t<64, 64, 32, AMODE_PLAIN, true>(p, s);
 #define AVSEP_CASE(BM_, BN_, BK_, AM_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
