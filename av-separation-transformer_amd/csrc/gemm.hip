@@ -52,107 +52,81 @@ __device__ __forceinline__ int xcd_tile(const GemmParams& p) {
   return tile;
 }
 
-// Fused epilogue shared by the GEMM kernels.  C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+reg.
-template <int BM, int BN, int WBM, int WBN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], int m0, int n0,
-                                              int wm, int wn, int fr, int fq) {
+// Fused epilogue shared by the GEMM kernels.  The MFMAs are issued with the operands swapped (A operand = W rows,
+// B operand = activation rows, see mfma_chunk), so the 16x16 C/D layout -- col = lane&15, row = 4*(lane>>4)+reg --
+// holds, for output row m = lane&15, FOUR CONSECUTIVE COLUMNS n = 4*(lane>>4)+reg per accumulator: one float4 store
+// per MFMA block and lane, bias / residual read as float4 too.  The straightforward orientation (4 consecutive rows
+// per lane) costs one 4-byte store per element with 64-byte row pieces and was store-ISSUE bound: ~1/5 of a 64x64
+// tile's life (in-kernel clocks), 3-5 % of every step.  Same products in the same order: results are bit-identical.
+// `mw`, `nw`: the wave's offset inside the tile.
+template <int WBM, int WBN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], int m0, int n0, int mw,
+                                              int nw, int fr, int fq) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool v4 = !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
+  const bool v2 = !(p.N & 1) && !(p.ldc & 1);
 #pragma unroll
-  for (int j = 0; j < WBN; ++j) {
-    const int n = n0 + wn * (BN / 2) + 16 * j + fr;
-    if (n >= p.N) continue;
-    const float bias = p.bias ? p.bias[n] : 0.0f;
-    int nf = 0;
-    if (p.C2) nf = n % p.F;
+  for (int i = 0; i < WBM; ++i) {
+    const int m = m0 + mw + 16 * i + fr;
+    if (m >= p.M) continue;
+    const int rr = p.rperiod > 0 ? (m % p.rperiod) : m;
 #pragma unroll
-    for (int i = 0; i < WBM; ++i) {
+    for (int j = 0; j < WBN; ++j) {
+      const int n = n0 + nw + 16 * j + 4 * fq;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (v4) {                                   // block-uniform
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * (BM / 2) + 16 * i + 4 * fq + r;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bias;
-        v = apply_act(v, p.act);
-        if (p.R) {
-          const int rr = p.rperiod > 0 ? (m % p.rperiod) : m;
-          v += p.R[(size_t)rr * p.ldr + n];
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
         }
-        p.C[(size_t)m * p.ldc + n] = v;
-        if (p.C2) p.C2[(size_t)m * p.ldc + n] = v * p.X[(size_t)m * p.ldx + nf];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        if (p.R) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        }
+        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        if (p.C2) {
+          f32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = v[e] * p.X[(size_t)m * p.ldx + (n + e) % p.F];
+          *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc + n) = w;
+        }
+        continue;
       }
-    }
-  }
-}
-
-// Vectorised epilogue: the C/D layout gives every lane 4 consecutive ROWS of one column, so storing straight from the
-// accumulators costs one 4-byte store instruction per element with 64-byte row pieces -- store-ISSUE bound: measured
-// ~3.6 us per 64x64 tile, 15 us of every 45 us "round" of tiles at K = 512 (tools/gemm_anatomy.hip has the loop at
-// 137 TFLOP/s, the kernel ran at 100).  Here the tile is transposed through LDS (free after the last chunk) and
-// leaves as float4 rows: 4x fewer store instructions, full 128-byte lines, bias / residual read as float4 too.
-// Values and rounding are those of gemm_epilogue (bit-identical outputs).  `mw`, `nw`: the wave's offset inside the
-// tile; NT threads; the caller guarantees a barrier between the last LDS read of the main loop and this call.
-template <int BM, int BN, int WBM, int WBN, int NT, int LDS_FLOATS>
-__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], float* ct, int m0,
-                                                   int n0, int mw, int nw, int fr, int fq) {
-  // padded rows (2-way instead of 4-way bank conflicts on the transposing writes) where the tile image still fits
-  constexpr int LDT = (BM * (BN + 4) <= LDS_FLOATS) ? BN + 4 : BN;
-  static_assert(BM * LDT <= LDS_FLOATS, "tile image does not fit the kernel's LDS");
+      float w[4];
 #pragma unroll
-  for (int j = 0; j < WBN; ++j)
-#pragma unroll
-    for (int i = 0; i < WBM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ct[(mw + 16 * i + 4 * fq + r) * LDT + nw + 16 * j + fr] = acc[i][j][r];
-  __syncthreads();
-  if (!(p.N & 3) && !(p.ldc & 3) && !p.C2 && (!p.R || !(p.ldr & 3))) {
-    constexpr int V = BN / 4;                    // float4 per tile row
-    for (int idx = threadIdx.x; idx < BM * V; idx += NT) {
-      const int row = idx / V, c4 = idx - row * V;
-      const int m = m0 + row, n = n0 + 4 * c4;
-      if (m >= p.M || n >= p.N) continue;        // N % 4 == 0: a float4 is inside or outside as a whole
-      f32x4 v = *reinterpret_cast<const f32x4*>(ct + row * LDT + 4 * c4);
-      if (p.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += b[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-      if (p.R) {
-        const int rr = p.rperiod > 0 ? (m % p.rperiod) : m;
-        const f32x4 rv = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += rv[e];
-      }
-      *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
-    }
-  } else {
-    // 8-byte rows: N and the row strides even (the mask head: N = S * 257 with S even), incl. the mask * mixed output
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    constexpr int V = BN / 2;
-    for (int idx = threadIdx.x; idx < BM * V; idx += NT) {
-      const int row = idx / V, c2 = idx - row * V;
-      const int m = m0 + row, n = n0 + 2 * c2;
-      if (m >= p.M || n >= p.N) continue;
-      f32x2 v = *reinterpret_cast<const f32x2*>(ct + row * LDT + 2 * c2);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float x = v[e] + (p.bias ? p.bias[n + e] : 0.0f);
+      for (int e = 0; e < 4; ++e) {
+        const bool in = n + e < p.N;
+        float x = v[e] + ((p.bias && in) ? p.bias[n + e] : 0.0f);
         x = apply_act(x, p.act);
-        if (p.R) x += p.R[(size_t)(p.rperiod > 0 ? (m % p.rperiod) : m) * p.ldr + n + e];
+        if (p.R && in) x += p.R[(size_t)rr * p.ldr + n + e];
         v[e] = x;
+        w[e] = (p.C2 && in) ? x * p.X[(size_t)m * p.ldx + (n + e) % p.F] : 0.0f;
       }
-      *reinterpret_cast<f32x2*>(p.C + (size_t)m * p.ldc + n) = v;
-      if (p.C2) {
-        f32x2 w;
+      float* c = p.C + (size_t)m * p.ldc + n;
+      float* c2 = p.C2 ? p.C2 + (size_t)m * p.ldc + n : nullptr;
+      if (v2) {                                   // N even: the pairs (n, n+1), (n+2, n+3) are inside or outside whole
+        *reinterpret_cast<f32x2*>(c) = f32x2{v[0], v[1]};
+        if (c2) *reinterpret_cast<f32x2*>(c2) = f32x2{w[0], w[1]};
+        if (n + 2 < p.N) {
+          *reinterpret_cast<f32x2*>(c + 2) = f32x2{v[2], v[3]};
+          if (c2) *reinterpret_cast<f32x2*>(c2 + 2) = f32x2{w[2], w[3]};
+        }
+      } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) w[e] = v[e] * p.X[(size_t)m * p.ldx + (n + e) % p.F];
-        *reinterpret_cast<f32x2*>(p.C2 + (size_t)m * p.ldc + n) = w;
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) {
+            c[e] = v[e];
+            if (c2) c2[e] = w[e];
+          }
       }
     }
   }
 }
-
-// vector rows need every row of C (and C2) to start 8-byte aligned and N even; float4 when 16-byte / multiple of 4
-__device__ __forceinline__ bool epilogue_rows_ok(const GemmParams& p) { return !(p.N & 1) && !(p.ldc & 1); }
 
 // One K-chunk of MFMAs from the LDS image (shared by the GEMM kernels).
 // PF = false: fragments of a k-step are read right before its MFMAs (what the compiler schedules best for occupancy).
@@ -192,7 +166,7 @@ __device__ __forceinline__ void mfma_chunk(const float* a, const float* b, const
       for (int i = 0; i < WBM; ++i)
 #pragma unroll
         for (int jn = 0; jn < WBN; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][c], fb[cur][jn][c], acc[i][jn], 0, 0, 0);
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cur][jn][c], fa[cur][i][c], acc[i][jn], 0, 0, 0);   // D^T: see gemm_epilogue
   }
 }
 
@@ -387,10 +361,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     }
   }
 
-  if (epilogue_rows_ok(p))   // block-uniform; the main loop ended on a barrier, so the LDS images are free
-    gemm_epilogue_rows<BM, BN, WBM, WBN, 256, 2 * (BM + BN) * BK>(p, acc, lds, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
-  else
-    gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+  gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -520,10 +491,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       }
     }
   }
-  // float4 rows through LDS (every path above ended on a barrier; K % 4 == 0 is a precondition of this kernel)
-  GemmParams q{};
+  GemmParams q{};   // float4 rows (K % 4 == 0 is a precondition of this kernel)
   q.C = out; q.M = p.N; q.N = p.K; q.ldc = p.K; q.act = ACT_NONE;
-  gemm_epilogue_rows<BM, BN, WBM, WBN, 256, 2 * (BM + BN) * BK>(q, acc, lds, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  gemm_epilogue<WBM, WBN>(q, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -671,10 +641,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
     }
   }
 
-  if (epilogue_rows_ok(p))   // the chunk loop ended on a barrier
-    gemm_epilogue_rows<BM, BN, WBM, WBN, 256, 2 * (BM + BN) * BK>(p, acc, lds, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
-  else
-    gemm_epilogue<BM, BN, WBM, WBN>(p, acc, m0, n0, wm, wn, fr, fq);
+  gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
 }
 
 template <int BM, int BN, int BK, int AMODE, bool PF = false>
