@@ -770,7 +770,7 @@ const char* gemm_instance_name(const GemmParams& p) {
   }
   const Tile t = pick_tile(p);
   if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true>");
-  else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.amode);
+  else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false>", t.bm, t.bn, t.bk, p.amode);   // as rocprofv3 prints it
   return buf;
 }
 
