@@ -514,23 +514,26 @@ int fusion_kv(avsep_ctx* c, const Workspace& w, const float* visual, int B, int 
 }
 
 // CrossModalFusion.forward (model.py:145-149) in place on x; final LayerNorm written to w.ln.
+int fusion_layer(avsep_ctx* c, const Workspace& w, float* x, int B, int T, int i, hipStream_t s) {
+  const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
+  const FusLayerW& L = c->f_layers[i];
+  RCK(run_ln_linear(c, x, L.g1, L.be1, w.ln, L.wq, L.bq, w.f_q, M, d, ACT_NONE, s));       // norm1 -> q proj
+  const float* kk = w.kv_all + (size_t)i * 2 * d;
+  RCK(run_attention(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, d, B, T, T, s));
+  GemmParams po = linear_params(w.att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
+  po.R = x; po.ldr = d;
+  RCK(run_gemm(c, po, s));
+  RCK(run_ln_linear(c, x, L.g2, L.be2, w.ln, L.w1, L.b1, w.ffn, M, 4 * d, ACT_GELU, s));   // norm2 -> ff.0
+  GemmParams p2 = linear_params(w.ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
+  p2.R = x; p2.ldr = d;
+  RCK(run_gemm(c, p2, s));
+  return record_tap(c, w, ("f_layer" + std::to_string(i)).c_str(), x, (size_t)M * d, s);
+}
+
 int fusion_layers(avsep_ctx* c, const Workspace& w, float* x, int B, int T, hipStream_t s, bool final_norm) {
   if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
-  const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
-  for (int i = 0; i < c->Lf; ++i) {
-    const FusLayerW& L = c->f_layers[i];
-    RCK(run_ln_linear(c, x, L.g1, L.be1, w.ln, L.wq, L.bq, w.f_q, M, d, ACT_NONE, s));       // norm1 -> q proj
-    const float* kk = w.kv_all + (size_t)i * 2 * d;
-    RCK(run_attention(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, d, B, T, T, s));
-    GemmParams po = linear_params(w.att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
-    po.R = x; po.ldr = d;
-    RCK(run_gemm(c, po, s));
-    RCK(run_ln_linear(c, x, L.g2, L.be2, w.ln, L.w1, L.b1, w.ffn, M, 4 * d, ACT_GELU, s));   // norm2 -> ff.0
-    GemmParams p2 = linear_params(w.ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
-    p2.R = x; p2.ldr = d;
-    RCK(run_gemm(c, p2, s));
-    RCK(record_tap(c, w, ("f_layer" + std::to_string(i)).c_str(), x, (size_t)M * d, s));
-  }
+  const int d = c->d, M = B * T;
+  for (int i = 0; i < c->Lf; ++i) RCK(fusion_layer(c, w, x, B, T, i, s));
   if (final_norm) {   // stand-alone CrossModalFusion: materialise fusion.norm; the full forward fuses it into the decoder
     RCK(run_layernorm(c, x, c->fn_g, c->fn_b, w.ln, M, d, s));
     RCK(record_tap(c, w, "f_norm", w.ln, (size_t)M * d, s));
@@ -615,15 +618,22 @@ int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const flo
     RCK(decoder_stage(c, w, w.a_x, masks, sep, B, T, sa, /*fuse_norm=*/true));
     return AVSEP_OK;
   }
-  const int b1 = (B + 1) / 2;   // clips [0,b1) on sa, [b1,B) on sv
-  int r0 = fusion_layers(c, w, w.a_x, b1, T, sa, false);
-  if (r0 == AVSEP_OK) r0 = decoder_stage(c, w, w.a_x, masks, sep, b1, T, sa, true);
-  stamp(c, 7, sa);
+  // clips [0,b1) on sa, [b1,B) on sv.  The two halves are enqueued layer by layer, the side stream's first: a graph
+  // replay submits its nodes in capture order (~0.8 us each), and with one half captured after the other the second
+  // one started ~10 us late and finished last (device stamps).
+  const int b1 = (B + 1) / 2;
+  if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
   const Workspace w1 = shift_rows(c, w, b1, T);
   stamp(c, 6, sv);
-  int r1 = fusion_layers(c, w1, w1.a_x, B - b1, T, sv, false);
+  int r0 = AVSEP_OK, r1 = AVSEP_OK;
+  for (int i = 0; i < c->Lf; ++i) {
+    if (r1 == AVSEP_OK) r1 = fusion_layer(c, w1, w1.a_x, B - b1, T, i, sv);
+    if (r0 == AVSEP_OK) r0 = fusion_layer(c, w, w.a_x, b1, T, i, sa);
+  }
   if (r1 == AVSEP_OK)
     r1 = decoder_stage(c, w1, w1.a_x, masks + (size_t)b1 * T * SF, sep + (size_t)b1 * T * SF, B - b1, T, sv, true);
+  if (r0 == AVSEP_OK) r0 = decoder_stage(c, w, w.a_x, masks, sep, b1, T, sa, true);
+  stamp(c, 7, sa);
   stamp(c, 8, sv);
   hipError_t et = hipEventRecord(c->ev_tdone[p], sv);
   hipError_t eu = hipStreamWaitEvent(sa, c->ev_tdone[p], 0);
