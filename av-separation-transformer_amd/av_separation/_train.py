@@ -4,8 +4,9 @@ What the reference gets from torch autograd over torch.nn modules (demo.py:83-11
 332-353) is rebuilt here as a composition of hand-written HIP ops (C ABI section "training ops" of
 include/avsep.h), each wrapped in a ``torch.autograd.Function`` whose forward AND backward are HIP kernels:
 
-    Linear / Conv1d / Conv2d   im2col (HIP) + fp32-MFMA GEMM; backward dX = dY W, dW = dY^T X on the same GEMM
-                               through HIP transposes, bias gradient by a deterministic column reduction
+    Linear / Conv1d / Conv2d   im2col (HIP) + fp32-MFMA GEMM; backward dX = dY W on the same GEMM, dW = dY^T X on the
+                               k-major weight-gradient kernel (no transposed copies), bias gradient by a
+                               deterministic column reduction
     LayerNorm, BatchNorm2d(train: batch statistics, running-stat update), ReLU/GELU/sigmoid, attention
     (forward keeps the log-sum-exp; backward recomputes the scores), average pool, linear interpolation,
     mask * mixed

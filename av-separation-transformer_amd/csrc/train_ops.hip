@@ -2,7 +2,8 @@
 // pieces that the inference path fuses away or never needs.  Round-1 goal is a CORRECT fwd+bwd with gradient
 // parity against the reference (tests/golden/train_*.npz); each op is its own launch, driven from Python
 // autograd wrappers (av_separation/_train.py).  All dense contractions, forward and backward, still run on
-// the fp32-MFMA GEMM of gemm.hip (dX = dY W, dW = dY^T X through transposed operands).
+// the fp32-MFMA kernels of gemm.hip (dX = dY W on gemm_kernel; dW = dY^T X on wgrad_kernel, which reads both operands
+// as they lie in memory -- the transposing path below is only used when N is not a multiple of 4).
 //
 // Layout convention: every activation is a row tensor [rows][C] (channels last), so conv layers become
 // im2col + GEMM and their backward col2im + GEMM; BatchNorm / bias / LayerNorm-affine gradients are
