@@ -76,8 +76,17 @@ def test_fuzz_training_gradients_against_torch_cpu_port(case):
     for k, v in state.items():
         if v.is_floating_point() and "running_" not in k and not k.endswith(".pe"):
             v.requires_grad_()
-    rsep, _ = torch_cpu.forward_train(state, torch.from_numpy(mixed), torch.from_numpy(lips), cfg["nhead"],
-                                      cfg["num_speakers"])
+    torch_cpu.RELU_PROBE = []
+    try:
+        rsep, _ = torch_cpu.forward_train(state, torch.from_numpy(mixed), torch.from_numpy(lips), cfg["nhead"],
+                                          cfg["num_speakers"])
+        nearest_kink = min(torch_cpu.RELU_PROBE)
+    finally:
+        torch_cpu.RELU_PROBE = None
+    # A ReLU input within rounding of 0: that unit's mask bit is not determined at fp32, and one flipped bit moves a
+    # whole row of a weight gradient by O(1) of its size (case 98: one hidden unit, one row of linear1.weight off by
+    # 5 %, everything else at 1e-3).  Such cases are compared in the L2 norm instead of element by element.
+    kinky = nearest_kink < 2e-6
     rloss = SeparationLoss(0.5)(rsep, tg)
     rloss.backward()
     sep, _ = m(torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev))
@@ -90,9 +99,13 @@ def test_fuzz_training_gradients_against_torch_cpu_port(case):
         if ref is None:                             # e.g. no layers -> parameter unused on both sides
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        err = maxabs(p.grad.cpu().numpy(), ref.numpy()) / max(1e-3, float(ref.abs().max()))
+        if kinky:
+            err = float((p.grad.cpu() - ref).norm()) / max(1e-3, float(ref.norm()))
+            assert err < 5e-2, (k, err, "L2", cfg, dm)
+        else:
+            err = maxabs(p.grad.cpu().numpy(), ref.numpy()) / max(1e-3, float(ref.abs().max()))
+            assert err < 5e-3, (k, err, cfg, dm)
         worst = max(worst, err)
-        assert err < 5e-3, (k, err, cfg, dm)
     for k, v in m.state_dict().items():
         if "running_" in k:
             assert maxabs(v.cpu().numpy(), state[k].numpy()) < 1e-4, (k, cfg, dm)
