@@ -109,7 +109,46 @@ def _sinusoid_table(d_model, max_len=_MAX_LEN):
     return table.unsqueeze(0)
 
 
-class _Node(nn.Module):
+# Every structural change of a module tree built here (a parameter / buffer / sub-module assigned, registered, deleted,
+# or moved by .to() / .float() / ..., which REPLACES buffer tensors) bumps this counter; the engines cache their flat
+# (key, tensor) lists against it, so the per-call "did a weight change?" check is a 15 us walk over cached tensors
+# (data_ptr + version) instead of a 120 us state_dict() traversal -- a third of the host cost of a graph-replayed step.
+_STRUCT_EPOCH = [0]
+
+
+class _Tracked(nn.Module):
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, nn.Module)) or name in self.__dict__.get("_parameters", ()) or \
+                name in self.__dict__.get("_buffers", ()) or name in self.__dict__.get("_modules", ()):
+            _STRUCT_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _STRUCT_EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        _STRUCT_EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        _STRUCT_EPOCH[0] += 1
+        super().register_buffer(name, tensor, persistent=persistent)
+
+    def add_module(self, name, module):
+        _STRUCT_EPOCH[0] += 1
+        super().add_module(name, module)
+
+    def _apply(self, fn, *args, **kwargs):
+        _STRUCT_EPOCH[0] += 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        _STRUCT_EPOCH[0] += 1          # copies in place (version bump) -- belt and braces for assign=True loads
+        return super()._load_from_state_dict(*args, **kwargs)
+
+
+class _Node(_Tracked):
     """Bare container: only there so dotted state_dict keys match the reference's module tree."""
 
 
@@ -165,6 +204,7 @@ class _Engine:
         self.ws = None
         self.taps = False
         self.static = None     # graph-replay buffers
+        self._flat, self._flat_epoch = None, -1
 
     # -- lifetime
     def _create(self, device):
@@ -191,20 +231,21 @@ class _Engine:
 
     def __getstate__(self):   # copy.deepcopy / pickle of a module: the copy gets a fresh native context
         state = self.__dict__.copy()
-        state.update(ctx=None, device=None, sig=None, ws=None, static=None)
+        state.update(ctx=None, device=None, sig=None, ws=None, static=None, _flat=None, _flat_epoch=-1)
         return state
 
     # -- weights
     def _tensors(self):
-        owner = self._owner_ref
-        for k, v in owner.state_dict(keep_vars=True).items():
-            if k.endswith("num_batches_tracked"):
-                continue
-            yield self.prefix + k, v
+        if self._flat is None or self._flat_epoch != _STRUCT_EPOCH[0]:
+            owner = self._owner_ref
+            self._flat = [(self.prefix + k, v) for k, v in owner.state_dict(keep_vars=True).items()
+                          if not k.endswith("num_batches_tracked")]
+            self._flat_epoch = _STRUCT_EPOCH[0]
+        return self._flat
 
     def sync_weights(self, device, stream):
-        tensors = list(self._tensors())
-        sig = tuple((k, v.data_ptr(), v._version) for k, v in tensors)
+        tensors = self._tensors()
+        sig = (self._flat_epoch,) + tuple((v.data_ptr(), v._version) for _, v in tensors)
         if self.ctx is None or self.device != device:
             self._create(device)
         if sig == self.sig:
@@ -285,7 +326,7 @@ def _stream(device):
 
 
 # --------------------------------------------------------------------------------------- public modules
-class PositionalEncoding(nn.Module):
+class PositionalEncoding(_Tracked):
     """x + pe[:, :L] (model.py:283-301).  Stand-alone it is pure tensor plumbing (one broadcast add); inside
     the encoders the add is fused into the producing GEMM's epilogue."""
 
@@ -303,7 +344,7 @@ class PositionalEncoding(nn.Module):
         return y
 
 
-class AudioEncoder(nn.Module):
+class AudioEncoder(_Tracked):
     """(B, freq_bins, T) -> (B, T, d_model): Conv1d-ReLU-Conv1d-ReLU, PE, pre-norm encoder layers."""
 
     def __init__(self, freq_bins: int = 257, d_model: int = 256, nhead: int = 4,
@@ -335,7 +376,7 @@ class AudioEncoder(nn.Module):
         return out
 
 
-class VisualEncoder(nn.Module):
+class VisualEncoder(_Tracked):
     """(B, N, H, W) lip frames -> (B, target_len, d_model)."""
 
     def __init__(self, d_model: int = 256, nhead: int = 4, num_layers: int = 2, dropout: float = 0.1):
@@ -368,7 +409,7 @@ class VisualEncoder(nn.Module):
         return out
 
 
-class CrossModalFusion(nn.Module):
+class CrossModalFusion(_Tracked):
     """audio (B,T,d) queries visual (B,T,d) keys/values -> (B,T,d)."""
 
     def __init__(self, d_model: int = 256, nhead: int = 4, num_layers: int = 2, dropout: float = 0.1):
@@ -398,7 +439,7 @@ class CrossModalFusion(nn.Module):
         return out
 
 
-class SeparationDecoder(nn.Module):
+class SeparationDecoder(_Tracked):
     """fused (B,T,d) -> masks (B,S,F,T) in [0,1]; ``separate`` applies them to the mixture."""
 
     def __init__(self, d_model: int = 256, freq_bins: int = 257, num_speakers: int = 2, dropout: float = 0.1):
@@ -433,7 +474,7 @@ class SeparationDecoder(nn.Module):
         return masks * mixed_spec.unsqueeze(1)
 
 
-class AVSeparationTransformer(nn.Module):
+class AVSeparationTransformer(_Tracked):
     """``model(mixed_spec (B,F,T), lip_frames (B,N,H,W)) -> (separated, masks)``, each (B,S,F,T)."""
 
     def __init__(self, freq_bins: int = 257, d_model: int = 256, nhead: int = 4, num_encoder_layers: int = 2,
