@@ -352,3 +352,34 @@ def test_input_plumbing_and_multiple_models(dev):
         assert torch.equal(k4, k1)
     rs, rm = _oracle(m1, mixed, lips, 4, 2)
     assert maxabs(k1.cpu().numpy(), rm) < MASK_TOL
+
+
+def test_cached_weight_list_follows_structural_changes(dev):
+    """The engine caches its flat (key, tensor) list against a structure epoch (model.py::_Tracked).  Replacing a
+    Parameter OBJECT, replacing buffer tensors through .double().float(), and re-registering a buffer must all reach the
+    packed weights -- a stale cache would keep computing with the old tensors."""
+    kw = dict(freq_bins=33, d_model=64, nhead=4, num_encoder_layers=1, num_fusion_layers=1, num_speakers=2)
+    m = _random_model(dev, seed=3, **kw)
+    mixed, lips = seeded.inputs(8, 2, 33, 20, 6, 16, 16)
+
+    def run():
+        with torch.no_grad():
+            sep, masks = m(t(mixed, dev), t(lips, dev))
+        rs, rm = _oracle(m, mixed, lips, kw["nhead"], kw["num_speakers"])
+        assert maxabs(masks.cpu().numpy(), rm) < MASK_TOL
+        return masks.clone()
+
+    a = run()
+    node = getattr(m.decoder.decoder, "3")
+    node.bias = torch.nn.Parameter(torch.full_like(node.bias, 0.7))            # a NEW Parameter object
+    b = run()
+    assert not torch.equal(a, b)
+    m.double().float()                                                            # every buffer tensor is replaced
+    bn = getattr(m.visual_encoder.conv, "1")
+    bn.running_mean.add_(0.25)                                                    # in place on the NEW buffer object
+    c = run()
+    assert not torch.equal(b, c)
+    del bn.running_var
+    bn.register_buffer("running_var", torch.full((32,), 2.0, device=dev))       # re-registered buffer
+    d = run()
+    assert not torch.equal(c, d)
