@@ -104,6 +104,7 @@ struct avsep_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gin = nullptr, ev_gout = nullptr;
   hipEvent_t ev_vdone[MAX_SPLIT] = {}, ev_pdone[MAX_SPLIT] = {}, ev_adone[MAX_SPLIT] = {}, ev_tdone[MAX_SPLIT] = {};
   bool no_fused_conv = false;                      // developer A/B switch (AVSEP_NO_FUSED_CONV)
+  bool capturing = false;                          // inside avsep_forward_graph's stream capture
   bool tail_split = true;                          // fusion+decoder: half the batch per stream after the join
   std::vector<GraphEntry> graphs;
   // live per-kernel profiler (HIP events around every launch, on the launch's own stream)
@@ -649,7 +650,9 @@ int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const flo
 // microseconds of MFMA work wrapped in a fixed prologue/epilogue; running several shards' kernels
 // concurrently fills those bubbles (DESIGN.md "batch shards").
 int pick_split(const avsep_ctx* c, int B) {
-  if (c->keep_taps || c->prof_on) return 1;
+  // batch shards are an eager-mode developer switch only: capturing 4+ forked streams into one graph crashed inside
+  // the runtime (segfault in replay) and never paid off anyway (0.57 -> 0.62 -> 0.85 ms)
+  if (c->keep_taps || c->prof_on || c->capturing) return 1;
   int p = c->split;
   if (p <= 0) p = 1;
   if (p > avsep_ctx::MAX_SPLIT) p = avsep_ctx::MAX_SPLIT;
@@ -980,6 +983,7 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
                         size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) try {
   RCK(check_common(c, B, T));
   if (c->keep_taps || c->prof_on) return fail(AVSEP_EINVAL, "debug taps / profiler are not available under graph replay");
+  c->capturing = false;   // (a capture that ended in an exception would have left it set)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   GraphEntry* hit = nullptr;
   for (auto& g : c->graphs)
@@ -990,7 +994,9 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
     // capture on the context's own stream (the caller's may be the legacy stream, which cannot capture)
     hipGraph_t graph = nullptr;
     HCK(hipStreamBeginCapture(c->gstream, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
     int r = forward_impl(c, mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, c->gstream);
+    c->capturing = false;
     hipError_t e = hipStreamEndCapture(c->gstream, &graph);
     if (r != AVSEP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
     HCK(e);
