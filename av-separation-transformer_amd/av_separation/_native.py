@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("AVSEP_LIB") or os.path.join(os.path.dirname(_HERE), "
 
 # every symbol include/avsep.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "avsep_abi_version", "avsep_last_error", "avsep_create", "avsep_destroy", "avsep_set_weight",
+    "avsep_abi_version", "avsep_last_error", "avsep_build_id", "avsep_create", "avsep_destroy", "avsep_set_weight",
     "avsep_finalize_weights", "avsep_workspace_bytes", "avsep_forward", "avsep_forward_graph",
     "avsep_audio_encoder", "avsep_visual_encoder", "avsep_fusion", "avsep_decoder",
     "avsep_set_debug_taps", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_layernorm",
@@ -52,6 +52,7 @@ def load():
     p, i, i64, sz, fp = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_void_p
     lib.avsep_abi_version.restype = i
     lib.avsep_last_error.restype = C.c_char_p
+    lib.avsep_build_id.restype = C.c_char_p
     lib.avsep_create.argtypes = [C.POINTER(AvsepConfig), C.POINTER(p)]
     lib.avsep_destroy.argtypes = [p]
     lib.avsep_destroy.restype = None
@@ -115,7 +116,7 @@ def load():
     lib.avsep_op_layernorm_bwd.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, i, i, f, p]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)     # AttributeError here = ABI drift between header and library
-        if fn.restype is C.c_int and name not in ("avsep_abi_version",):
+        if fn.restype is C.c_int and name not in ("avsep_abi_version", "avsep_build_id"):
             fn.restype = i
     if lib.avsep_abi_version() != 1:
         raise RuntimeError("libavsep_hip.so ABI version mismatch")

@@ -351,18 +351,19 @@ class SyncBatchNormReluFn(torch.autograd.Function):
         xh, y = torch.empty_like(x), torch.empty_like(x)
         _ck(lib.avsep_op_bn_apply(x.data_ptr(), mean.data_ptr(), var.data_ptr(), g.data_ptr(), b.data_ptr(),
                                   xh.data_ptr(), y.data_ptr(), M, Cc, eps, 1, _st(x)), "bn_apply")
+        # `total` (rows of all ranks; ragged shards are legal) stays on the device: no host sync per BatchNorm layer
         with torch.no_grad():
-            n = float(total)
+            unbias = total / torch.clamp(total - 1.0, min=1.0)
             rmean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
-            rvar.mul_(1.0 - momentum).add_(var, alpha=momentum * n / max(n - 1.0, 1.0))
-        ctx.eps, ctx.group, ctx.inv_count = eps, group, 1.0 / float(total)
-        ctx.save_for_backward(y, xh, g, var)
+            rvar.mul_(1.0 - momentum).add_(var * unbias, alpha=momentum)
+        ctx.eps, ctx.group = eps, group
+        ctx.save_for_backward(y, xh, g, var, (1.0 / total).reshape(1))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .parallel import all_reduce_sum_
-        y, xh, g, var = ctx.saved_tensors
+        y, xh, g, var, inv_total = ctx.saved_tensors
         dy = _c(dy)
         M, Cc = y.shape
         lib = _lib()
@@ -373,8 +374,9 @@ class SyncBatchNormReluFn(torch.autograd.Function):
                                      sums[Cc:].data_ptr(), s.data_ptr(), M, Cc, 1, _st(y)), "bn_bwd_sums")
         local = sums.clone()              # parameter gradients stay per-rank; the bucket all-reduce averages them
         all_reduce_sum_(sums, ctx.group)
+        sums = sums * inv_total           # the 1/rows factor applied on the device (the row count never visits the host)
         _ck(lib.avsep_op_bn_bwd_dx(dyr.data_ptr(), xh.data_ptr(), g.data_ptr(), var.data_ptr(), sums.data_ptr(),
-                                   sums[Cc:].data_ptr(), dx.data_ptr(), M, Cc, ctx.inv_count, ctx.eps, _st(y)),
+                                   sums[Cc:].data_ptr(), dx.data_ptr(), M, Cc, 1.0, ctx.eps, _st(y)),
             "bn_bwd_dx")
         return dx, local[Cc:].clone(), local[:Cc].clone(), None, None, None, None, None
 
@@ -682,6 +684,21 @@ def _tensors(module):
     return dict(module.named_parameters()), dict(module.named_buffers())
 
 
+def _on_device(fn):
+    """Run a forward entry point with its tensors' device current: the op ABI has no device argument (launches,
+    hipFuncSetAttribute and occupancy queries act on the current device), so a model on cuda:1 called while cuda:0 is
+    current would launch on the wrong GPU.  The backward needs no guard of its own: autograd runs each node on the
+    worker thread of the device its forward ran on."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(mod, x, *args, **kwargs):
+        with torch.cuda.device(x.device):
+            return fn(mod, x, *args, **kwargs)
+    return wrapped
+
+
+@_on_device
 def train_forward(model, mixed, lips, seed=None, group=None):
     """AVSeparationTransformer.forward (model.py:268-276) with autograd through the HIP ops: train-mode semantics
     (dropout, BatchNorm batch statistics) when ``model.training``, eval semantics otherwise.
@@ -707,6 +724,7 @@ def train_forward(model, mixed, lips, seed=None, group=None):
 
 
 # ---- the stand-alone stage modules (the reference's tests and users call them directly, in train mode by default)
+@_on_device
 def audio_encoder_forward(mod, x, seed=None):
     P, Bf = _tensors(mod)
     B, Fq, T = x.shape
@@ -715,6 +733,7 @@ def audio_encoder_forward(mod, x, seed=None):
     return a.view(B, T, mod.d_model)
 
 
+@_on_device
 def visual_encoder_forward(mod, frames, T, seed=None):
     P, Bf = _tensors(mod)
     drop = make_drop(mod, (mod.dropout_p,), seed)
@@ -722,6 +741,7 @@ def visual_encoder_forward(mod, frames, T, seed=None):
     return v.view(frames.shape[0], T, mod.d_model)
 
 
+@_on_device
 def fusion_forward(mod, audio, visual, seed=None):
     P, _ = _tensors(mod)
     B, T, d = audio.shape
@@ -731,6 +751,7 @@ def fusion_forward(mod, audio, visual, seed=None):
     return out.view(B, T, d)
 
 
+@_on_device
 def decoder_forward(mod, fused, seed=None):
     P, _ = _tensors(mod)
     B, T, d = fused.shape

@@ -147,6 +147,23 @@ class _Tracked(nn.Module):
         _STRUCT_EPOCH[0] += 1          # copies in place (version bump) -- belt and braces for assign=True loads
         return super()._load_from_state_dict(*args, **kwargs)
 
+    def train(self, mode: bool = True):
+        # A train() <-> eval() transition re-packs the weights on the next fused forward.  The per-call change check
+        # compares (data_ptr, _version) of every tensor, and writes through ``.data`` (EMA, clamps, hand-rolled
+        # loaders: ``p.data.mul_()``, ``p.data.copy_()``) do not bump ``_version`` -- the usual place for such writes
+        # is a training loop, which ends with ``.eval()``.
+        if bool(mode) != self.training:
+            _STRUCT_EPOCH[0] += 1
+        return super().train(mode)
+
+    def invalidate_weights(self):
+        """Force the next fused forward to re-pack the weights.  Needed only after in-place writes through ``.data``
+        (or raw pointers) while the module stays in eval mode: those bypass autograd's version counter, which is what
+        the per-call change check reads.  ``optimizer.step()``, ``load_state_dict``, ``.to()`` and in-place ops under
+        ``torch.no_grad()`` are detected without it."""
+        _STRUCT_EPOCH[0] += 1
+        return self
+
 
 class _Node(_Tracked):
     """Bare container: only there so dotted state_dict keys match the reference's module tree."""

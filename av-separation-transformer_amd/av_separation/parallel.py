@@ -178,7 +178,10 @@ class DataParallel(nn.Module):
                     dist.broadcast(h, src, group=group)
                     t.copy_(h)
                 else:
-                    dist.broadcast(t.data, src, group=group)
+                    dist.broadcast(t, src, group=group)    # into the tensor itself: bumps its version counter, which
+                                                           # is what the fused path's weight-change check reads
+        if hasattr(module, "invalidate_weights"):
+            module.invalidate_weights()                    # ranks > 0 may have run a forward before being wrapped
         object.__setattr__(module, "_dp_group", group if (sync_bn and self.world > 1) else None)
         old = getattr(module, "_dp_buckets", None)
         if old is not None:               # re-wrapping the same module: the previous hooks would count arrivals twice

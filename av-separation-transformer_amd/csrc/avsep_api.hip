@@ -76,6 +76,7 @@ struct GraphEntry {
   size_t ws_bytes;
   int B, T, N, H, W;
   hipGraphExec_t exec;
+  hipStream_t last_stream;   // where the graph was launched last (drained before the exec is destroyed)
 };
 
 }  // namespace
@@ -97,14 +98,10 @@ struct avsep_ctx {
   std::vector<FusLayerW> f_layers;
   float *fn_g, *fn_b, *d_w1, *d_b1, *d_w2, *d_b2;
   // streams / events for the audio || visual fork-join and graph replay
-  static constexpr int MAX_SPLIT = 4;
-  int split = 1;                                   // batch shards per forward (measured: >1 is slower) (avsep_set_option "split")
+  int device = 0;                                  // the device the context (arena, streams, events, graphs) lives on
   hipStream_t side = nullptr, gstream = nullptr;
-  hipStream_t pstream[2 * MAX_SPLIT] = {};         // [2p], [2p+1]: audio / visual stream of shard p >= 1
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gin = nullptr, ev_gout = nullptr;
-  hipEvent_t ev_vdone[MAX_SPLIT] = {}, ev_pdone[MAX_SPLIT] = {}, ev_adone[MAX_SPLIT] = {}, ev_tdone[MAX_SPLIT] = {};
+  hipEvent_t ev_fork = nullptr, ev_vdone = nullptr, ev_adone = nullptr, ev_tdone = nullptr;
   bool no_fused_conv = false;                      // developer A/B switch (AVSEP_NO_FUSED_CONV)
-  bool capturing = false;                          // inside avsep_forward_graph's stream capture
   bool tail_split = true;                          // fusion+decoder: half the batch per stream after the join
   std::vector<GraphEntry> graphs;
   // live per-kernel profiler (HIP events around every launch, on the launch's own stream)
@@ -588,24 +585,24 @@ inline void stamp(avsep_ctx* c, int idx, hipStream_t s) {
 }
 
 int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const float* lips, float* masks, float* sep,
-                 int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv, int p) {
+                 int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv) {
   stamp(c, 1, sv);
   int rv = visual_branch(c, w, lips, B, N, H, W, T, sv);
   stamp(c, 2, sv);
   if (rv == AVSEP_OK) rv = fusion_kv(c, w, w.v_up, B, T, sv);
   stamp(c, 3, sv);
   // always join, even on error, so a capture in progress is not left forked
-  hipError_t ej = hipEventRecord(c->ev_vdone[p], sv);
+  hipError_t ej = hipEventRecord(c->ev_vdone, sv);
   stamp(c, 0, sa);
   int ra = audio_branch(c, w, mixed, B, T, sa);
   stamp(c, 4, sa);
-  hipError_t ew = hipStreamWaitEvent(sa, c->ev_vdone[p], 0);
+  hipError_t ew = hipStreamWaitEvent(sa, c->ev_vdone, 0);
   stamp(c, 5, sa);
   const bool tail_split = c->tail_split && B >= 2 && !c->keep_taps && !c->prof_on;
   hipError_t ea = hipSuccess, eb = hipSuccess;
   if (tail_split) {
-    ea = hipEventRecord(c->ev_adone[p], sa);
-    eb = hipStreamWaitEvent(sv, c->ev_adone[p], 0);
+    ea = hipEventRecord(c->ev_adone, sa);
+    eb = hipStreamWaitEvent(sv, c->ev_adone, 0);
   }
   if (rv != AVSEP_OK) return rv;
   if (ra != AVSEP_OK) return ra;
@@ -636,8 +633,8 @@ int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const flo
   if (r0 == AVSEP_OK) r0 = decoder_stage(c, w, w.a_x, masks, sep, b1, T, sa, true);
   stamp(c, 7, sa);
   stamp(c, 8, sv);
-  hipError_t et = hipEventRecord(c->ev_tdone[p], sv);
-  hipError_t eu = hipStreamWaitEvent(sa, c->ev_tdone[p], 0);
+  hipError_t et = hipEventRecord(c->ev_tdone, sv);
+  hipError_t eu = hipStreamWaitEvent(sa, c->ev_tdone, 0);
   stamp(c, 9, sa);
   if (r0 != AVSEP_OK) return r0;
   if (r1 != AVSEP_OK) return r1;
@@ -646,67 +643,41 @@ int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const flo
   return AVSEP_OK;
 }
 
-// Number of independent batch shards run on their own stream pairs.  At small batch every kernel is a few
-// microseconds of MFMA work wrapped in a fixed prologue/epilogue; running several shards' kernels
-// concurrently fills those bubbles (DESIGN.md "batch shards").
-int pick_split(const avsep_ctx* c, int B) {
-  // batch shards are an eager-mode developer switch only: capturing 4+ forked streams into one graph crashed inside
-  // the runtime (segfault in replay) and never paid off anyway (0.57 -> 0.62 -> 0.85 ms)
-  if (c->keep_taps || c->prof_on || c->capturing) return 1;
-  int p = c->split;
-  if (p <= 0) p = 1;
-  if (p > avsep_ctx::MAX_SPLIT) p = avsep_ctx::MAX_SPLIT;
-  if (p > B) p = B;
-  return p;
-}
-
-size_t carve_all(const avsep_ctx* c, int P, Workspace* parts, float* base, int B, int T, int N, int H, int W) {
-  size_t off = 0;
-  for (int p = 0; p < P; ++p) {
-    const int b0 = (int)((long)B * p / P), b1 = (int)((long)B * (p + 1) / P);
-    off += carve(c, parts ? &parts[p] : nullptr, base ? base + off : nullptr, b1 - b0, T, N, H, W);
-  }
-  return off;
-}
-
 int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
                  size_t ws_bytes, int B, int T, int N, int H, int W, hipStream_t s) {
   RCK(check_common(c, B, T));
   if (!mixed || !lips || !masks || !sep || !ws) return fail(AVSEP_EINVAL, "null tensor pointer");
-  const int P = pick_split(c, B);
-  Workspace w[avsep_ctx::MAX_SPLIT];
-  const size_t need = carve_all(c, P, w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float);
+  Workspace w;
+  const size_t need = carve(c, &w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float);
   if (ws_bytes < need) return fail(AVSEP_ENOMEM, "workspace too small: see avsep_workspace_bytes()");
   c->taps.clear();
   c->tap_cursor = 0;
   // profiling: park the stream so the launches below are already queued when the GPU reaches them
   if (c->prof_on) HCK(launch_delay(5000, s));
-  // fork every shard's streams off the caller's stream
+  // fork the side stream off the caller's stream; forward_part joins it back on every path (also on errors), so a
+  // capture in progress is never left with an un-joined stream
   HCK(hipEventRecord(c->ev_fork, s));
-  int rc = AVSEP_OK;
-  const size_t SF = (size_t)c->S * c->F;
-  for (int p = 0; p < P; ++p) {
-    const int b0 = (int)((long)B * p / P), b1 = (int)((long)B * (p + 1) / P);
-    hipStream_t sa = p == 0 ? s : c->pstream[2 * p];
-    hipStream_t sv = p == 0 ? c->side : c->pstream[2 * p + 1];
-    static const bool serial = getenv("AVSEP_SERIAL") != nullptr;   // developer A/B: everything on one stream
-    // the live profiler times every kernel alone on the chip: with two streams the 20x repeated launches of one
-    // branch would overlap the other branch's and inflate both (conv_stack's LDS footprint stalls the audio GEMMs)
-    if (serial || c->prof_on) sv = sa;
-    if (p) HCK(hipStreamWaitEvent(sa, c->ev_fork, 0));
-    HCK(hipStreamWaitEvent(sv, c->ev_fork, 0));
-    const int r = forward_part(c, w[p], mixed + (size_t)b0 * c->F * T, lips + (size_t)b0 * N * H * W,
-                               masks + (size_t)b0 * T * SF, sep + (size_t)b0 * T * SF, b1 - b0, T, N, H, W, sa, sv, p);
-    if (r != AVSEP_OK && rc == AVSEP_OK) rc = r;
-    if (p) {   // join the shard back into the caller's stream
-      hipError_t e1 = hipEventRecord(c->ev_pdone[p], sa);
-      hipError_t e2 = hipStreamWaitEvent(s, c->ev_pdone[p], 0);
-      if (rc == AVSEP_OK && e1 != hipSuccess) rc = fail_hip(e1, "hipEventRecord(shard done)");
-      if (rc == AVSEP_OK && e2 != hipSuccess) rc = fail_hip(e2, "hipStreamWaitEvent(shard done)");
-    }
-  }
-  return rc;
+  hipStream_t sv = c->side;
+  static const bool serial = getenv("AVSEP_SERIAL") != nullptr;   // developer A/B: everything on one stream
+  // the live profiler times every kernel alone on the chip: with two streams the 20x repeated launches of one
+  // branch would overlap the other branch's and inflate both (conv_stack's LDS footprint stalls the audio GEMMs)
+  if (serial || c->prof_on) sv = s;
+  HCK(hipStreamWaitEvent(sv, c->ev_fork, 0));
+  return forward_part(c, w, mixed, lips, masks, sep, B, T, N, H, W, s, sv);
 }
+
+// Guard for entry points that own device-wide state: makes the context's device current for the scope.
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 
 }  // namespace
 
@@ -737,6 +708,7 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   size_t off = 0;
   layout_arena(c, [&](size_t n) { off += align_up(n ? n : 1, 64); return (float*)nullptr; });
   c->arena_floats = off;
+  (void)hipGetDevice(&c->device);   // the caller's current device owns this context (model.py enters torch.cuda.device)
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->arena), off * sizeof(float));
   if (e != hipSuccess) { delete c; return fail_hip(e, "hipMalloc(weight arena)"); }
   off = 0;
@@ -744,19 +716,9 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_gin, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_gout, hipEventDisableTiming) == hipSuccess;
-  for (int p = 0; p < avsep_ctx::MAX_SPLIT && ok; ++p) {
-    ok = hipEventCreateWithFlags(&c->ev_vdone[p], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_pdone[p], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_adone[p], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_tdone[p], hipEventDisableTiming) == hipSuccess;
-    if (p && ok)
-      ok = hipStreamCreateWithFlags(&c->pstream[2 * p], hipStreamNonBlocking) == hipSuccess &&
-           hipStreamCreateWithFlags(&c->pstream[2 * p + 1], hipStreamNonBlocking) == hipSuccess;
-  }
-  if (const char* e = getenv("AVSEP_SPLIT")) c->split = atoi(e);
+            hipEventCreateWithFlags(&c->ev_vdone, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_adone, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_tdone, hipEventDisableTiming) == hipSuccess;
   if (const char* e = getenv("AVSEP_TAIL_SPLIT")) c->tail_split = atoi(e) != 0;
   c->no_fused_conv = getenv("AVSEP_NO_FUSED_CONV") != nullptr;
   if (getenv("AVSEP_STAMPS")) {
@@ -772,21 +734,19 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
 
 void avsep_destroy(avsep_ctx* c) {
   if (!c) return;
-  (void)hipDeviceSynchronize();   // work of this context may still be in flight on the caller's and the side streams
+  // Work of this context may still be in flight: on its own two streams, and on every caller stream a graph was
+  // replayed on.  Drain exactly those, on the context's own device (the caller's current device may be another GPU).
+  DeviceScope guard(c->device);
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  if (c->gstream) (void)hipStreamSynchronize(c->gstream);
+  for (auto& g : c->graphs) (void)hipStreamSynchronize(g.last_stream);
+  (void)hipDeviceSynchronize();   // eager forwards ran on caller streams this context keeps no record of
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->ev_gin) (void)hipEventDestroy(c->ev_gin);
-  if (c->ev_gout) (void)hipEventDestroy(c->ev_gout);
-  for (int p = 0; p < avsep_ctx::MAX_SPLIT; ++p) {
-    if (c->ev_vdone[p]) (void)hipEventDestroy(c->ev_vdone[p]);
-    if (c->ev_pdone[p]) (void)hipEventDestroy(c->ev_pdone[p]);
-    if (c->ev_adone[p]) (void)hipEventDestroy(c->ev_adone[p]);
-    if (c->ev_tdone[p]) (void)hipEventDestroy(c->ev_tdone[p]);
-    if (c->pstream[2 * p]) (void)hipStreamDestroy(c->pstream[2 * p]);
-    if (c->pstream[2 * p + 1]) (void)hipStreamDestroy(c->pstream[2 * p + 1]);
-  }
+  if (c->ev_vdone) (void)hipEventDestroy(c->ev_vdone);
+  if (c->ev_adone) (void)hipEventDestroy(c->ev_adone);
+  if (c->ev_tdone) (void)hipEventDestroy(c->ev_tdone);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->gstream) (void)hipStreamDestroy(c->gstream);
   if (c->arena) (void)hipFree(c->arena);
@@ -964,12 +924,7 @@ int avsep_finalize_weights(avsep_ctx* c, void* stream) try {
 
 size_t avsep_workspace_bytes(const avsep_ctx* c, int B, int T, int N, int H, int W) {
   if (!c || B <= 0 || T <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
-  size_t need = carve(c, nullptr, nullptr, B, T, N, H, W);          // unsplit layout (taps / profiler / stages)
-  for (int P = 2; P <= avsep_ctx::MAX_SPLIT; ++P) {
-    const size_t n = carve_all(c, P < B ? P : B, nullptr, nullptr, B, T, N, H, W);
-    if (n > need) need = n;
-  }
-  return need * sizeof(float);
+  return carve(c, nullptr, nullptr, B, T, N, H, W) * sizeof(float);
 }
 
 int avsep_forward(avsep_ctx* c, const float* mixed, const float* lips, float* masks, float* sep, void* ws,
@@ -983,7 +938,6 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
                         size_t ws_bytes, int B, int T, int N, int H, int W, void* stream) try {
   RCK(check_common(c, B, T));
   if (c->keep_taps || c->prof_on) return fail(AVSEP_EINVAL, "debug taps / profiler are not available under graph replay");
-  c->capturing = false;   // (a capture that ended in an exception would have left it set)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   GraphEntry* hit = nullptr;
   for (auto& g : c->graphs)
@@ -994,19 +948,18 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
     // capture on the context's own stream (the caller's may be the legacy stream, which cannot capture)
     hipGraph_t graph = nullptr;
     HCK(hipStreamBeginCapture(c->gstream, hipStreamCaptureModeThreadLocal));
-    c->capturing = true;
     int r = forward_impl(c, mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, c->gstream);
-    c->capturing = false;
     hipError_t e = hipStreamEndCapture(c->gstream, &graph);
     if (r != AVSEP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
     HCK(e);
-    GraphEntry g{mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, nullptr};
+    GraphEntry g{mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, nullptr, s};
     e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HCK(e);
     if (c->graphs.size() >= 8) {
-      // the evicted graph may still be replaying on the caller's stream: let it drain before its nodes are freed
-      (void)hipStreamSynchronize(s);
+      // the evicted graph may still be replaying on the stream it was last launched on (not necessarily this
+      // caller's): let it drain there before its nodes are freed
+      (void)hipStreamSynchronize(c->graphs.front().last_stream);
       (void)hipGraphExecDestroy(c->graphs.front().exec);
       c->graphs.erase(c->graphs.begin());
     }
@@ -1016,6 +969,7 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
   // Replay on the caller's own stream: no event fences between consecutive steps (the fenced hand-off to the
   // capture stream left a ~40-60 us bubble per step).  Only capture needs a non-legacy stream, launch does not.
   HCK(hipGraphLaunch(hit->exec, s));
+  hit->last_stream = s;
   return AVSEP_OK;
 } catch (...) {
   return on_exception();

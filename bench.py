@@ -88,6 +88,131 @@ def max_over_ranks(dist, seconds, dev):
     return float(t.item())
 
 
+def spawn_ranks(n, argv):
+    """Launcher half of `python bench.py --gpus N` (N > 1, no torchrun around it): run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <same arguments>` as a CHILD process -- never an exec, and before this process has touched the GPU -- with stdout /
+    stderr inherited, so rank 0's JSON line is the launcher's JSON line.  Returns the child's exit status (non-zero when
+    any rank failed: torchrun tears the others down)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL between processes on this stack
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def selftest_launch(rank, world, a):
+    """--selftest-launch: everything of the N>1 path except the GPU work, on gloo."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("AVSEP_SELFTEST_FAIL_RANK") == str(rank):      # a rank dying mid-run: the launcher must report it
+        os._exit(3)
+    dist.barrier()
+    elapsed = max_over_ranks(dist, 0.010 * (rank + 1), torch.device("cpu"))     # pretend rank r took 10*(r+1) ms
+    clips = list(shard_range(rank, world, 4))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "elapsed_max": elapsed, "rank0_clips": clips}))
+
+
+def host_cpu_info():
+    """Physical cores / logical CPUs / model name of this box's host CPU (BASELINE.md §3 wants them next to the CPU
+    baseline)."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return {"cpu_model": model, "host_cores": len(phys) or (os.cpu_count() or 1), "host_logical_cpus": logical or usable,
+            "usable_cpus": usable}
+
+
+def stream_leg(model, ds, B, dev, steps, inflight=2):
+    """--stream: the same forward fed like a service would feed it -- DISTINCT batches living in pinned host memory,
+    H2D of batch i+1 and D2H of batch i-1 on their own streams under the compute of batch i (double-buffered device
+    buffers, one hipGraph per buffer set).  Reported next to the resident-batch `value`, never instead of it."""
+    nb = 4                                                              # distinct host batches, cycled
+    host_in = []
+    for j in range(nb):
+        items = [ds[(j * B + i) % len(ds)] for i in range(B)]
+        host_in.append((torch.stack([it["mixed_spec"] for it in items]).contiguous().pin_memory(),
+                        torch.stack([it["lip_frames"] for it in items]).contiguous().pin_memory()))
+    _, F, T = host_in[0][0].shape
+    S = model.num_speakers
+    sets = []
+    for _ in range(inflight):
+        sets.append(dict(mixed=torch.empty(host_in[0][0].shape, device=dev), lips=torch.empty(host_in[0][1].shape, device=dev),
+                         masks=torch.empty(B, T, S, F, device=dev), sep=torch.empty(B, T, S, F, device=dev),
+                         h_masks=torch.empty(B, T, S, F).pin_memory(), h_sep=torch.empty(B, T, S, F).pin_memory(),
+                         ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_out=torch.cuda.Event()))
+    s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
+
+    def run(n):
+        for i in range(n):
+            st = sets[i % inflight]
+            hm, hl = host_in[i % nb]
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(st["ev_out"])                       # the previous occupant's outputs have left
+                st["mixed"].copy_(hm, non_blocking=True)
+                st["lips"].copy_(hl, non_blocking=True)
+                st["ev_in"].record(s_in)
+            with torch.cuda.stream(s_cmp), torch.no_grad():
+                s_cmp.wait_event(st["ev_in"])
+                model.run_static(st["mixed"], st["lips"], st["masks"], st["sep"], graph=True)
+                st["ev_done"].record(s_cmp)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(st["ev_done"])
+                st["h_masks"].copy_(st["masks"], non_blocking=True)
+                st["h_sep"].copy_(st["sep"], non_blocking=True)
+                st["ev_out"].record(s_out)
+        torch.cuda.synchronize()
+
+    for st in sets:
+        st["ev_out"].record(s_out)
+    run(2 * inflight + 2)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    in_mb = sum(t.numel() * 4 for t in host_in[0]) / 1e6
+    out_mb = 2 * sets[0]["masks"].numel() * 4 / 1e6
+    # the last batch's outputs against a resident re-run of the same batch: the streamed path computes the same bits
+    st = sets[(steps - 1) % inflight]
+    chk_m, chk_s = torch.empty_like(st["masks"]), torch.empty_like(st["sep"])
+    with torch.no_grad():
+        model.run_static(st["mixed"], st["lips"], chk_m, chk_s, graph=False)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(chk_m.cpu(), st["h_masks"]) and torch.equal(chk_s.cpu(), st["h_sep"]))
+    return {"value": round(B * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "distinct_batches": nb, "buffers_in_flight": inflight, "h2d_mb_per_step": round(in_mb, 2),
+            "d2h_mb_per_step": round(out_mb, 2), "pcie_gbs": round((in_mb + out_mb) * steps / dt / 1e3, 2),
+            "outputs_bit_equal_to_resident_run": same,
+            "note": "pinned host buffers, H2D / compute / D2H on three streams, PCIe-inclusive; not the headline value"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,15 +227,28 @@ def main():
     ap.add_argument("--mode", default="forward", choices=("forward", "train"),
                     help="forward = the headline metric; train = one DP training step per 'step' (row N1, not the headline)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode only (reference default 0.1)")
+    ap.add_argument("--stream", action="store_true",
+                    help="also time the PCIe-inclusive streamed mode (distinct pinned host batches, double-buffered "
+                         "H2D/D2H on side streams); reported as `stream` next to the resident-batch value")
+    ap.add_argument("--stream-steps", type=int, default=200)
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU-only check of the N>1 launch path (spawn, rendezvous, barrier, max-over-ranks, one JSON "
+                         "line): no GPU work, gloo backend; used by tests/test_shards_gloo.py")
     a = ap.parse_args()
     if a.mode == "train" and a.workload == "cfg2" and "--workload" not in " ".join(sys.argv):
         a.workload = "cfg4"
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call yet (importing
+        # torch does not initialise HIP), starts one fresh worker per GPU and relays their output and exit status.
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree")
+    if a.selftest_launch:
+        return selftest_launch(rank, world, a)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
     # rehearsal hook for the one-GPU test box (tests/test_bench_gpu.py): all ranks on device 0, gloo instead of RCCL
@@ -204,13 +342,20 @@ def main():
     }
 
     # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same command
-    # (tools/pmc_bench.sh -> profiles/pmc_hbm_traffic.json; counters cannot be read from inside the process)
+    # (tools/pmc_bench.sh -> profiles/pmc_hbm_traffic.json; counters cannot be read from inside the process).  The file
+    # carries the build id of the library it was measured on: a different loaded library gets no traffic figure.
+    from av_separation import _native
+    build_id = _native.load().avsep_build_id().decode()
+    roofline["library_build_id"] = build_id
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))["kernels"]
-        hit = pmc.get(dom["name"])
-        if hit:
+        pmc_file = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        hit = pmc_file["kernels"].get(dom["name"])
+        if pmc_file.get("build_id") != build_id:
+            roofline["traffic_note"] = (f"profiles/pmc_hbm_traffic.json was measured on build {pmc_file.get('build_id')}, "
+                                        f"the loaded library is {build_id}: traffic withheld (re-run tools/pmc_bench.sh)")
+        elif hit:
             roofline["traffic"] = round(hit["fetch_bytes_per_launch"] + hit["write_bytes_per_launch"])
-            roofline["traffic_unit"] = "HBM-side bytes per launch (PMC, profiles/pmc_hbm_traffic.json)"
+            roofline["traffic_unit"] = "HBM-side bytes per launch (PMC, profiles/pmc_hbm_traffic.json, same build id)"
             roofline["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["calls"])
     except (OSError, KeyError, ValueError):
         pass
@@ -230,6 +375,11 @@ def main():
                      "tflops": round(k["tflops"], 2), "gbs": round(k["gbs"], 1)} for k in kernels],
     }
 
+    if rank == 0 and world == 1 and a.stream:
+        out["stream"] = stream_leg(model, ds, B, dev, a.stream_steps)
+        with torch.cuda.stream(stream), torch.no_grad():           # leave the resident batch's outputs behind again
+            model.run_static(mixed, lips, masks, sep, graph=graph)
+        torch.cuda.synchronize()
     if rank == 0 and world == 1 and not a.no_cpu:
         clean = torch.stack([it["clean_specs"] for it in items])
         out["cpu_baseline"] = cpu_baseline(model, mixed, lips, masks, sep, clean, mk, B, a.cpu_seconds)
@@ -356,7 +506,8 @@ def cpu_train_baseline(model, mixed, lips, targets, mk, B, dropout, budget_s):
         times.append(time.perf_counter() - t0)
     torch.set_num_threads(avail)
     best = min(times)
-    return {"value": round(B / best, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+    return {"value": round(B / best, 3), "unit": "clips/s", "cores": threads, "threads": threads, **host_cpu_info(),
+            "kind": "port",
             "sample": f"{len(times)} training steps of the same {B}-clip batch, best {best:.2f} s "
                       f"(torch {torch.__version__} CPU autograd, fp32, dropout {dropout})"}
 
@@ -382,11 +533,14 @@ def cpu_baseline(model, mixed, lips, masks_gpu, sep_gpu, clean, mk, B, budget_s)
     # for these small ops, so pick the fastest of a few counts first and report the one used
     avail = torch.get_num_threads()
     best_t, threads = None, avail
-    for n in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
+    swept = sorted({c for c in (8, 16, 32, 64, avail) if c <= avail})
+    for n in swept:
         torch.set_num_threads(n)
+        t0 = time.perf_counter()
         run()
+        reps = 3 if time.perf_counter() - t0 < 0.5 else 1      # big configs: one timed run per count bounds the sweep
         dt = float("inf")
-        for _ in range(3):                       # best of 3: single timings on a shared host are noisy
+        for _ in range(reps):                    # best of 3: single timings on a shared host are noisy
             t0 = time.perf_counter()
             run()
             dt = min(dt, time.perf_counter() - t0)
@@ -407,10 +561,11 @@ def cpu_baseline(model, mixed, lips, masks_gpu, sep_gpu, clean, mk, B, budget_s)
     quality = {"si_snr_i_db_gpu": round(si_snr_improvement(got_sep, mx, clean), 4),
                "si_snr_i_db_cpu": round(si_snr_improvement(ref_sep, mx, clean), 4),
                "weights": "random init (torch.manual_seed(0)): the pair shows parity of the metric, not separation quality"}
-    return {"value": round(B / med, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+    return {"value": round(B / med, 2), "unit": "clips/s", "cores": threads, "threads": threads, **host_cpu_info(),
+            "kind": "port",
             "sample": f"{len(times)} forwards of the same {B}-clip batch, median {med * 1e3:.1f} ms "
-                      f"(torch {torch.__version__} CPU, eval/no_grad/fp32, fused encoder fast path; best of "
-                      f"8/16/32/64/{avail} threads)",
+                      f"(torch {torch.__version__} CPU, eval/no_grad/fp32, fused encoder fast path; `cores` = the "
+                      f"thread count used = fastest of {swept} threads; host_cores = physical cores of the box)",
             "gpu_masks_max_abs_err_vs_cpu": float((got - ref_masks).abs().max()),
             "gpu_separated_max_abs_err_vs_cpu": float((got_sep - ref_sep).abs().max()), **quality}
 

@@ -52,6 +52,9 @@ typedef struct avsep_ctx avsep_ctx;
 
 int avsep_abi_version(void);
 const char* avsep_last_error(void);
+/* 16 hex digits: hash of the kernel sources this library was built from (csrc/Makefile).  Measurement hygiene only:
+ * profiles/pmc_hbm_traffic.json is stamped with it and bench.py reports PMC traffic only for a matching library. */
+const char* avsep_build_id(void);
 
 /* One context per device & model.  Allocates (hipMalloc) the packed-weight arena. */
 int avsep_create(const avsep_config* cfg, avsep_ctx** out);

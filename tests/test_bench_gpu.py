@@ -40,14 +40,18 @@ def test_bench_single_gpu_contract_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["gpu_masks_max_abs_err_vs_cpu"] < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["forward", "train"])
-def test_bench_two_rank_rehearsal(mode):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    args = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2"]
+@pytest.mark.parametrize("mode,launcher", [("forward", "self"), ("forward", "torchrun"), ("train", "self")])
+def test_bench_two_rank_rehearsal(mode, launcher):
+    """`self`: plain `python bench.py --gpus 2` (the driver's observed form) -- bench.py spawns its own ranks;
+    `torchrun`: launched under torch.distributed.run (the contract's documented form)."""
+    args = ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    if launcher == "torchrun":
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        args = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)] + args
     if mode == "train":
         args += ["--mode", "train", "--batch", "2"]
     out = _run(args, {"AVSEP_BENCH_REHEARSAL": "1"})

@@ -49,6 +49,37 @@ def test_two_rank_sharding_and_max_time(tmp_path):
     assert abs(world * batch * 1 / r["tmax"] - 3200.0) < 1e-6
 
 
+def _bench(args, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_plain_bench_gpus2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it (how the driver calls it): the parent spawns one worker
+    per rank before any GPU call and relays rank 0's single JSON line; --selftest-launch stops short of the GPU work."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    rc, lines, err = _bench(["--gpus", "2", "--selftest-launch"], env)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    assert abs(lines[0]["elapsed_max"] - 0.020) < 1e-12 and lines[0]["rank0_clips"] == [0, 1, 2, 3]
+
+
+def test_plain_bench_propagates_a_worker_failure():
+    rc, lines, _ = _bench(["--gpus", "2", "--selftest-launch"], {"AVSEP_SELFTEST_FAIL_RANK": "1"})
+    assert rc != 0 and not lines
+
+
+def test_world_size_mismatch_is_an_error():
+    rc, lines, err = _bench(["--gpus", "2", "--selftest-launch"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and "disagree" in err
+
+
 def test_flops_per_clip_matches_survey_table():
     import bench
     f = bench.flops_per_clip

@@ -31,5 +31,7 @@ js={n:{"calls_per_forward":calls[n]/fw,
        "fetch_bytes_per_launch":c.get("FETCH_SIZE",0)*1024*2/max(1,calls[n]),
        "write_bytes_per_launch":c.get("WRITE_SIZE",0)*1024/max(1,calls[n]),
        "l2_hit_rate":c.get("TCC_HIT_sum",0)/max(1,c.get("TCC_HIT_sum",0)+c.get("TCC_MISS_sum",0))} for n,c in tot.items()}
-json.dump({"note":"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes over `bench.py --no-graph`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream)","kernels":js}, open(OUT+"/pmc_hbm_traffic.json","w"), indent=1)
+import subprocess, sys
+bid=subprocess.run([sys.executable,"-c","import sys;sys.path.insert(0,'%s/av-separation-transformer_amd');from av_separation import _native;print(_native.load().avsep_build_id().decode())"%R],capture_output=True,text=True).stdout.strip()
+json.dump({"build_id":bid,"note":"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes over `bench.py --no-graph`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream)","kernels":js}, open(OUT+"/pmc_hbm_traffic.json","w"), indent=1)
 PY
