@@ -280,12 +280,18 @@ def make_losses(outdir):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def make_train(outdir):
+def make_train(outdir, only=None):
     """Train-mode forward + backward of the reference (dropout 0 so it is deterministic, as in the reference's own
     gradient tests, tests/test_model.py:195,338): BatchNorm batch statistics, SeparationLoss(0.5), every
     parameter gradient, updated BN buffers.  Pins the N1 training path."""
-    for name, base, full in (("tiny", "tiny", True), ("odd", "odd", False)):
+    # cfg4 = BASELINE configs[3]'s model (d=512, 6+4 layers, 3 speakers) at B=2: pins the long-K weight-gradient paths,
+    # the d=512 LayerNorm backward and the L=251 attention backward against the reference itself
+    for name, base, full in (("tiny", "tiny", True), ("odd", "odd", False), ("cfg4", "cfg4", False)):
+        if only not in (None, "train", "train_" + name):
+            continue
         c = dict(CONFIGS[base], seed=CONFIGS[base]["seed"] + 100)
+        if name == "cfg4":
+            c["B"] = 2
         shapes = seeded.model_shapes(c["F"], c["d"], c["h"], c["Le"], c["Lf"], c["S"])
         state = seeded.fill_state(shapes, c["seed"], gain=1.0)
         m = build_reference(c, state).train()
@@ -298,14 +304,22 @@ def make_train(outdir):
         loss.backward()
         out = {"config": np.array(json.dumps(c)), "targets": tg, "loss": np.float64(loss.item()),
                "gain": np.float64(1.0)}
-        out["separated"] = sep.detach().contiguous().numpy()
-        out["masks"] = masks.detach().contiguous().numpy()
+        if name == "cfg4":       # big outputs: strided slices (tests/helpers.sliced, step 7) + fp64 checksums
+            for nm, a_ in (("separated", sep), ("masks", masks)):
+                a_ = a_.detach().contiguous().numpy()
+                out[nm + ".slice"] = a_.reshape(-1)[::7].copy()
+                out[nm + ".sum"] = np.float64(a_.astype(np.float64).sum())
+        else:
+            out["separated"] = sep.detach().contiguous().numpy()
+            out["masks"] = masks.detach().contiguous().numpy()
         for k, p_ in m.named_parameters():
             g_ = p_.grad.numpy()
             if full:
                 out["g." + k] = g_
             else:
-                out["g." + k + ".slice"] = g_.reshape(-1)[::5].copy()
+                step = 5 if name != "cfg4" else max(5, g_.size // 2000) | 1      # <= ~2000 samples per tensor
+                out["g." + k + ".slice"] = g_.reshape(-1)[::step].copy()
+                out["g." + k + ".step"] = np.int64(step)
                 out["g." + k + ".norm"] = np.float64(np.linalg.norm(g_.astype(np.float64)))
         for k, v in m.state_dict().items():
             if "running_" in k or k.endswith("num_batches_tracked"):
@@ -353,8 +367,8 @@ def main():
         make_losses(a.out)
     if a.only in (None, "eval"):
         make_eval(a.out)
-    if a.only in (None, "train"):
-        make_train(a.out)
+    if a.only is None or a.only.startswith("train"):
+        make_train(a.out, a.only)
 
 
 if __name__ == "__main__":

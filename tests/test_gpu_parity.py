@@ -20,7 +20,7 @@ from oracle import seeded
 
 pytestmark = pytest.mark.gpu
 
-MASK_TOL = 1e-5          # typical gate; BASELINE's hard gate is 1e-4
+MASK_TOL = 4e-6          # 10x the worst error observed on any fixture (4e-7); BASELINE's hard gate is 1e-4
 FULL = ["fwd_tiny", "fwd_odd", "fwd_down", "fwd_t1", "trained_tiny"]
 BIG = ["fwd_cfg1", "fwd_cfg3", "fwd_cfg4", "fwd_cfg5"]
 
@@ -134,6 +134,65 @@ def test_full_batch_properties_cfg2(dev):
     rs, rm = onp.forward(state, mixed[:2].cpu().numpy(), lips[:2].cpu().numpy(), 4, 2)
     assert maxabs(masks[:2].cpu().numpy(), rm) < MASK_TOL
     assert maxabs(sep[:2].cpu().numpy(), rs) < MASK_TOL * float(mixed.max())
+
+
+@pytest.mark.parametrize("wl", ["cfg3", "cfg5"])
+def test_full_batch_properties_big_configs(golden, dev, wl):
+    """BASELINE configs[2] / [4] at their FULL per-GPU batch (64 / 32 clips, M = 16 k rows: the large-tile GEMM, the
+    long-sequence attention and the M-dependent tile choices run here): determinism, clip independence bit for bit
+    against sub-batches, and clip 0 against the reference's B=1 golden of the same clip."""
+    import bench
+    g = golden("fwd_" + wl)
+    c = g["config"]
+    B = bench.WORKLOADS[wl]["batch"]
+    m = build_model(g, dev)
+    mx0, lp0 = golden_inputs(g)                                  # the golden's single clip = clip 0 of the batch
+    mx, lp = seeded.inputs(c["seed"] + 1000, B, c["F"], c["T"], c["N"], c["H"], c["W"])
+    mx[0], lp[0] = mx0[0], lp0[0]
+    mixed, lips = t(mx, dev), t(lp, dev)
+    with torch.no_grad():
+        sep, masks = m(mixed, lips)
+        sep2, masks2 = m(mixed, lips)
+        assert torch.equal(masks, masks2) and torch.equal(sep, sep2)                # run-to-run determinism
+        assert float(masks.min()) >= 0.0 and float(masks.max()) <= 1.0
+        assert torch.equal(sep, masks * mixed.unsqueeze(1))
+        for sl in (slice(0, 1), slice(B - 3, B), slice(B // 2, B // 2 + 17)):     # sub-batches: other tiles, same bits
+            s1, m1 = m(mixed[sl], lips[sl])
+            assert torch.equal(m1, masks[sl]) and torch.equal(s1, sep[sl]), sl
+    mk = masks[:1].contiguous().cpu().numpy()
+    sp = sep[:1].contiguous().cpu().numpy()
+    scale = max(1.0, float(np.abs(mx0).max()))
+    assert maxabs(sliced(mk, 7), g["masks.slice"]) < MASK_TOL
+    assert maxabs(sliced(sp, 7), g["separated.slice"]) < MASK_TOL * scale
+    assert abs(mk.astype(np.float64).sum() - g["masks.sum"]) < 1e-6 * g["masks.abssum"]
+
+
+def test_data_writes_are_picked_up_after_invalidate_or_mode_change(dev, golden):
+    """Writes through ``.data`` do not bump a tensor's version counter: ``invalidate_weights()`` or a
+    train() -> eval() transition re-packs; the result is checked against the oracle on the NEW weights."""
+    g = golden("fwd_tiny")
+    c = g["config"]
+    m = build_model(g, dev)
+    mixed, lips = golden_inputs(g)
+    x, y = t(mixed, dev), t(lips, dev)
+
+    def oracle_masks():
+        state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        return onp.forward(state, mixed, lips, c["h"], c["S"])[1]
+
+    with torch.no_grad():
+        _, m0 = m(x, y)
+        for p in m.parameters():
+            p.data.mul_(0.9)                                     # EMA / clamp style write: no version bump
+        m.invalidate_weights()
+        _, m1 = m(x, y)
+        assert maxabs(m1.cpu().numpy(), oracle_masks()) < MASK_TOL and not torch.equal(m0, m1)
+        m.train()
+        for p in m.parameters():
+            p.data.mul_(1.05)
+        m.eval()                                                 # the mode change re-packs without an explicit call
+        _, m2 = m(x, y)
+        assert maxabs(m2.cpu().numpy(), oracle_masks()) < MASK_TOL and not torch.equal(m1, m2)
 
 
 def test_weights_are_repacked_after_update(dev, golden):

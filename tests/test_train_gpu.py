@@ -24,7 +24,11 @@ def _build(g, dev):
     return m.to(dev).train()
 
 
-@pytest.mark.parametrize("name", ["train_tiny", "train_odd"])
+GRAD_TOL = 5e-5     # relative to the largest entry of each gradient tensor; observed 5e-6 (10x head-room, not 400x)
+MASK_TOL = 4e-6     # observed 4e-7
+
+
+@pytest.mark.parametrize("name", ["train_tiny", "train_odd", "train_cfg4"])
 def test_train_forward_backward_matches_reference(golden, name):
     from av_separation.losses import SeparationLoss
     g = golden(name)
@@ -34,8 +38,15 @@ def test_train_forward_backward_matches_reference(golden, name):
     mx, lp = seeded.inputs(c["seed"], c["B"], c["F"], c["T"], c["N"], c["H"], c["W"])
     sep, masks = m(torch.from_numpy(mx).to(dev), torch.from_numpy(lp).to(dev))
     assert sep.requires_grad and masks.shape == (c["B"], c["S"], c["F"], c["T"])
-    assert maxabs(masks.detach().cpu().numpy(), g["masks"]) < 1e-5
-    assert maxabs(sep.detach().cpu().numpy(), g["separated"]) < 1e-5 * max(1.0, float(np.abs(mx).max()))
+    scale = max(1.0, float(np.abs(mx).max()))
+    if "masks" in g:
+        assert maxabs(masks.detach().cpu().numpy(), g["masks"]) < MASK_TOL
+        assert maxabs(sep.detach().cpu().numpy(), g["separated"]) < MASK_TOL * scale
+    else:       # BASELINE-size fixture: strided slices + fp64 checksums
+        mk, sp = masks.detach().contiguous().cpu().numpy(), sep.detach().contiguous().cpu().numpy()
+        assert maxabs(mk.reshape(-1)[::7], g["masks.slice"]) < MASK_TOL
+        assert maxabs(sp.reshape(-1)[::7], g["separated.slice"]) < MASK_TOL * scale
+        assert abs(mk.astype(np.float64).sum() - float(g["masks.sum"])) < 1e-6 * mk.size
     loss = SeparationLoss(l1_weight=0.5)(sep, torch.from_numpy(g["targets"]).to(dev))
     assert abs(float(loss) - float(g["loss"])) < 2e-5
     loss.backward()
@@ -50,10 +61,11 @@ def test_train_forward_backward_matches_reference(golden, name):
         else:
             ref = g["g." + k + ".slice"]
             scale = max(1e-3, float(np.abs(ref).max()))
-            err = maxabs(got.reshape(-1)[::5], ref) / scale
-            assert abs(np.linalg.norm(got.astype(np.float64)) - g["g." + k + ".norm"]) < 1e-3 * max(1e-3, g["g." + k + ".norm"])
+            step = int(g["g." + k + ".step"]) if "g." + k + ".step" in g else 5
+            err = maxabs(got.reshape(-1)[::step], ref) / scale
+            assert abs(np.linalg.norm(got.astype(np.float64)) - g["g." + k + ".norm"]) < 1e-4 * max(1e-3, g["g." + k + ".norm"])
         worst = max(worst, err)
-        if err >= 2e-3:
+        if err >= GRAD_TOL:
             bad.append((k, round(err, 4)))
     assert not bad, bad                      # errors are relative to the largest gradient entry of each tensor
     # BatchNorm buffers after one training forward (momentum 0.1, unbiased variance)
@@ -199,13 +211,13 @@ def test_two_rank_data_parallel_step_matches_reference_full_batch(golden, tmp_pa
     g = golden("train_tiny")
     assert len(r0["buckets"]) >= 2
     assert abs(r0["loss"] - float(g["loss"])) < 2e-5
-    assert maxabs(torch.cat([r0["masks"], r1["masks"]]).numpy(), g["masks"]) < 1e-5
+    assert maxabs(torch.cat([r0["masks"], r1["masks"]]).numpy(), g["masks"]) < MASK_TOL
     worst = 0.0
     for k, got in r0["grads"].items():
         assert torch.equal(got, r1["grads"][k]), k
         ref = g["g." + k]
         worst = max(worst, maxabs(got.numpy(), ref) / max(1e-3, float(np.abs(ref).max())))
-    assert worst < 2e-3, worst
+    assert worst < GRAD_TOL, worst
     for k, v in r0["bufs"].items():
         assert maxabs(v.numpy(), g["buf." + k]) < 1e-5, k
         assert torch.equal(v, r1["bufs"][k])
