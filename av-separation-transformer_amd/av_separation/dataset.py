@@ -63,8 +63,7 @@ class SyntheticAVDataset(Dataset):
         patch[h0:h1, w0:w1] = np.clip(level + jitter, 0, 1)
         return patch
 
-    def __getitem__(self, idx: int):
-        rng = np.random.default_rng(idx)
+    def _voices(self, rng: np.random.Generator):
         amps = rng.uniform(0.3, 1.0, size=self.num_speakers)
         voices = []
         for f0, amp in zip(self.speaker_freqs, amps):
@@ -74,7 +73,18 @@ class SyntheticAVDataset(Dataset):
         mix = voices[0]
         for v in voices[1:]:
             mix = mix + v
-        mix = mix.astype(np.float32)
+        return voices, mix.astype(np.float32)
+
+    def waveforms(self, idx: int):
+        """The time-domain signals behind item ``idx`` -- (mixed (L,), clean (S, L)) float32 -- i.e. what the reference
+        feeds to ``_stft`` (dataset.py:74-89).  For producing spectrograms on the device with
+        ``av_separation.stft.stft_magnitude`` instead of on the host in ``__getitem__``."""
+        voices, mix = self._voices(np.random.default_rng(idx))
+        return torch.from_numpy(mix), torch.from_numpy(np.stack(voices, axis=0))
+
+    def __getitem__(self, idx: int):
+        rng = np.random.default_rng(idx)
+        voices, mix = self._voices(rng)
 
         mixed_spec = self._stft(mix)
         clean = np.stack([self._stft(v) for v in voices], axis=0)

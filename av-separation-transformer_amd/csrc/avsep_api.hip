@@ -1086,6 +1086,40 @@ int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const f
   return AVSEP_OK;
 }
 
+// ---------------------------------------------------------------------------------- STFT front-end
+int64_t avsep_stft_basis_floats(int n_fft) {
+  if (n_fft <= 0 || (n_fft & 31)) return fail(AVSEP_EINVAL, "n_fft must be a positive multiple of 32");
+  return (int64_t)2 * (n_fft / 2 + 1) * n_fft;
+}
+
+int avsep_stft_basis(float* basis, int n_fft, void* stream) {
+  if (!basis) return fail(AVSEP_EINVAL, "null pointer");
+  if (n_fft <= 0 || (n_fft & 31)) return fail(AVSEP_EINVAL, "n_fft must be a positive multiple of 32");
+  HCK(launch_stft_basis(basis, n_fft, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+// spec[b][f][t] = | sum_k hann[k] audio[b][t*hop + k] e^{-2 pi i f k / n_fft} |, samples beyond L read as zero,
+// T = 1 + L / hop frames (dataset.py:63-65, 122-135) -- one GEMM over overlapping rows of the waveform against the
+// windowed DFT basis, magnitude taken in the epilogue, output in the reference's (B, F, T) layout.
+int avsep_op_stft_mag(const float* audio, const float* basis, float* spec, int B, int L, int n_fft, int hop,
+                      void* stream) {
+  if (!audio || !basis || !spec) return fail(AVSEP_EINVAL, "null pointer");
+  if (B <= 0 || L <= 0 || hop <= 0) return fail(AVSEP_EINVAL, "B, L and hop must be positive");
+  if (n_fft <= 0 || (n_fft & 31)) return fail(AVSEP_EINVAL, "n_fft must be a positive multiple of 32");
+  if ((L & 3) || (hop & 3)) return fail(AVSEP_EINVAL, "clip length and hop must be multiples of 4 samples (16-byte loads)");
+  const int T = 1 + L / hop, F = n_fft / 2 + 1;
+  if ((long long)B * T > 0x7fffffffLL) return fail(AVSEP_EINVAL, "too many frames");
+  GemmParams p{};
+  p.A = audio; p.W = basis; p.C = spec;
+  p.M = B * T; p.N = 2 * F; p.K = n_fft;
+  p.lda = hop; p.ldw = n_fft; p.ldc = 2 * F;
+  p.amode = AMODE_FRAMES; p.T = T; p.frame_hop = hop; p.frame_len = L; p.mag_F = F;
+  p.act = ACT_NONE;
+  HCK(launch_gemm(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream) {
   if (!x || !y || B <= 0 || N <= 0 || T <= 0 || d <= 0) return fail(AVSEP_EINVAL, "bad argument");
   HCK(launch_interp_linear(x, y, B, N, T, d, reinterpret_cast<hipStream_t>(stream)));

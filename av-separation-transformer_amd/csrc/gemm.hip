@@ -25,6 +25,7 @@
 //     in the reference's (B,T,S,F) memory order.
 #include "kernels.h"
 #include <algorithm>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -59,12 +60,100 @@ __device__ __forceinline__ int xcd_tile(const GemmParams& p) {
 // per lane) costs one 4-byte store per element with 64-byte row pieces and was store-ISSUE bound: ~1/5 of a 64x64
 // tile's life (in-kernel clocks), 3-5 % of every step.  Same products in the same order: results are bit-identical.
 // `mw`, `nw`: the wave's offset inside the tile.
+template <int ACT>
+__device__ __forceinline__ float act_t(float v) {
+  if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+  if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// Straight-line epilogue for N % 4 == 0 (see the note on gemm_epilogue): every load of the tile is UNCONDITIONAL
+// (out-of-range rows / columns are clamped to the tile's last valid row / float4, a missing bias or residual reads the
+// same addresses of whatever pointer is valid and is discarded by a select), then the arithmetic, then the stores.
+template <int WBM, int WBN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], int mbase, int nbase,
+                                                   int fr, int fq) {
+  const bool has_b = p.bias != nullptr, has_r = p.R != nullptr;            // block-uniform
+  const float* bsrc = has_b ? p.bias : p.W;                               // W: at least N*K >= N floats, always readable
+  const float* rsrc = has_r ? p.R : p.C;
+  const int ldr = has_r ? p.ldr : p.ldc;
+  f32x4 bv[WBN], rv[WBM][WBN];
+  int mrow[WBM], ncol[WBN];
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    ncol[j] = nbase + 16 * j + 4 * fq;
+    bv[j] = *reinterpret_cast<const f32x4*>(bsrc + min(ncol[j], p.N - 4));
+  }
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    mrow[i] = mbase + 16 * i + fr;
+    const int mc = min(mrow[i], p.M - 1);
+    const int rr = (has_r && p.rperiod > 0) ? (mc % p.rperiod) : mc;
+#pragma unroll
+    for (int j = 0; j < WBN; ++j)
+      rv[i][j] = *reinterpret_cast<const f32x4*>(rsrc + (size_t)rr * ldr + min(ncol[j], p.N - 4));
+  }
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = has_b ? acc[i][j][e] + bv[j][e] : acc[i][j][e];
+        x = act_t<ACT>(x);
+        rv[i][j][e] = has_r ? x + rv[i][j][e] : x;
+      }
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j)
+      if (mrow[i] < p.M && ncol[j] < p.N) *reinterpret_cast<f32x4*>(p.C + (size_t)mrow[i] * p.ldc + ncol[j]) = rv[i][j];
+}
+
+// ORDER MATTERS: on CDNA loads and stores share one in-order counter (vmcnt), so a load issued after a store cannot be
+// waited for without also waiting for that store to be acknowledged by memory (1-2 us under load).  The first version
+// of this epilogue went block by block -- load bias / residual, compute, store -- and every block's loads waited for
+// the previous block's stores: 17.8 us of a 128x64 tile's 58.6 us life (in-kernel stamps, AVSEP_GEMM_DBG;
+// profiles/r02_gemm_phase_stamps.txt) -- and with loads on some control-flow path behind the stores, hipcc also drains
+// the counter (s_waitcnt vmcnt(0)) after every pair of stores.  The fast path below is straight-line code: ALL loads
+// of the tile (bias, residual / positional rows), then the arithmetic, then nothing but stores.
 template <int WBM, int WBN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], int m0, int n0, int mw,
                                               int nw, int fr, int fq) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const bool v4 = !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
+  if (p.mag_F > 0) {                            // block-uniform: STFT magnitude, (re, im) column pairs -> |.| at (b, f, t)
+#pragma unroll
+    for (int i = 0; i < WBM; ++i) {
+      const int m = m0 + mw + 16 * i + fr;
+      if (m >= p.M) continue;
+      const int b = m / p.T, t = m - b * p.T;
+#pragma unroll
+      for (int j = 0; j < WBN; ++j) {
+        const int n = n0 + nw + 16 * j + 4 * fq;
+        if (n >= p.N) continue;
+        const f32x4 v = acc[i][j];
+        const int f = n >> 1;
+        float* dst = p.C + ((size_t)b * p.mag_F + f) * p.T + t;
+        dst[0] = sqrtf(v[0] * v[0] + v[1] * v[1]);
+        if (f + 1 < p.mag_F) dst[p.T] = sqrtf(v[2] * v[2] + v[3] * v[3]);
+      }
+    }
+    return;
+  }
+  const bool v4 = !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));   // block-uniform
   const bool v2 = !(p.N & 1) && !(p.ldc & 1);
+  if (v4 && !p.C2 && !p.epi_general) {            // every GEMM of the model but the mask head
+    switch (p.act) {                              // block-uniform: one straight-line expansion per activation
+      case ACT_RELU: gemm_epilogue_fast<WBM, WBN, ACT_RELU>(p, acc, m0 + mw, n0 + nw, fr, fq); break;
+      case ACT_GELU: gemm_epilogue_fast<WBM, WBN, ACT_GELU>(p, acc, m0 + mw, n0 + nw, fr, fq); break;
+      case ACT_SIGMOID: gemm_epilogue_fast<WBM, WBN, ACT_SIGMOID>(p, acc, m0 + mw, n0 + nw, fr, fq); break;
+      default: gemm_epilogue_fast<WBM, WBN, ACT_NONE>(p, acc, m0 + mw, n0 + nw, fr, fq); break;
+    }
+    return;
+  }
+  // ---- general path: N not a multiple of 4 and / or the mask head's second output (separated = masks * mixture,
+  //      model.py:220), block by block
 #pragma unroll
   for (int i = 0; i < WBM; ++i) {
     const int m = m0 + mw + 16 * i + fr;
@@ -75,33 +164,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
       const int n = n0 + nw + 16 * j + 4 * fq;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
-      if (v4) {                                   // block-uniform
-        if (p.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
-        if (p.R) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rv[e];
-        }
-        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
-        if (p.C2) {
-          f32x4 w;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = v[e] * p.X[(size_t)m * p.ldx + (n + e) % p.F];
-          *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc + n) = w;
-        }
-        continue;
-      }
       float w[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool in = n + e < p.N;
-        float x = v[e] + ((p.bias && in) ? p.bias[n + e] : 0.0f);
+        float x = (p.bias && in) ? v[e] + p.bias[n + e] : v[e];
         x = apply_act(x, p.act);
         if (p.R && in) x += p.R[(size_t)rr * p.ldr + n + e];
         v[e] = x;
@@ -109,7 +176,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
       }
       float* c = p.C + (size_t)m * p.ldc + n;
       float* c2 = p.C2 ? p.C2 + (size_t)m * p.ldc + n : nullptr;
-      if (v2) {                                   // N even: the pairs (n, n+1), (n+2, n+3) are inside or outside whole
+      if (v4) {
+        *reinterpret_cast<f32x4*>(c) = v;
+        if (c2) *reinterpret_cast<f32x4*>(c2) = f32x4{w[0], w[1], w[2], w[3]};
+      } else if (v2) {                            // N even: the pairs (n, n+1), (n+2, n+3) are inside or outside whole
         *reinterpret_cast<f32x2*>(c) = f32x2{v[0], v[1]};
         if (c2) *reinterpret_cast<f32x2*>(c2) = f32x2{w[0], w[1]};
         if (n + 2 < p.N) {
@@ -177,9 +247,17 @@ __device__ __forceinline__ int swz(int row) {
   return SLOTS == 8 ? ((row >> 1) & 7) : (row & 15);
 }
 
+// Developer diagnostics (AVSEP_GEMM_DBG=1): one lane per workgroup stamps the 100 MHz wall clock at entry, after the
+// prologue (first chunk in LDS), after the K loop, after the epilogue's stores are issued and after they have
+// drained; launch_gemm() prints the per-phase statistics.  p.dbg is null in every normal launch.
+__device__ __forceinline__ void dbg_stamp(const GemmParams& p, int slot) {
+  if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+
 template <int BM, int BN, int BK, int AMODE, bool PF = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
+  dbg_stamp(p, 0);
   if (p.ksplit > 1) {                      // block-uniform: slice blockIdx.y of the contraction
     const int z = blockIdx.y;
     p.A += (size_t)z * p.kchunk;
@@ -231,6 +309,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
       a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;
       a_aux0[i] = m % p.T;
       a_aux1[i] = 0;
+    } else if (AMODE == AMODE_FRAMES) {
+      const int b = m / p.T, t = m - b * p.T;
+      a_src[i] = p.A + (size_t)b * p.frame_len;        // the clip; the frame offset is kept separately for the bound
+      a_aux0[i] = t * p.frame_hop + 4 * sslot;          // sample index of this thread's first float4
+      a_aux1[i] = 0;
     } else {
       const int hw = p.Hout * p.Wout;
       const int img = m / hw;
@@ -253,7 +336,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
   }
 
   const int nk = p.K / BK;
-  const int cpt = (AMODE == AMODE_PLAIN) ? nk : (p.Kt / BK);   // chunks per tap
+  const int cpt = (AMODE == AMODE_PLAIN || AMODE == AMODE_FRAMES) ? nk : (p.Kt / BK);   // chunks per tap
   int tap = 0, sub = 0;                                        // (tap, chunk-in-tap) of the NEXT chunk to load
   int kload = 0;                                               // index of the next chunk to load
 
@@ -273,6 +356,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
         const float* src = a_src[i] + (ptrdiff_t)(ok ? tap - 1 : 0) * p.lda + sub * BK;
         ra[slot][i] = *reinterpret_cast<const f32x4*>(src);
         rok[slot][i] = ok;
+      } else if (AMODE == AMODE_FRAMES) {
+        const int smp = a_aux0[i] + kload * BK;          // multiples of 4 throughout: a float4 is inside or outside whole
+        const bool ok = smp < p.frame_len;
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + (ok ? smp : 0));
+        rok[slot][i] = ok;
       } else {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int iy = a_aux0[i] + ky, ix = a_aux1[i] + kx;
@@ -285,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + kload * BK);
     ++kload;
-    if (AMODE != AMODE_PLAIN) {
+    if (AMODE == AMODE_TAPS3 || AMODE == AMODE_CONV2D) {
       if (++sub == cpt) { sub = 0; ++tap; }
     }
   };
@@ -330,6 +418,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     if (j < nk) load_chunk(j);
   store_chunk(0, 0);
   __syncthreads();
+  dbg_stamp(p, 1);
 
   // Steady state: groups of D chunks in which EVERY refill exists, so the loads are unconditional.  With a
   // conditional load in the loop body the compiler cannot know how many loads are outstanding at the ds_write that
@@ -361,7 +450,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
     }
   }
 
+  dbg_stamp(p, 2);
   gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  if (p.dbg) {                                                   // block-uniform, diagnostics only
+    dbg_stamp(p, 3);
+    __builtin_amdgcn_s_waitcnt(0);                               // vmcnt(0): the stores have left
+    __syncthreads();
+    dbg_stamp(p, 4);
+    if (threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -644,6 +741,292 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
   gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Large-tile instance on v_mfma_f32_32x32x2_f32 (BM x BN = 128 x 128 or 256 x 128, 4 wavefronts as 2 x 2, each wave a
+// (BM/2) x (BN/2) tile made of 32 x 32 MFMA blocks).  For the M ~ 16 k shapes of configs 3-5 and the training step.
+//   * Half the matrix instructions of the 16x16x4 form for the same tile (one 64-cycle MFMA per 32x32x2 product): the
+//     issue slots between MFMAs are what the fragment reads, the staging loads and the LDS writes of the next chunk
+//     live in, and a 64x64 wave tile needs only 8 ds_read_b128 per 32 MFMAs (2048 matrix cycles).
+//   * A chunk of BK = 32 is 4096 matrix cycles per wave, longer than an L2 / Infinity-Cache round trip, so the register
+//     ring is ONE chunk deep: loads of chunk c+1 are issued before the MFMAs of chunk c and written to the other LDS
+//     buffer after them (issue-early / write-late); 64 KB of LDS -> two workgroups per CU, whose barriers, prologues
+//     and epilogues overlap each other's MFMAs.
+//   * Same LDS image, same swizzle, same k order as gemm_kernel: lane (r = l&31, h = l>>5) reads the two float4 slots
+//     {4s+h, 4s+2+h} of k-step s and feeds component c of the first then of the second to consecutive MFMAs, i.e. the
+//     products enter every accumulator in the order k = 16s+c, +4, +8, +12 (c = 0..3) -- exactly the order of the
+//     16x16x4 kernels (their k index is the lane quarter), and both instructions are plain k-ordered fma chains, so the
+//     results are BIT-IDENTICAL across all tile shapes (tests/test_gpu_parity.py::test_op_linear_tiles_bit_identical).
+//   * Operands swapped like gemm_epilogue's: D[n][m], lane = output row m, registers 4g..4g+3 = columns
+//     n = 8g + 4h + (0..3): float4 stores, bias / residual read as float4.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm32_epilogue(const GemmParams& p, const f32x16 (&acc)[TM][TN], int m0, int n0, int mw,
+                                                int nw, int lr, int lh) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool v4 = !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
+  const bool v2 = !(p.N & 1) && !(p.ldc & 1);
+  constexpr int NP = 4 * TN;                    // float4 pieces per output row and lane
+  f32x4 bv[NP];
+  int ncol[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int n = n0 + nw + 32 * (q >> 2) + 8 * (q & 3) + 4 * lh;
+    ncol[q] = n;
+    bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) {
+      if (v4) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[q][e] = (n + e < p.N) ? p.bias[n + e] : 0.0f;
+      }
+    }
+  }
+  // one 32-row block at a time: all its loads, then all its stores (see gemm_epilogue: loads behind stores wait for
+  // the stores on CDNA's shared in-order memory counter)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + mw + 32 * i + lr;
+    if (m >= p.M) continue;
+    const int rr = p.rperiod > 0 ? (m % p.rperiod) : m;
+    f32x4 rv[NP], xv[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int n = ncol[q];
+      rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n >= p.N) continue;
+      if (p.R) {
+        if (v4) rv[q] = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + n);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rv[q][e] = (n + e < p.N) ? p.R[(size_t)rr * p.ldr + n + e] : 0.0f;
+        }
+      }
+      if (p.C2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[q][e] = (n + e < p.N) ? p.X[(size_t)m * p.ldx + (n + e) % p.F] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int n = ncol[q];
+      if (n >= p.N) continue;
+      const int j = q >> 2, g = q & 3;
+      f32x4 v, w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = acc[i][j][4 * g + e];
+        x = p.bias ? x + bv[q][e] : x;
+        x = apply_act(x, p.act);
+        if (p.R) x += rv[q][e];
+        v[e] = x;
+        w[e] = x * xv[q][e];
+      }
+      float* c = p.C + (size_t)m * p.ldc + n;
+      float* c2 = p.C2 ? p.C2 + (size_t)m * p.ldc + n : nullptr;
+      if (v4) {
+        *reinterpret_cast<f32x4*>(c) = v;
+        if (c2) *reinterpret_cast<f32x4*>(c2) = w;
+      } else if (v2) {
+        *reinterpret_cast<f32x2*>(c) = f32x2{v[0], v[1]};
+        if (c2) *reinterpret_cast<f32x2*>(c2) = f32x2{w[0], w[1]};
+        if (n + 2 < p.N) {
+          *reinterpret_cast<f32x2*>(c + 2) = f32x2{v[2], v[3]};
+          if (c2) *reinterpret_cast<f32x2*>(c2 + 2) = f32x2{w[2], w[3]};
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) {
+            c[e] = v[e];
+            if (c2) c2[e] = w[e];
+          }
+      }
+    }
+  }
+}
+
+// One BK = 32 chunk (two k-steps of 16) of 32x32x2 MFMAs from the swizzled LDS image.  PF: the fragments of the next
+// k-step are fetched before the MFMAs of the current one (second register set).
+template <int TM, int TN, bool PF>
+__device__ __forceinline__ void mfma32_chunk(const float* a, const float* b, const int (&a_off)[TM], const int (&a_swz)[TM],
+                                             const int (&b_off)[TN], const int (&b_swz)[TN], int lh,
+                                             f32x16 (&acc)[TM][TN]) {
+  constexpr int S = 2;   // BK / 16
+  f32x4 fa[PF ? 2 : 1][TM][2], fb[PF ? 2 : 1][TN][2];
+  auto fetch = [&](int s, int set) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        fa[set][i][q] = *reinterpret_cast<const f32x4*>(a + a_off[i] + (((4 * s + 2 * q + lh) ^ a_swz[i]) << 2));
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        fb[set][j][q] = *reinterpret_cast<const f32x4*>(b + b_off[j] + (((4 * s + 2 * q + lh) ^ b_swz[j]) << 2));
+  };
+  if (PF) fetch(0, 0);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int cur = PF ? (s & 1) : 0;
+    if (PF) {
+      if (s + 1 < S) {
+        fetch(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      fetch(s, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][j][q][c], fa[cur][i][q][c], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <int BM, int BN, int AMODE, bool PF>
+__global__ __launch_bounds__(256, BM * BN <= 128 * 128 ? 2 : 1) void gemm32_kernel(const GemmParams pin) {
+  GemmParams p = pin;
+  constexpr int BK = 32, SLOTS = 8, RPP = 32;
+  constexpr int APASS = BM / RPP, BPASS = BN / RPP;
+  constexpr int TM = BM / 64, TN = BN / 64;            // 32x32 blocks per wave (2 x 2 waves)
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * BK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + BN - 1) / BN;
+  const int tile = xcd_tile(p);
+  const int bm = tile / nbn;
+  const int bn = tile - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const int srow = tid >> 3;
+  const int sslot = tid & 7;
+  const float* a_src[APASS];
+  int a_t[APASS];                    // TAPS3: time index of the row
+  int a_st[APASS], b_st[BPASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int r = srow + RPP * i;
+    a_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    int m = m0 + r;
+    m = m < p.M ? m : p.M - 1;
+    a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;
+    a_t[i] = AMODE == AMODE_TAPS3 ? m % p.T : 0;
+  }
+  const float* b_src[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int r = srow + RPP * i;
+    b_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    b_src[i] = p.W + (size_t)n * p.ldw + 4 * sslot;
+  }
+  const int nk = p.K / BK;
+  const int cpt = (AMODE == AMODE_PLAIN) ? nk : (p.Kt / BK);   // chunks per tap
+  int tap = 0, sub = 0, kload = 0;
+
+  // register ring, two chunks deep: the LDS write of chunk c+1 (wherever the compiler schedules it inside the
+  // iteration) waits only for loads issued a whole iteration earlier, never for the ones just issued
+  f32x4 ra[2][APASS], rb[2][BPASS];
+  bool rok[2][APASS];
+  auto load_chunk = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      if (AMODE == AMODE_PLAIN) {
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + kload * BK);
+      } else {   // TAPS3: unconditional load from an always-valid address, zeroed at the LDS write when out of range
+        const int t = a_t[i] + tap - 1;
+        const bool ok = (t >= 0) && (t < p.T);
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + (ptrdiff_t)(ok ? tap - 1 : 0) * p.lda + sub * BK);
+        rok[slot][i] = ok;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + kload * BK);
+    ++kload;
+    if (AMODE != AMODE_PLAIN) {
+      if (++sub == cpt) { sub = 0; ++tap; }
+    }
+  };
+  auto store_chunk = [&](int slot, int buf) {
+    float* a = As + buf * BM * BK;
+    float* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      f32x4 v = ra[slot][i];
+      if (AMODE != AMODE_PLAIN) v = rok[slot][i] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(a + a_st[i]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<f32x4*>(b + b_st[i]) = rb[slot][i];
+  };
+
+  const int lr = lane & 31, lh = lane >> 5;
+  int a_off[TM], a_swz[TM], b_off[TN], b_swz[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * (BM / 2) + 32 * i + lr;
+    a_off[i] = r * BK;
+    a_swz[i] = swz<SLOTS>(r);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * (BN / 2) + 32 * j + lr;
+    b_off[j] = r * BK;
+    b_swz[j] = swz<SLOTS>(r);
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // chunk c lives in ring slot c & 1 and LDS buffer c & 1
+  load_chunk(0);
+  if (nk > 1) load_chunk(1);
+  store_chunk(0, 0);
+  __syncthreads();
+  auto step = [&](int j, bool refill, bool has_next) {       // j = parity of the current chunk (compile-time after unroll)
+    if (refill) load_chunk(j);                               // chunk kc+2 into the slot chunk kc left one iteration ago
+    mfma32_chunk<TM, TN, PF>(As + j * BM * BK, Bs + j * BN * BK, a_off, a_swz, b_off, b_swz, lh, acc);
+    if (has_next) store_chunk(j ^ 1, j ^ 1);                 // chunk kc+1: loaded one iteration ago
+    __syncthreads();
+  };
+  int kc = 0;
+  for (; kc + 4 <= nk; kc += 2) {     // steady state: every refill exists -> unconditional loads, counted vmcnt waits
+    step(0, true, true);
+    step(1, true, true);
+  }
+  for (; kc < nk; kc += 2) {          // tail (block-uniform conditions)
+    step(0, kc + 2 < nk, kc + 1 < nk);
+    if (kc + 1 < nk) step(1, kc + 3 < nk, kc + 2 < nk);
+  }
+
+  gemm32_epilogue<TM, TN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), lr, lh);
+}
+
+template <int BM, int BN, int AMODE, bool PF>
+hipError_t launch32_t(const GemmParams& p, hipStream_t s) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm32_kernel<BM, BN, AMODE, PF>), dim3(nbm * nbn), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
 template <int BM, int BN, int BK, int AMODE, bool PF = false>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -651,7 +1034,8 @@ hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-struct Tile { int bm, bn, bk; };
+struct Tile { int bm, bn, bk; };   // bm >= 128 && bn >= 128: the 32x32x2 large-tile kernel (gemm32_kernel)
+inline bool is_g32(const Tile& t) { return t.bm >= 128 && t.bn >= 128; }
 
 // Block tile and K-chunk for one launch.
 //  * (BM,BN): measured on MI355X (tools/gemm_sweep.py, profiles/r01a_gemm_tile_sweep.txt): what decides the
@@ -676,11 +1060,18 @@ Tile pick_tile(const GemmParams& p) {
   auto blocks = [&](int bm, int bn) { return slices * ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   static const long t64 = getenv("AVSEP_T64") ? atol(getenv("AVSEP_T64")) : 512;       // developer sweeps
   static const long t6432 = getenv("AVSEP_T6432") ? atol(getenv("AVSEP_T6432")) : 512;
+  // measured (profiles/r02_gemm_tile_sweep.txt): the 32x32x2 large-tile kernel is bit-identical but 3-8 % SLOWER than the
+  // 128x64 / 64x64 16x16x4 tiles on every cfg3-5 shape, so it is off unless a developer asks for it (AVSEP_T128)
+  static const long t128 = getenv("AVSEP_T128") ? atol(getenv("AVSEP_T128")) : 1L << 40;
+  static const long t256 = getenv("AVSEP_T256") ? atol(getenv("AVSEP_T256")) : 1L << 40;
   Tile pick{32, 32, 32};
-  if (blocks(128, 64) >= 2048) pick = Tile{128, 64, 32};
+  const bool g32_ok = (p.amode == AMODE_PLAIN || p.amode == AMODE_TAPS3) && slices == 1 && p.mag_F == 0;
+  if (g32_ok && blocks(256, 128) >= t256) pick = Tile{256, 128, 32};
+  else if (g32_ok && blocks(128, 128) >= t128) pick = Tile{128, 128, 32};
+  else if (blocks(128, 64) >= 2048) pick = Tile{128, 64, 32};
   else if (blocks(64, 64) >= t64) pick = Tile{64, 64, 32};
   else if (blocks(64, 32) >= t6432) pick = Tile{64, 32, 32};
-  const int kunit = p.amode == AMODE_PLAIN ? p.K : p.Kt;   // a chunk must not straddle a tap
+  const int kunit = (p.amode == AMODE_PLAIN || p.amode == AMODE_FRAMES) ? p.K : p.Kt;   // a chunk must not straddle a tap
   if (pick.bm + pick.bn <= 96 && kunit % 64 == 0) pick.bk = 64;
   return pick;
 }
@@ -761,6 +1152,11 @@ bool fragment_prefetch(const Tile& t, const GemmParams& p) {
   return t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && p.K >= kmin;
 }
 
+bool g32_prefetch() {
+  static const bool pf = getenv("AVSEP_G32_PF") ? atoi(getenv("AVSEP_G32_PF")) != 0 : true;   // developer A/B switch
+  return pf;
+}
+
 const char* gemm_instance_name(const GemmParams& p) {
   static thread_local char buf[64];
   if (p.ln_gamma) {
@@ -769,17 +1165,77 @@ const char* gemm_instance_name(const GemmParams& p) {
     return buf;
   }
   const Tile t = pick_tile(p);
-  if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true>");
+  if (is_g32(t)) snprintf(buf, sizeof buf, "gemm32_kernel<%d, %d, %d, %s>", t.bm, t.bn, p.amode, g32_prefetch() ? "true" : "false");
+  else if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true>");
   else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false>", t.bm, t.bn, t.bk, p.amode);   // as rocprofv3 prints it
   return buf;
 }
 
+hipError_t launch_gemm_impl(GemmParams p, hipStream_t s);
+
+// AVSEP_GEMM_DBG: run the launch with the stamp buffer, wait, print where a workgroup's life goes (10 ns ticks)
+hipError_t launch_gemm_dbg(const GemmParams& p_in, hipStream_t s) {
+  static unsigned long long* buf = nullptr;
+  const size_t cap = (size_t)1 << 20;   // workgroups
+  if (!buf && hipMalloc(reinterpret_cast<void**>(&buf), cap * 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+  GemmParams p = p_in;
+  p.dbg = buf;
+  (void)hipMemsetAsync(buf, 0, cap * 8 * sizeof(unsigned long long), s);
+  hipError_t e = launch_gemm_impl(p, s);
+  if (e != hipSuccess) return e;
+  (void)hipStreamSynchronize(s);
+  static int shown = 0;
+  if (shown++ % 16 != 8) return hipSuccess;          // one report per 16 launches, after warm-up
+  std::vector<unsigned long long> h(cap * 8);
+  (void)hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  unsigned long long t0 = ~0ull, t1 = 0;
+  size_t n = 0;
+  double pro = 0, loop = 0, epi = 0, drain = 0;
+  std::vector<std::pair<unsigned long long, unsigned long long>> spans;
+  for (size_t b = 0; b < cap; ++b) {
+    const unsigned long long* r = &h[b * 8];
+    if (!r[0] || !r[4]) continue;
+    ++n;
+    t0 = std::min(t0, r[0]); t1 = std::max(t1, r[4]);
+    pro += r[1] - r[0]; loop += r[2] - r[1]; epi += r[3] - r[2]; drain += r[4] - r[3];
+    spans.emplace_back(r[0], r[4]);
+  }
+  if (!n) return hipSuccess;
+  // resident workgroups over time, sampled: how long is the chip under-filled at the start / end of the launch?
+  const double span = (double)(t1 - t0);
+  fprintf(stderr, "[gemm dbg] %s M=%d N=%d K=%d: %zu workgroups, launch span %.2f us; mean per workgroup: prologue %.2f  loop %.2f  "
+                  "epilogue(issue) %.2f  store drain %.2f us (life %.2f us)\n", gemm_instance_name(p_in), p.M, p.N, p.K, n, span / 100,
+          pro / n / 100, loop / n / 100, epi / n / 100, drain / n / 100, (pro + loop + epi + drain) / n / 100);
+  const int NB = 24;
+  fprintf(stderr, "[gemm dbg] resident workgroups at %d sample points: ", NB);
+  for (int i = 0; i < NB; ++i) {
+    const unsigned long long t = t0 + (unsigned long long)(span * (i + 0.5) / NB);
+    size_t c = 0;
+    for (auto& sp : spans) c += (sp.first <= t && t < sp.second);
+    fprintf(stderr, "%zu ", c);
+  }
+  fprintf(stderr, "\n");
+  return hipSuccess;
+}
+
 hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
+  static const bool epi_general = getenv("AVSEP_EPI_GENERAL") != nullptr;   // developer A/B: block-by-block epilogue
+  p.epi_general = epi_general ? 1 : 0;
+  static const bool dbg = getenv("AVSEP_GEMM_DBG") != nullptr;
+  if (dbg && !p.dbg && !p.ln_gamma) return launch_gemm_dbg(p, s);
+  return launch_gemm_impl(p, s);
+}
+
+hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   static const bool no_remap = getenv("AVSEP_NO_XCD_REMAP") != nullptr;   // developer A/B switch
   p.no_xcd_remap = no_remap ? 1 : 0;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 31)) return hipErrorInvalidValue;
-  if (p.amode != AMODE_PLAIN && (p.Kt <= 0 || (p.Kt & 31))) return hipErrorInvalidValue;
+  if ((p.amode == AMODE_TAPS3 || p.amode == AMODE_CONV2D) && (p.Kt <= 0 || (p.Kt & 31))) return hipErrorInvalidValue;
+  if (p.amode == AMODE_FRAMES && (p.T <= 0 || p.frame_hop <= 0 || (p.frame_hop & 3) || p.frame_len <= 0 || (p.frame_len & 3)))
+    return hipErrorInvalidValue;
+  if (p.mag_F > 0 && ((p.N & 1) || p.N != 2 * p.mag_F || p.T <= 0 || p.bias || p.R || p.C2 || p.act != ACT_NONE))
+    return hipErrorInvalidValue;
   if (p.ksplit > 1) {
     if (p.amode != AMODE_PLAIN || p.bias || p.R || p.C2 || p.ln_gamma || p.act != ACT_NONE) return hipErrorInvalidValue;
     if (p.kchunk <= 0 || (p.kchunk & 63) || (long long)(p.ksplit - 1) * p.kchunk >= p.K) return hipErrorInvalidValue;
@@ -790,6 +1246,17 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   }
   const Tile t = pick_tile(p);
   if (p.K % t.bk) return hipErrorInvalidValue;
+  if (is_g32(t)) {
+    if ((p.amode != AMODE_PLAIN && p.amode != AMODE_TAPS3) || p.mag_F > 0 || p.ksplit > 1 || t.bk != 32 || t.bn != 128)
+      return hipErrorInvalidValue;
+    const bool pf = g32_prefetch();
+#define AVSEP_G32(BM_, AM_)                                                              \
+    if (t.bm == BM_ && p.amode == AM_)                                                   \
+      return pf ? launch32_t<BM_, 128, AM_, true>(p, s) : launch32_t<BM_, 128, AM_, false>(p, s);
+    AVSEP_G32(128, AMODE_PLAIN) AVSEP_G32(128, AMODE_TAPS3) AVSEP_G32(256, AMODE_PLAIN) AVSEP_G32(256, AMODE_TAPS3)
+#undef AVSEP_G32
+    return hipErrorInvalidValue;
+  }
   if (fragment_prefetch(t, p)) return launch_t<64, 64, 32, AMODE_PLAIN, true>(p, s);
 #define AVSEP_CASE(BM_, BN_, BK_, AM_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
@@ -804,6 +1271,8 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   AVSEP_MODES(32, 32, 64)
   AVSEP_CASE(32, 32, 128, AMODE_PLAIN)
   AVSEP_CASE(32, 32, 128, AMODE_TAPS3)
+  AVSEP_CASE(32, 32, 64, AMODE_FRAMES) AVSEP_CASE(64, 32, 64, AMODE_FRAMES) AVSEP_CASE(64, 64, 32, AMODE_FRAMES)
+  AVSEP_CASE(32, 32, 32, AMODE_FRAMES) AVSEP_CASE(64, 32, 32, AMODE_FRAMES) AVSEP_CASE(128, 64, 32, AMODE_FRAMES)
 #undef AVSEP_MODES
 #undef AVSEP_CASE
   return hipErrorInvalidValue;

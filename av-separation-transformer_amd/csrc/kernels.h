@@ -17,7 +17,7 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
 }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
-enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2 };
+enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2, AMODE_FRAMES = 3 };
 
 // C[M,N] = epilogue( A'[M,K] * W[N,K]^T ), fp32 in / fp32 accumulate on the matrix cores.
 // A' is A itself (PLAIN), a 3-tap shifted view of a (B,T,Kt) sequence tensor (TAPS3: Conv1d k=3 p=1 as one
@@ -40,7 +40,15 @@ struct GemmParams {
   float* C2;           // mask mode (SeparationDecoder.separate, model.py:220): C2 = C * X[m][n % F]
   const float* X;
   int ldx, F;
+  // FRAMES mode (STFT front-end, dataset.py:122-135): row m = (clip b, frame t) of T frames per clip is the window
+  // audio[b][t*frame_hop .. + K) of a (B, frame_len) signal -- overlapping rows read straight from the waveform, samples
+  // at or beyond frame_len read as zero (the reference zero-pads tail frames).  frame_hop % 4 == frame_len % 4 == 0.
+  // With mag_F > 0 the epilogue takes columns (2f, 2f+1) as (re, im) of bin f and stores |.| to C[(b*mag_F + f)*T + t],
+  // i.e. the reference's (B, F, T) spectrogram layout; bias / act / R / C2 are not used then.
+  int frame_hop, frame_len, mag_F;
   int no_xcd_remap;    // developer switch: 1 = launch-order tiles (A/B measurements)
+  int epi_general;           // developer A/B switch (AVSEP_EPI_GENERAL): 1 = block-by-block epilogue everywhere
+  unsigned long long* dbg;   // developer diagnostics (AVSEP_GEMM_DBG): per-workgroup phase stamps, null otherwise
   // Fused LayerNorm prologue (PLAIN mode, K == normalised width): A' = (A - mean_row) * rstd_row * gamma + beta,
   // row statistics computed in-kernel by a pre-pass over the block's rows (nn.LayerNorm, eps ln_eps).
   const float* ln_gamma;
@@ -112,6 +120,9 @@ hipError_t launch_conv_stack(const float* frames, const float* w1, const float* 
 // mean over P positions: x (M,P,C) -> y (M,C)
 hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);
+// Hann-windowed real-DFT basis [2*(n_fft/2+1)][n_fft]: row 2f = w[k] cos(2 pi f k / n_fft), row 2f+1 = -w[k] sin(..),
+// w = np.hanning(n_fft) (symmetric); evaluated in double precision, rounded once
+hipError_t launch_stft_basis(float* basis, int n_fft, hipStream_t s);
 
 hipError_t launch_delay(unsigned us, hipStream_t s);
 hipError_t launch_stamp(unsigned long long* buf, int idx, hipStream_t s);   // profiling aid, see rowops.hip

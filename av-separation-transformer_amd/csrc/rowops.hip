@@ -291,3 +291,28 @@ hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, i
   hipLaunchKernelGGL(scale_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, scale, scale_n);
   return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Hann-windowed real-DFT basis for the STFT front-end (dataset.py:122-135: np.hanning(n_fft) window, np.fft.rfft):
+// basis[2f][k] = w[k] cos(2 pi f k / n), basis[2f+1][k] = -w[k] sin(2 pi f k / n), w[k] = 0.5 - 0.5 cos(2 pi k / (n-1)).
+// Angles are reduced exactly in integers (f*k mod n) and evaluated in double precision; one rounding to fp32.
+namespace {
+__global__ __launch_bounds__(256) void stft_basis_kernel(float* __restrict__ basis, int n) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int F = n / 2 + 1;
+  if (idx >= (size_t)2 * F * n) return;
+  const int row = (int)(idx / n), k = (int)(idx - (size_t)row * n);
+  const int f = row >> 1;
+  const double two_pi = 6.283185307179586476925286766559;
+  const double w = n > 1 ? 0.5 - 0.5 * cos(two_pi * (double)k / (double)(n - 1)) : 1.0;
+  const double ang = two_pi * (double)(((long long)f * k) % n) / (double)n;
+  basis[idx] = (float)((row & 1) ? -w * sin(ang) : w * cos(ang));
+}
+}  // namespace
+
+hipError_t launch_stft_basis(float* basis, int n_fft, hipStream_t s) {
+  if (!basis || n_fft <= 0) return hipErrorInvalidValue;
+  const size_t n = (size_t)2 * (n_fft / 2 + 1) * n_fft;
+  hipLaunchKernelGGL(stft_basis_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, basis, n_fft);
+  return hipGetLastError();
+}

@@ -140,6 +140,21 @@ int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const f
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * STFT magnitude front-end: replaces SyntheticAVDataset._stft
+ * (/root/reference/src/av_separation/dataset.py:122-135) -- Hann(n_fft) window (np.hanning, symmetric), hop `hop`,
+ * T = 1 + L / hop frames (dataset.py:63-65), tail frames zero-padded, |rfft| -- for a batch of waveforms resident in
+ * HBM.  One fp32-MFMA GEMM of overlapping waveform rows against a windowed real-DFT basis, magnitude in the epilogue.
+ *   avsep_stft_basis_floats(n_fft)      floats the caller allocates for the basis (2*(n_fft/2+1) * n_fft)
+ *   avsep_stft_basis(basis, n_fft, s)   fills it (once per n_fft)
+ *   avsep_op_stft_mag(audio (B,L), basis, spec (B, n_fft/2+1, T), B, L, n_fft, hop, s)
+ * n_fft % 32 == 0, L % 4 == 0, hop % 4 == 0 (every configuration the reference uses); otherwise AVSEP_EINVAL.
+ * ------------------------------------------------------------------------------------------------------------ */
+int64_t avsep_stft_basis_floats(int n_fft);
+int avsep_stft_basis(float* basis, int n_fft, void* stream);
+int avsep_op_stft_mag(const float* audio, const float* basis, float* spec, int B, int L, int n_fft, int hop,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Training ops (what demo.py:83-113 / tests/test_model.py:210-217,332-353 exercise through
  * torch autograd).  Stateless; activations are row tensors [rows][C] (channels last); scratch is caller-owned.
  * The Python layer (av_separation/_train.py) composes them under torch.autograd.Function wrappers.  Dense

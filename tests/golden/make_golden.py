@@ -324,6 +324,15 @@ def make_train(outdir, only=None):
         for k, v in m.state_dict().items():
             if "running_" in k or k.endswith("num_batches_tracked"):
                 out["buf." + k] = v.numpy()
+        if name == "cfg4":
+            # At this depth the reference's own fp32 gradient is 1e-3 (one ReLU-kink tensor: 2.5e-2) away from its fp64
+            # gradient, so the fp64 run is stored too: the HIP path is gated on its distance to fp64 relative to the
+            # reference's own fp32-vs-fp64 distance, not on agreeing with fp32 rounding noise.
+            m64 = build_reference(c, state).train().double()
+            sep64, _ = m64(mixed.double(), lips.double())
+            SeparationLoss(l1_weight=0.5)(sep64, targets.double()).backward()
+            for k, p_ in m64.named_parameters():
+                out["g64." + k + ".slice"] = p_.grad.numpy().reshape(-1)[::int(out["g." + k + ".step"])].copy()
         path = os.path.join(outdir, f"train_{name}.npz")
         np.savez_compressed(path, **out)
         gn = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in m.parameters())))

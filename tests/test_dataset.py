@@ -46,3 +46,16 @@ def test_shapes_ranges_determinism():
     assert torch.equal(a["mixed_spec"], b["mixed_spec"]) and not torch.equal(a["mixed_spec"], c["mixed_spec"])
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=4)))
     assert batch["mixed_spec"].shape[0] == 4 and batch["lip_frames"].dim() == 4
+
+
+def test_waveforms_are_what_the_items_are_made_of():
+    """`waveforms(idx)` (the input of the device STFT, av_separation/stft.py) replays the item's random stream: the
+    host STFT of those signals is the item's spectrogram bit for bit."""
+    ds = SyntheticAVDataset(num_samples=6, sample_rate=8000, duration=0.5, n_fft=128, hop_length=32, num_frames=5,
+                            frame_h=8, frame_w=8, speaker_freqs=(220.0, 440.0, 660.0))
+    for idx in (0, 4):
+        mix, clean = ds.waveforms(idx)
+        it = ds[idx]
+        assert mix.shape == (4000,) and clean.shape == (3, 4000) and mix.dtype == torch.float32
+        assert np.array_equal(ds._stft(mix.numpy()), it["mixed_spec"].numpy())
+        assert np.array_equal(np.stack([ds._stft(c.numpy()) for c in clean]), it["clean_specs"].numpy())

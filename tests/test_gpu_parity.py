@@ -288,6 +288,31 @@ def test_op_linear(lib, dev, M, N, K, act, res):
     assert maxabs(y.cpu().numpy(), ref) < 2e-6 * max(1.0, float(np.abs(ref).max())) * math.sqrt(K / 32)
 
 
+def test_op_linear_tiles_bit_identical(lib, dev):
+    """Every GEMM instance -- 16x16x4 MFMA tiles of any shape and the 32x32x2 large-tile kernel -- feeds the products
+    into each accumulator in the same k order, so the outputs are bit-identical whatever tile the dispatcher picks
+    (this is what makes results independent of the batch size)."""
+    import os
+    from av_separation._native import check
+    M, N, K = 700, 384, 512
+    x, w = t(seeded.tensor(7, "x", (M, K), -2, 2), dev), t(seeded.tensor(7, "w", (N, K), -0.3, 0.3), dev)
+    b, r = t(seeded.tensor(7, "b", (N,), -1, 1), dev), t(seeded.tensor(7, "r", (M, N), -1, 1), dev)
+    outs = {}
+    try:
+        for tile in ("32x32x32", "32x32x64", "64x32x64", "64x64x32", "128x64x32", "128x128x32", "256x128x32"):
+            os.environ["AVSEP_GEMM_TILE"] = tile
+            y = torch.full((M, N), float("nan"), device=dev)
+            check(lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2,
+                                      _stream()))
+            outs[tile] = y
+    finally:
+        os.environ.pop("AVSEP_GEMM_TILE", None)
+    ref = outs.pop("32x32x32")
+    assert torch.isfinite(ref).all()
+    for tile, y in outs.items():
+        assert torch.equal(y, ref), tile
+
+
 def test_op_linear_rejects_bad_k(lib, dev):
     y = torch.empty(4, 4, device=dev)
     assert lib.avsep_op_linear(y.data_ptr(), y.data_ptr(), None, None, y.data_ptr(), 4, 4, 30, 0, _stream()) == -1

@@ -4,10 +4,14 @@ workload.  Tiles are forced through the AVSEP_GEMM_TILE developer override, one 
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))
-TILES = ["128x64x32", "64x64x32", "64x64x64", "64x32x32", "64x32x64", "32x32x32", "32x32x64", "32x32x128"]
+TILES = ["256x128x32", "128x128x32", "128x128x32/nopf", "128x64x32", "64x64x32", "64x64x64", "64x32x32", "64x32x64", "32x32x32", "32x32x64"]
 SHAPES = [(2016, 256, 256), (2016, 256, 1024), (2016, 768, 256), (2016, 1024, 256), (2016, 512, 256),
           (2016, 514, 512), (1600, 256, 256), (1600, 768, 256), (1600, 1024, 256), (1600, 256, 1024),
-          (1600, 256, 128), (16064, 512, 512), (16064, 2048, 512), (16064, 512, 2048)]
+          (1600, 256, 128), (3200, 512, 512), (3200, 2048, 512), (3200, 512, 2048),
+          (16064, 512, 512), (16064, 1536, 512), (16064, 2048, 512), (16064, 512, 2048), (16064, 514, 1024),
+          (16032, 4096, 512)]
+if os.environ.get("SWEEP_BIG"):
+    SHAPES = [s_ for s_ in SHAPES if s_[0] >= 3200]
 
 def child():
     import torch
@@ -35,17 +39,34 @@ def child():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child(); sys.exit(0)
+    if os.environ.get("SWEEP_VAR"):      # sweep the values of one developer environment switch instead of the tiles
+        var, vals = os.environ["SWEEP_VAR"], os.environ["SWEEP_VALS"].split(",")
+        res = {}
+        for v in vals:
+            env = dict(os.environ)
+            if v != "unset": env[var] = v
+            r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            res[v] = json.loads(line[-1]) if line else {}
+        print(f"{var:>18s} " + " ".join(f"{v:>10s}" for v in vals))
+        for (M, N, K) in SHAPES:
+            k = f"{M}x{N}x{K}"
+            print(f"{k:>18s} " + " ".join(f"{res[v].get(k) or 0:10.1f}" for v in vals) + "   TF: " +
+                  " ".join(f"{2*M*N*K/(res[v].get(k) or 1e9)/1e6:6.1f}" for v in vals))
+        sys.exit(0)
     res = {}
     for t in TILES + ["auto"]:
         env = dict(os.environ)
-        if t != "auto": env["AVSEP_GEMM_TILE"] = t
+        if t != "auto":
+            env["AVSEP_GEMM_TILE"] = t.split("/")[0]
+            if t.endswith("/nopf"): env["AVSEP_G32_PF"] = "0"
         r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         res[t] = json.loads(line[-1]) if line else {}
         if not line: print(t, "FAILED", r.stderr[-500:])
-    print(f"{'shape':>18s} " + " ".join(f"{t:>10s}" for t in TILES + ['auto']) + "   best  TF(best)")
+    print(f"{'shape':>18s} " + " ".join(f"{t:>15s}" for t in TILES + ['auto']) + "   best  TF(best)")
     for (M, N, K) in SHAPES:
         k = f"{M}x{N}x{K}"
         vals = [res[t].get(k) for t in TILES + ["auto"]]
         best = min((v, t) for v, t in zip(vals[:-1], TILES) if v)
-        print(f"{k:>18s} " + " ".join(f"{v:10.1f}" if v else f"{'-':>10s}" for v in vals) + f"   {best[1]:>7s} {2*M*N*K/best[0]/1e6:6.1f}")
+        print(f"{k:>18s} " + " ".join(f"{v:15.1f}" if v else f"{'-':>15s}" for v in vals) + f"   {best[1]:>15s} {2*M*N*K/best[0]/1e6:6.1f}")
