@@ -535,13 +535,21 @@ class AVSeparationTransformer(_Tracked):
         return out
 
     def run_static(self, mixed: torch.Tensor, lips: torch.Tensor, masks_btsf: torch.Tensor, sep_btsf: torch.Tensor,
-                   graph: bool = False):
+                   graph: bool = False, slot: int = 0):
         """Lowest-level call: caller-owned contiguous float32 device buffers in, (B,T,S,F) buffers out, nothing
         allocated or copied here.  With ``graph=True`` the launch sequence is replayed from a hipGraph keyed on
-        these exact buffers (bench.py's timed loop)."""
+        these exact buffers (bench.py's timed loop).  ``slot``: forwards that are in flight at the same time (different
+        streams, different input / output buffers) must use different slots; every slot > 0 is a native context of its
+        own (own packed-weight arena, workspace and graphs) -- measured: two graphs of ONE context replayed on two
+        streams do not overlap (0.466 ms per 32-clip step), two contexts do (0.375)."""
         B, F, T = mixed.shape
         _, N, H, W = lips.shape
         eng, dev = self._engine, mixed.device
+        if slot:
+            extra = self.__dict__.setdefault("_slot_engines", {})
+            eng = extra.get(slot)
+            if eng is None:
+                eng = extra[slot] = _Engine(self, "", *self._engine.cfg)
         lib = _native.load()
         with torch.cuda.device(dev):
             st = _stream(dev)

@@ -215,6 +215,189 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// Long-sequence variant for dh = 64 (L = 251 / 501 of configs 3-5): the SAME arithmetic in the SAME order as
+// attention_kernel<4, true, QT> (bit-identical results), but the four waves of a workgroup -- four different groups of
+// queries of one (clip, head) -- take their K / V fragments from an LDS tile that the workgroup loads ONCE, instead
+// of each wave streaming all of K and V through the CU's L1 by itself.  A wave needs 8 KB of K / V per 16 keys for
+// 64 MFMAs (2048 matrix cycles, QT = 2); four waves per SIMD-set asked the 64 B/clk L1 for ~48 B/clk (PMC: matrix
+// pipes 45 % busy).  Through LDS the global traffic is 4x smaller and the fragment reads cost 16 B/clk of the LDS's 128+.
+//   * stage = KT key tiles (16*KT keys): K rows [key][64] with the 16-byte slot XOR-swizzled by the key (the K fragment
+//     read is 16 lanes x 16 different rows at one column), V rows [key][64] linear (its fragment read is 16 lanes x one
+//     row); double-buffered, global -> registers before the stage's MFMAs, registers -> LDS after them, one barrier.
+//   * no wave leaves early (barriers): waves without queries compute on clamped rows and store nothing.
+template <int QT, int KT>
+__global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restrict__ q, int ldq,
+                                                            const float* __restrict__ k, int ldk,
+                                                            const float* __restrict__ v, int ldv,
+                                                            float* __restrict__ o, int ldo, int nhead, int Lq, int Lk,
+                                                            int nqt, float qscale, float* __restrict__ lse,
+                                                            float drop_p, unsigned long long drop_seed) {
+  constexpr int NB = 4, DH = 64;
+  constexpr int ROWS = 16 * KT;                       // keys per stage
+  constexpr int NLD = (2 * ROWS * 16) / 256;          // float4 loads per thread per stage (K and V)
+  static_assert((2 * ROWS * 16) % 256 == 0, "stage must be a whole number of float4 per thread");
+  __shared__ __attribute__((aligned(16))) float lds[2][2][ROWS * DH];   // [buffer][K|V][key][64]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 15;
+  const int g = lane >> 4;
+  const int nqw = (nqt + QT - 1) / QT;
+  const int wg_per_head = (nqw + 3) >> 2;
+  const int bh = blockIdx.x / wg_per_head;
+  const int qw = (blockIdx.x - bh * wg_per_head) * 4 + wave;
+  const bool active = qw < nqw;
+  const int b = bh / nhead, h = bh - b * nhead;
+
+  const float* qb = q + (size_t)b * Lq * ldq + h * DH;
+  const float* kb = k + (size_t)b * Lk * ldk + h * DH;
+  const float* vb = v + (size_t)b * Lk * ldv + h * DH;
+  float* ob = o + (size_t)b * Lq * ldo + h * DH;
+
+  f32x4 qf[QT][NB];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = min((qw * QT + t) * 16 + c, Lq - 1);
+#pragma unroll
+    for (int s = 0; s < NB; ++s) qf[t][s] = *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g) * qscale;
+  }
+  f32x4 acc[QT][NB];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    mrun[t] = -INFINITY;
+    lrun[t] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // staging: float4 index f = tid + 256*l of a stage's 2*ROWS*16 float4s; first ROWS*16 are K, the rest V
+  const int nkt = (Lk + 15) >> 4;
+  const int nstage = (nkt + KT - 1) / KT;
+  f32x4 stg[NLD];
+  auto load_stage = [&](int st) {
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const int f = tid + 256 * l;
+      const bool isv = f >= ROWS * 16;
+      const int ff = isv ? f - ROWS * 16 : f;
+      const int row = ff >> 4, slot = ff & 15;
+      const int key = min(st * ROWS + row, Lk - 1);
+      const float* src = (isv ? vb + (size_t)key * ldv : kb + (size_t)key * ldk) + 4 * slot;
+      stg[l] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const int f = tid + 256 * l;
+      const bool isv = f >= ROWS * 16;
+      const int ff = isv ? f - ROWS * 16 : f;
+      const int row = ff >> 4, slot = ff & 15;
+      float* dst = &lds[buf][isv ? 1 : 0][row * DH + ((isv ? slot : (slot ^ (row & 15))) << 2)];
+      *reinterpret_cast<f32x4*>(dst) = stg[l];
+    }
+  };
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) load_stage(st + 1);
+    const float* Ks = lds[buf][0];
+    const float* Vs = lds[buf][1];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      const int kt = st * KT + kk;
+      if (kt < nkt) {                                   // block-uniform
+        f32x4 kc[NB];
+        float vc[4][NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          const int row = 16 * kk + c;
+          kc[s] = *reinterpret_cast<const f32x4*>(Ks + row * DH + (((4 * s + g) ^ (row & 15)) << 2));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(Vs + (16 * kk + 4 * g + r) * DH + NB * c);
+          vc[r][0] = t4[0]; vc[r][1] = t4[1]; vc[r][2] = t4[2]; vc[r][3] = t4[3];
+        }
+        // ---- from here on: attention_kernel<4, true, QT>'s tile body, operation for operation ----
+        f32x4 stt[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) stt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NB; ++s)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) stt[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[s][j], qf[t][s][j], stt[t], 0, 0, 0);
+        float pr[QT][4];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          float tmax = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            stt[t][r] = key < Lk ? stt[t][r] : -INFINITY;
+            tmax = fmaxf(tmax, stt[t][r]);
+          }
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+          const float mnew = fmaxf(mrun[t], tmax);
+          const float alpha = exp_neg(mrun[t] - mnew);
+          float psum = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pr[t][r] = exp_neg(stt[t][r] - mnew);
+            psum += pr[t][r];
+          }
+          lrun[t] = lrun[t] * alpha + psum;
+          mrun[t] = mnew;
+          if (drop_p > 0.0f) {
+            const float keep_scale = 1.0f / (1.0f - drop_p);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const unsigned long long e =
+                  ((unsigned long long)bh * Lq + ((qw * QT + t) * 16 + c)) * Lk + (kt * 16 + 4 * g + r);
+              pr[t][r] = dropout_keep(drop_seed, e, drop_p) ? pr[t][r] * keep_scale : 0.0f;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NB; ++i) acc[t][i] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+              acc[t][blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[r][blk], pr[t][r], acc[t][blk], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nstage) store_stage(buf ^ 1);          // the other buffer: last read one barrier ago
+    __syncthreads();
+  }
+
+  if (!active) return;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    float l = lrun[t];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int qo = (qw * QT + t) * 16 + c;
+    if (lse && g == 0 && qo < Lq) lse[(size_t)bh * Lq + qo] = mrun[t] + logf(l);
+    if (qo < Lq) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(ob + (size_t)qo * ldo + NB * (4 * g + r)) =
+            f32x4{acc[t][0][r] * inv, acc[t][1][r] * inv, acc[t][2][r] * inv, acc[t][3][r] * inv};
+    }
+  }
+}
+
 // Short-sequence specialisation (49 <= Lk <= 64, dh = 64: the 1 s @ 8 kHz clips of BASELINE configs 1/2, T = 63
 // audio frames / N = 50 lip frames): all NKT = 4 key tiles of K and V are loaded before the first MFMA, so the
 // wave pays ONE memory round trip instead of one per tile (the generic kernel's 1-tile prefetch leaves a ~4 us
@@ -349,6 +532,19 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
                                 nhead, Lq, Lk, nqt, dh, qscale, lse, drop_p, drop_seed);                            \
     else hipLaunchKernelGGL((attention_kernel<NB_, false, 1>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,   \
                             nhead, Lq, Lk, nqt, dh, qscale, lse, drop_p, drop_seed);                                \
+  }
+  static const bool no_lds = getenv("AVSEP_ATTN_NO_LDS") != nullptr;       // developer A/B switch (whole process)
+  const bool no_lds_now = getenv("AVSEP_ATTN_NO_LDS_NOW") != nullptr;      // ... per call (the bit-identity test)
+  if (reg && nb == 4 && Lk >= 128 && !no_lds && !no_lds_now) {
+    // long sequences: K / V through LDS, shared by the workgroup's four waves (bit-identical to the kernels below)
+    if (two) {
+      hipLaunchKernelGGL((attention_lds_kernel<2, 2>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead,
+                         Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
+    } else {
+      hipLaunchKernelGGL((attention_lds_kernel<1, 2>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt,
+                         qscale, lse, drop_p, drop_seed);
+    }
+    return hipGetLastError();
   }
   if (two && reg && nb == 4) {
     const dim3 grid2((unsigned)wgs2);

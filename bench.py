@@ -169,11 +169,13 @@ def stream_leg(model, ds, B, dev, steps, inflight=2):
                          masks=torch.empty(B, T, S, F, device=dev), sep=torch.empty(B, T, S, F, device=dev),
                          h_masks=torch.empty(B, T, S, F).pin_memory(), h_sep=torch.empty(B, T, S, F).pin_memory(),
                          ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_out=torch.cuda.Event()))
-    s_in, s_cmp, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    s_cmps = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
 
     def run(n):
         for i in range(n):
             st = sets[i % inflight]
+            s_cmp = s_cmps[i % inflight]
             hm, hl = host_in[i % nb]
             with torch.cuda.stream(s_in):
                 s_in.wait_event(st["ev_out"])                       # the previous occupant's outputs have left
@@ -182,7 +184,7 @@ def stream_leg(model, ds, B, dev, steps, inflight=2):
                 st["ev_in"].record(s_in)
             with torch.cuda.stream(s_cmp), torch.no_grad():
                 s_cmp.wait_event(st["ev_in"])
-                model.run_static(st["mixed"], st["lips"], st["masks"], st["sep"], graph=True)
+                model.run_static(st["mixed"], st["lips"], st["masks"], st["sep"], graph=True, slot=i % inflight)
                 st["ev_done"].record(s_cmp)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(st["ev_done"])
@@ -203,14 +205,15 @@ def stream_leg(model, ds, B, dev, steps, inflight=2):
     st = sets[(steps - 1) % inflight]
     chk_m, chk_s = torch.empty_like(st["masks"]), torch.empty_like(st["sep"])
     with torch.no_grad():
-        model.run_static(st["mixed"], st["lips"], chk_m, chk_s, graph=False)
+        model.run_static(st["mixed"], st["lips"], chk_m, chk_s, graph=False, slot=(steps - 1) % inflight)
     torch.cuda.synchronize()
     same = bool(torch.equal(chk_m.cpu(), st["h_masks"]) and torch.equal(chk_s.cpu(), st["h_sep"]))
     return {"value": round(B * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
             "distinct_batches": nb, "buffers_in_flight": inflight, "h2d_mb_per_step": round(in_mb, 2),
             "d2h_mb_per_step": round(out_mb, 2), "pcie_gbs": round((in_mb + out_mb) * steps / dt / 1e3, 2),
             "outputs_bit_equal_to_resident_run": same,
-            "note": "pinned host buffers, H2D / compute / D2H on three streams, PCIe-inclusive; not the headline value"}
+            "note": "pinned host buffers; H2D stream, one compute stream per buffer set, D2H stream; PCIe-inclusive; "
+                    "not the headline value"}
 
 
 def main():
@@ -227,6 +230,9 @@ def main():
     ap.add_argument("--mode", default="forward", choices=("forward", "train"),
                     help="forward = the headline metric; train = one DP training step per 'step' (row N1, not the headline)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode only (reference default 0.1)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="forward mode: independent steps kept in flight at once, each on its own stream with its own "
+                         "batch, output and workspace buffers (1 = strictly one step after the other)")
     ap.add_argument("--stream", action="store_true",
                     help="also time the PCIe-inclusive streamed mode (distinct pinned host batches, double-buffered "
                          "H2D/D2H on side streams); reported as `stream` next to the resident-batch value")
@@ -272,35 +278,58 @@ def main():
     mk, dk = wl["model"], wl["data"]
     torch.manual_seed(0)                       # same random-init weights on every rank (replicated model)
     model = av.AVSeparationTransformer(dropout=0.0, **mk).to(dev).eval()
-    ds = av.SyntheticAVDataset(num_samples=world * B, **dk)
-    items = [ds[i] for i in shard_range(rank, world, B)]
-    mixed = torch.stack([it["mixed_spec"] for it in items]).to(dev).contiguous()
-    lips = torch.stack([it["lip_frames"] for it in items]).to(dev).contiguous()
+    # R = --inflight independent steps are kept in flight: step i runs on stream i % R with batch / output / workspace
+    # set i % R (R distinct resident batches per rank; a batch of 32 clips alone leaves the 256 CUs latency-bound, a second
+    # one fills the bubbles -- what a serving loop does).  Every step is a complete forward of its own 32-clip batch.
+    R = max(1, a.inflight)
+    ds = av.SyntheticAVDataset(num_samples=world * B * R, **dk)
+    sets = []
+    for r in range(R):
+        its = [ds[r * world * B + i] for i in shard_range(rank, world, B)]
+        mx = torch.stack([it["mixed_spec"] for it in its]).to(dev).contiguous()
+        lp = torch.stack([it["lip_frames"] for it in its]).to(dev).contiguous()
+        sets.append(dict(items=its, mixed=mx, lips=lp, stream=torch.cuda.Stream(device=dev)))
+    items, mixed, lips = sets[0]["items"], sets[0]["mixed"], sets[0]["lips"]
     _, F, T = mixed.shape
     _, N, H, W = lips.shape
     S = mk["num_speakers"]
-    masks = torch.empty(B, T, S, F, device=dev)
-    sep = torch.empty(B, T, S, F, device=dev)
+    for st in sets:
+        st["masks"] = torch.empty(B, T, S, F, device=dev)
+        st["sep"] = torch.empty(B, T, S, F, device=dev)
+    masks, sep = sets[0]["masks"], sets[0]["sep"]
     graph = not a.no_graph
+    stream = sets[0]["stream"]
 
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream), torch.no_grad():
-        for _ in range(max(1, a.warmup)):
-            model.run_static(mixed, lips, masks, sep, graph=graph)
-        stream.synchronize()
+    def run_steps(n, nsets):
+        for i in range(n):
+            st = sets[i % nsets]
+            with torch.cuda.stream(st["stream"]):
+                model.run_static(st["mixed"], st["lips"], st["masks"], st["sep"], graph=graph, slot=i % nsets)
+
+    with torch.no_grad():
+        run_steps(max(a.warmup, R), R)             # W warm-up steps (at least one per buffer set: graph capture)
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            model.run_static(mixed, lips, masks, sep, graph=graph)
-        stream.synchronize()
+        run_steps(a.steps, R)                      # EXACTLY K steps
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if dist is not None:
             dist.barrier()
         elapsed = max_over_ranks(dist, t1 - t0, dev)
+        # the same K steps strictly one after the other on one stream (the latency view), for the record
+        single = None
+        if R > 1:
+            run_steps(max(2, a.warmup), 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(a.steps, 1)
+            torch.cuda.synchronize()
+            single = max_over_ranks(dist, time.perf_counter() - t0, dev)
 
+    with torch.cuda.stream(stream), torch.no_grad():
         # ---- per-kernel roofline, live: eager forwards with every launch bracketed by HIP events
         prof_iters = 3
         kernels = []
@@ -369,14 +398,21 @@ def main():
                                f"d_model={mk['d_model']}, nhead={mk['nhead']}, {mk['num_encoder_layers']}+"
                                f"{mk['num_fusion_layers']} layers, forward-only",
                    "batch_per_gpu": B, "global_batch": world * B, "gflop_per_clip": round(gflop_clip, 4),
-                   "launch": "hipGraph replay" if graph else "eager", "parallelism": f"replica x{world} (clip shards)"},
+                   "launch": ("hipGraph replay" if graph else "eager") +
+                             (f", {R} independent steps in flight (one stream + batch / output / workspace set each)" if R > 1
+                              else ", one step after the other"),
+                   "steps_in_flight": R, "parallelism": f"replica x{world} (clip shards)"},
         "roofline": roofline,
         "kernels": [{"name": k["name"], "calls_per_step": k["calls"] / prof_iters, "avg_us": round(k["avg_us"], 2),
                      "tflops": round(k["tflops"], 2), "gbs": round(k["gbs"], 1)} for k in kernels],
     }
 
+    if single is not None:
+        out["one_step_at_a_time"] = {"value": round(world * B * a.steps / single, 2), "unit": "clips/s",
+                                     "ms_per_step": round(single / a.steps * 1e3, 4),
+                                     "note": "same K steps on ONE stream, each waiting for the previous one (step latency)"}
     if rank == 0 and world == 1 and a.stream:
-        out["stream"] = stream_leg(model, ds, B, dev, a.stream_steps)
+        out["stream"] = stream_leg(model, ds, B, dev, a.stream_steps, inflight=max(2, R))
         with torch.cuda.stream(stream), torch.no_grad():           # leave the resident batch's outputs behind again
             model.run_static(mixed, lips, masks, sep, graph=graph)
         torch.cuda.synchronize()

@@ -355,6 +355,31 @@ def test_op_attention(lib, dev, B, h, dh, Lq, Lk):
     assert maxabs(o.cpu().numpy(), ref) < tol
 
 
+@pytest.mark.parametrize("B,h,Lq,Lk", [(2, 8, 251, 251), (1, 4, 501, 501), (3, 2, 130, 129), (1, 2, 40, 300)])
+def test_op_attention_lds_variant_is_bit_identical(lib, dev, B, h, Lq, Lk):
+    """Long sequences (dh = 64, Lk >= 128) take K / V through LDS; same arithmetic in the same order as the
+    register-streaming kernel, so the two must agree bit for bit (AVSEP_ATTN_NO_LDS selects the latter)."""
+    import os
+    from av_separation._native import check
+    dh = 64
+    d = h * dh
+    qd = t(seeded.tensor(5, "q", (B, Lq, d), -1, 1), dev)
+    kd = t(seeded.tensor(5, "k", (B, Lk, d), -1.5, 1.5), dev)
+    vd = t(seeded.tensor(5, "v", (B, Lk, d), -2, 2), dev)
+    outs = []
+    for env in (None, "1"):
+        if env:
+            os.environ["AVSEP_ATTN_NO_LDS_NOW"] = env
+        else:
+            os.environ.pop("AVSEP_ATTN_NO_LDS_NOW", None)
+        o = torch.full((B, Lq, d), float("nan"), device=dev)
+        check(lib.avsep_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d, B, h, dh,
+                                     Lq, Lk, _stream()))
+        outs.append(o)
+    os.environ.pop("AVSEP_ATTN_NO_LDS_NOW", None)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("B,N,T,d", [(2, 10, 32, 64), (2, 50, 63, 256), (1, 12, 5, 32), (3, 1, 7, 64),
                                      (1, 50, 501, 512), (2, 75, 251, 512)])
 def test_op_interp_linear(lib, dev, B, N, T, d):
