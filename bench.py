@@ -301,6 +301,8 @@ def main():
     stream = sets[0]["stream"]
 
     def run_steps(n, nsets):
+        # ONE host thread feeds all buffer sets (one thread per set was measured: 0.478 vs 0.378 ms/step -- the HIP
+        # runtime serialises concurrent hipGraphLaunch calls)
         for i in range(n):
             st = sets[i % nsets]
             with torch.cuda.stream(st["stream"]):
