@@ -3,8 +3,9 @@
 process, demo.py:121), so this is new functionality whose contract is: G ranks x B/G clips produce the SAME
 parameter update as the reference's single process on the B-clip batch.  That needs three exchanges per step:
 
-  1. gradients     : all-reduce(sum)/G of every parameter gradient, in flat buckets launched from autograd hooks
-                     while the rest of the backward still runs (``GradBuckets``);
+  1. gradients     : sum/G of every parameter gradient as reduce-scatter + all-gather over flat buckets, the
+                     reduce-scatters launched from autograd hooks while the rest of the backward still runs
+                     (``GradBuckets``);
   2. BatchNorm     : per-channel statistics over the rows of all ranks, forward (mean/var/count all-gather) and
                      backward (two sums all-reduce) -- ``_train.SyncBatchNormReluFn``, 3 layers x 224 channels total;
   3. PIT loss      : the permutation is chosen for the WHOLE batch from the batch-mean loss (losses.py:65-71), so the
@@ -63,17 +64,23 @@ def combine_bn_stats(means: torch.Tensor, variances: torch.Tensor, counts: torch
 
 # ------------------------------------------------------------------------------------------- gradient buckets
 class GradBuckets:
-    """Flat gradient buckets with the all-reduce overlapped with the backward pass.
+    """Flat gradient buckets, exchanged as reduce-scatter + all-gather, overlapped with the backward pass.
 
     Parameters are taken in REVERSE registration order (roughly the order the backward produces their gradients);
     each parameter's ``.grad`` is a view into its bucket's flat buffer, so there is no gather/scatter copy: autograd
-    accumulates in place, the post-accumulate hook counts arrivals and the bucket's collective is launched
+    accumulates in place, the post-accumulate hook counts arrivals and the bucket's REDUCE-SCATTER is launched
     (``async_op``) the moment its last gradient lands.  ``finish()`` launches any bucket that did not fill (unused
-    parameters contribute zeros), waits, and scales by 1/G.  Use ``zero_grad()`` of this object (it keeps the views)."""
+    parameters contribute zeros), waits for the reduce-scatters, scales each rank's 1/G shard by 1/G (1/G of the
+    elementwise work of scaling after an all-reduce) and ALL-GATHERS the shards back into the flat buffers.
+    Why the two-step form: on the fully connected xGMI node every rank sends a different 1/G slice to
+    each of its 7 peers at once -- all links busy in both phases -- where a ring all-reduce moves the whole buffer
+    round one link at a time; and the shard is where a sharded optimizer / gradient norm would hook in.
+    Buckets are padded to a multiple of G elements.  Use ``zero_grad()`` of this object (it keeps the views)."""
 
     def __init__(self, params, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
         self.buckets = []                      # dict(flat, params, pending, work)
         self._where = {}                       # param -> (bucket index, byte offset in its flat buffer)
@@ -88,17 +95,22 @@ class GradBuckets:
         if cur:
             self._close(cur)
         self._hooks = [p.register_post_accumulate_grad_hook(self._arrived) for p in self.params]
+        self.exposed_wait_s = 0.0              # host time finish() spent waiting on collectives (last call)
         self._begin()
 
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
-        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        quantum = 4 * self.world                                   # shards of whole float4s
+        npad = (n + quantum - 1) // quantum * quantum
+        flat = torch.zeros(npad, dtype=plist[0].dtype, device=plist[0].device)
         off = 0
         for p in plist:
             p.grad = flat[off:off + p.numel()].view_as(p)
             self._where[p] = (len(self.buckets), off * p.element_size())
             off += p.numel()
-        self.buckets.append(dict(flat=flat, params=plist, pending=len(plist), work=None, launched=False))
+        shard = flat.new_empty(npad // self.world)
+        self.buckets.append(dict(flat=flat, shard=shard, used=n, params=plist, pending=len(plist), work=None,
+                                 launched=False))
 
     def _begin(self):
         for b in self.buckets:
@@ -108,10 +120,12 @@ class GradBuckets:
         b["launched"] = True
         if self.world == 1:
             return
-        if _staged(b["flat"], self.group):
-            all_reduce_sum_(b["flat"], self.group)           # host-staged (gloo + device tensor): synchronous
+        if _staged(b["flat"], self.group):                  # gloo + device tensor (CPU-hosted tests): synchronous
+            h, hs = b["flat"].detach().cpu(), torch.empty(b["shard"].numel())
+            dist.reduce_scatter_tensor(hs, h, group=self.group)
+            b["shard"].copy_(hs)
         else:
-            b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
+            b["work"] = dist.reduce_scatter_tensor(b["shard"], b["flat"], group=self.group, async_op=True)
 
     def _arrived(self, p):
         bi, off = self._where[p]
@@ -125,14 +139,29 @@ class GradBuckets:
 
     def finish(self):
         """Call after ``backward()``: every gradient is the mean over ranks when this returns."""
+        import time
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
-        for b in self.buckets:
+        if self.world == 1:
+            self.exposed_wait_s = 0.0
+            self._begin()
+            return
+        t0 = time.perf_counter()
+        gathers = []
+        for b in self.buckets:                              # in launch order: the early buckets are done first
             if b["work"] is not None:
                 b["work"].wait()
-            if self.world > 1:
-                b["flat"].mul_(1.0 / self.world)
+            b["shard"].mul_(1.0 / self.world)
+            if _staged(b["flat"], self.group):
+                hs, h = b["shard"].detach().cpu(), torch.empty(b["flat"].numel())
+                dist.all_gather_into_tensor(h, hs, group=self.group)
+                b["flat"].copy_(h)
+            else:
+                gathers.append(dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True))
+        for w in gathers:
+            w.wait()
+        self.exposed_wait_s = time.perf_counter() - t0
         self._begin()
 
     def zero_grad(self):

@@ -450,7 +450,7 @@ def train_main(a, av, dev, dist, rank, world):
     crit = SeparationLoss(0.5)
     dp = parallel.DataParallel(model) if dist is not None else None
     opt = torch.optim.Adam(model.parameters(), lr=3e-4, fused=True)
-    losses = []
+    losses, bwd_events, exposed = [], [], []
 
     def step():
         if dp is not None:
@@ -459,9 +459,15 @@ def train_main(a, av, dev, dist, rank, world):
             opt.zero_grad(set_to_none=False)
         sep, _ = model(mixed, lips)
         loss = crit(sep, targets, group=dp.group if dp is not None else None)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
         loss.backward()
+        e1.record()
         if dp is not None:
             dp.reduce_gradients()
+            exposed.append(dp.buckets.exposed_wait_s)
+        e2.record()
+        bwd_events.append((e0, e1, e2))
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0, foreach=True)
         opt.step()
         losses.append(loss.detach())
@@ -472,6 +478,8 @@ def train_main(a, av, dev, dist, rank, world):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    bwd_events.clear()
+    exposed.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -500,6 +508,16 @@ def train_main(a, av, dev, dist, rank, world):
                      "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4),
                      "traffic": None},
         "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+        # the exchange step next to the backward it overlaps: device time of backward() (reduce-scatters are launched
+        # from its hooks), device time from its end to the end of reduce_gradients() (= the part of the exchange the
+        # backward did not hide, plus the all-gathers), host time spent waiting inside reduce_gradients()
+        "exchange": {"backward_ms": round(sum(e0.elapsed_time(e1) for e0, e1, _ in bwd_events) / len(bwd_events), 3),
+                     "after_backward_ms": round(sum(e1.elapsed_time(e2) for _, e1, e2 in bwd_events) / len(bwd_events), 3),
+                     "host_wait_ms": round(1e3 * sum(exposed) / max(1, len(exposed)), 3),
+                     "gradient_mb": round(4 * nparam / 1e6, 1),
+                     "buckets": len(dp.buckets.buckets) if dp is not None else 0,
+                     "form": "reduce-scatter (from backward hooks) + 1/G on the shard + all-gather" if dp is not None
+                     else "single rank: no exchange"},
     }
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_train_baseline(model, mixed, lips, targets, mk, B, a.dropout, a.cpu_seconds)
