@@ -34,3 +34,21 @@ def test_identities():
     assert float(si_snr(a, b)) < 0
     loss = SeparationLoss()(torch.rand(2, 2, 65, 32), torch.rand(2, 2, 65, 32))
     assert loss.dim() == 0 and not torch.isnan(loss)
+
+
+def test_pairwise_ranking_equals_candidate_by_candidate_evaluation():
+    """SeparationLoss ranks the S! speaker orders from pairwise statistics (one pass) instead of S! evaluations of the
+    loss; the ranking values must agree with the direct ones and pick the same order (reference: losses.py:61-73)."""
+    from itertools import permutations
+    torch.manual_seed(0)
+    crit = SeparationLoss(0.5)
+    for n_spk in (2, 3, 4):
+        orders = list(permutations(range(n_spk)))
+        for trial in range(4):
+            tgt = torch.rand(3, n_spk, 17, 12) * 3
+            est = tgt[:, list(orders[(trial * 5 + 1) % len(orders)])] * (0.9 + 0.03 * trial) + 0.05 * torch.randn_like(tgt)
+            table = crit._order_table(n_spk, est.device)
+            fast = crit._ranking(est, tgt, table)
+            slow = torch.stack([crit._value(est[:, list(o)], tgt) for o in orders])
+            assert float((fast - slow).abs().max()) < 1e-3 and int(fast.argmin()) == int(slow.argmin())
+            assert float(crit(est, tgt)) == float(slow.min())

@@ -191,3 +191,22 @@ def test_attention_backward_rejects_unsupported_head_dim(dev):
     o = tr.AttentionFn.apply(qkv, qkv, 0, 32, 64, 1, 4, 8, 4, 4, 1.0 / math.sqrt(8))
     with pytest.raises(RuntimeError, match="multiple of 16"):
         o.sum().backward()
+
+
+@pytest.mark.parametrize("B,N,T,d", [(16, 75, 251, 512), (2, 50, 63, 256), (3, 12, 5, 32), (2, 1, 7, 64), (2, 9, 1, 64),
+                                     (1, 50, 501, 512), (4, 10, 10, 32)])
+def test_interp_fn_backward_is_the_adjoint_of_f_interpolate(dev, B, N, T, d):
+    """InterpFn backward (gather formulation) against torch autograd of F.interpolate(mode="linear",
+    align_corners=False) on the HOST (model.py:114-116), up- and down-sampling, single-row edge cases."""
+    from av_separation import _train as tr
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + N * 10 + T)
+    x = torch.randn(B * N, d, generator=g)
+    dy = torch.randn(B * T, d, generator=g)
+    xd = x.to(dev).requires_grad_()
+    y = tr.InterpFn.apply(xd, B, N, T)
+    y.backward(dy.to(dev))
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr.view(B, N, d).permute(0, 2, 1), size=T, mode="linear", align_corners=False).permute(0, 2, 1)
+    yr.reshape(B * T, d).backward(dy)
+    assert _rel(y.detach().cpu(), yr.detach().reshape(B * T, d)) < 2e-6
+    assert _rel(xd.grad.cpu(), xr.grad) < 3e-6
