@@ -61,7 +61,7 @@ class SeparationLoss(nn.Module):
         n_el = e.shape[2]
         ec = e - e.mean(dim=(1, 2), keepdim=True)                   # si_snr centres over speakers AND bins together
         tc = t - t.mean(dim=(1, 2), keepdim=True)
-        dots = torch.bmm(ec, tc.transpose(1, 2))                    # (B, S_est, S_tgt)
+        dots = (ec.unsqueeze(2) * tc.unsqueeze(1)).sum(dim=3)       # (B, S_est, S_tgt); elementwise + reduce, no BLAS call
         ee = (ec * ec).sum(dim=(1, 2))                              # (B,)
         tt = (tc * tc).sum(dim=(1, 2))
         l1 = (e.unsqueeze(2) - t.unsqueeze(1)).abs().sum(dim=(0, 3))   # (S_est, S_tgt)
