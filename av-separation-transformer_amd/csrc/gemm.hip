@@ -28,6 +28,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // through v_mov / v_accvgpr webs (measured 4.5 TFLOP/s on the 8-chunk variant).
 template <int BM, int BN, int BK, int NKMAX>
 __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
+  dbg_stamp(p, 0);
   constexpr int SLOTS = BK / 4;
   constexpr int RPP = 256 / SLOTS;
   constexpr int APASS = BM / RPP;
@@ -748,6 +750,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
 
   store_chunk(0, 0);
   __syncthreads();
+  dbg_stamp(p, 1);
 #pragma unroll
   for (int kc = 0; kc < NKMAX; ++kc) {
     if (kc < nk) {   // block-uniform
@@ -759,7 +762,14 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
     }
   }
 
+  dbg_stamp(p, 2);
   gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  if (p.dbg) {                                                   // block-uniform, diagnostics only
+    dbg_stamp(p, 3);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    dbg_stamp(p, 4);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1206,7 +1216,9 @@ hipError_t launch_gemm_dbg(const GemmParams& p_in, hipStream_t s) {
   if (e != hipSuccess) return e;
   (void)hipStreamSynchronize(s);
   static int shown = 0;
-  if (shown++ % 16 != 8) return hipSuccess;          // one report per 16 launches, after warm-up
+  static const bool all = getenv("AVSEP_GEMM_DBG") && !strcmp(getenv("AVSEP_GEMM_DBG"), "all");
+  ++shown;
+  if (all ? shown > 400 : shown % 16 != 9) return hipSuccess;   // "all": every launch (capped); else one report per 16
   std::vector<unsigned long long> h(cap * 8);
   (void)hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   unsigned long long t0 = ~0ull, t1 = 0;
@@ -1244,7 +1256,7 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   static const bool epi_general = getenv("AVSEP_EPI_GENERAL") != nullptr;   // developer A/B: block-by-block epilogue
   p.epi_general = epi_general ? 1 : 0;
   static const bool dbg = getenv("AVSEP_GEMM_DBG") != nullptr;
-  if (dbg && !p.dbg && !p.ln_gamma) return launch_gemm_dbg(p, s);
+  if (dbg && !p.dbg) return launch_gemm_dbg(p, s);
   return launch_gemm_impl(p, s);
 }
 

@@ -2,9 +2,9 @@
 # Developer tool (GPU box): HBM-side traffic per kernel of the bench forward (separate PMC passes, no tracing).
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph > /dev/null 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, collections, os
 R=os.environ["GRAFT_REPO_ROOT"]; OUT=R+"/gpurun_out/pmc_bench"
