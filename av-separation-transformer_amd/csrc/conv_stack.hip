@@ -4,7 +4,8 @@
 // activation kept in LDS: the only HBM traffic is the frames in (H*W*4 B each) and 128 floats out per frame,
 // instead of writing and re-reading act1 (52 MB) / act2 (26 MB) / act3 (13 MB) per 32-clip batch.
 //
-//   phase 1  conv1 (Cin = 1: 9 MACs per output) on the VALU, channels-last into a zero-haloed LDS image
+//   phase 1  conv1 (Cin = 1: 9 taps, zero-extended to K = 12) as three 16x16x4 MFMA steps per 16 pixels x 16 channels,
+//            the 3x3 window gathered from the raw frame in LDS; channels-last into a zero-haloed LDS image
 //   phase 2  conv2 as an implicit GEMM on the fp32 matrix cores: rows = output positions of the G frames,
 //            K = 9 taps x 32 ch; A fragments are ds_read_b128 gathers from the haloed image (no predication),
 //            W fragments stream from L2 (each wave owns 16 of the 64 output channels, so a workgroup reads
@@ -16,6 +17,8 @@
 // C+4 floats so neighbouring positions fall on different banks for the b128 gathers.
 #include "kernels.h"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace {
 
@@ -33,7 +36,14 @@ struct ConvStackParams {
   float* pooled;         // (Mv, 128)
   int Mv, H, W, H1, W1, H2, W2, H3, W3;
   int a1_frame, a2_frame;   // floats per frame image incl. halo
+  unsigned long long* dbg;  // developer diagnostics (AVSEP_CONV_DBG): per-workgroup phase clock sums, null otherwise
 };
+
+// AVSEP_CONV_DBG: thread 0 of every workgroup accumulates the 100 MHz wall-clock time of each phase over its passes
+// into dbg[blockIdx * 8 + phase]; launch_conv_stack prints the means.  One scalar clock read per phase otherwise unused.
+__device__ __forceinline__ unsigned long long cs_tick(const ConvStackParams& p) {
+  return p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+}
 
 // RB2 / RB3: 16-row MFMA blocks of the conv2 / conv3 output rows, COMPILE-TIME so the accumulator arrays stay in
 // registers with no per-block predication (a runtime "if (i < rb)" around each MFMA made hipcc shuffle the whole
@@ -93,15 +103,22 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   const int ch3 = 16 * CB3 * wave + c;      // first conv3 channel of this lane
   const float* w3l0 = p.w3 + (size_t)ch3 * 9 * C2 + 4 * q;
   const float* w3l1 = w3l0 + (size_t)(CB3 > 1 ? 16 : 0) * 9 * C2;
-  const float bias2 = p.b2[16 * cb2 + c];
+  const f32x4 bias2v = *reinterpret_cast<const f32x4*>(p.b2 + 16 * cb2 + 4 * q);
   const float bias3_0 = p.b3[ch3], bias3_1 = p.b3[ch3 + (CB3 > 1 ? 16 : 0)];
 
-  // conv1 weights of this thread's 4 channels (cq = tid & 7 is the same for every element a thread visits)
-  const int cq1 = tid & 7;
-  f32x4 w1r[9];
+  // conv1 as MFMA operands: weights of channel 16cb + c for the taps k = 4s + q (zero beyond the 9th), bias of the four
+  // channels 16cb + 4q .. +3 this lane's accumulator holds
+  float w1a[2][3];
+  f32x4 b1c[2];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) w1r[t] = *reinterpret_cast<const f32x4*>(p.w1 + t * C1 + 4 * cq1);
-  const f32x4 b1r = *reinterpret_cast<const f32x4*>(p.b1 + 4 * cq1);
+  for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int k = 4 * s3 + q;
+      w1a[cb][s3] = k < 9 ? p.w1[k * C1 + 16 * cb + c] : 0.0f;
+    }
+    b1c[cb] = *reinterpret_cast<const f32x4*>(p.b1 + 16 * cb + 4 * q);
+  }
 
   // Raw frames are staged through LDS: the next pass's G*H*W pixels are fetched into registers (RAWN coalesced
   // loads per thread) while this pass runs on the matrix cores, so conv1 never waits on HBM.
@@ -119,8 +136,10 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   };
   if ((int)blockIdx.x < ngroups) fetch_raw(blockIdx.x);
 
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int f0 = grp * G;
+    const unsigned long long t0 = cs_tick(p);
     __syncthreads();   // previous pass done with a1/a2/raw (and the zero fill on the first pass)
 #pragma unroll
     for (int k = 0; k < RAWN; ++k) {
@@ -129,36 +148,56 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
     }
     __syncthreads();
     if (grp + (int)gridDim.x < ngroups) fetch_raw(grp + gridDim.x);
+    const unsigned long long t1 = cs_tick(p);
 
-    // ---------------- phase 1: conv1 + BN + ReLU on the VALU -> a1 interior ----------------------------
-    for (int idx = tid; idx < G * P1 * 8; idx += NT) {
-      const int px = idx >> 3;
-      const int g = px / P1, pos = px - g * P1;
-      const int y = pos / p.W1, x = pos - y * p.W1;
-      f32x4 acc = b1r;
-      if (f0 + g < p.Mv) {
-        const float* fr = raw + g * HW;
+    // ---------------- phase 1: conv1 + BN + ReLU on the matrix cores -> a1 interior ---------------------
+    // Cin = 1: K = 9 taps, zero-extended to 12 = three 16x16x4 MFMA steps.  Operands swapped like the GEMM epilogue's:
+    // A = weights (lane: channel 16cb + (lane&15), k = 4s + (lane>>4)), B = the 3x3 window gathered from the raw
+    // frame (lane: output pixel lane&15 of a 16-pixel block, same k), C = bias, so lane (pixel, q) ends up with the
+    // four consecutive channels 16cb + 4q .. +3 of its pixel: one ds_write_b128 per block into the channels-last image.
+    // The MFMA is a k-ordered fma chain starting from C, i.e. bias, tap 0, tap 1, ... -- bit-identical to the VALU
+    // loop it replaces (which took 7.8 of a pass's 28 us with the matrix pipes idle: in-kernel phase clocks).
+    {
+      const int npb = (G * P1 + 15) >> 4;                 // 16-pixel blocks of this pass
+      constexpr int U = 4;                                // blocks in flight per wave: independent gather -> MFMA -> store chains
+      for (int pb0 = wave; pb0 < npb; pb0 += U * NW) {    // wave-uniform trip count
+        float xv[U][3];
+        int dst[U];
+        bool pin[U], live[U];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = 2 * y - 1 + ky;
+        for (int u = 0; u < U; ++u) {
+          const int px = 16 * (pb0 + u * NW) + c;
+          pin[u] = px < G * P1;                           // also false for blocks beyond npb
+          const int pxc = pin[u] ? px : 0;
+          const int g = pxc / P1, pos = pxc - g * P1;
+          const int y = pos / p.W1, x = pos - y * p.W1;
+          const float* fr = raw + g * HW;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = 2 * x - 1 + kx;
-            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const float v = ok ? fr[iy * p.W + ix] : 0.0f;
-            const f32x4 w4 = w1r[ky * 3 + kx];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, w4[e], acc[e]);
+          for (int s3 = 0; s3 < 3; ++s3) {
+            const int k = 4 * s3 + q;                     // tap index of this lane in MFMA step s3
+            const int ky = k / 3, kx = k - 3 * ky;
+            const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
+            const bool ok = k < 9 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            xv[u][s3] = ok ? fr[ok ? iy * p.W + ix : 0] : 0.0f;
           }
+          live[u] = pin[u] && (f0 + g < p.Mv);
+          dst[u] = g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * q;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.0f);
-      } else {
-        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x4 acc = b1c[cb];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[cb][s3], xv[u][s3], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = live[u] ? fmaxf(acc[e], 0.0f) : 0.0f;
+            if (pin[u]) *reinterpret_cast<f32x4*>(a1 + dst[u] + 16 * cb) = acc;
+          }
       }
-      *reinterpret_cast<f32x4*>(a1 + g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * cq1) = acc;
     }
     __syncthreads();
+    const unsigned long long t2 = cs_tick(p);
 
     // ---------------- phase 2: conv2 implicit GEMM, wave owns output channels [16*wave, 16*wave+16) -----
     {
@@ -189,26 +228,29 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < RB2MAX; ++i)
-              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], b[e], acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[e], fa[i][e], acc[i], 0, 0, 0);   // D[channel][position]
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) wc[s] = wn[s];
       }
-      // bias + ReLU -> a2 interior (C/D: col = c -> channel 16*wave+c, row = 4q + r -> position)
+      // bias + ReLU -> a2 interior.  Operands are swapped (weights as the A operand), so lane (position c, q) holds the
+      // four consecutive channels 16*cb2 + 4q .. +3 of its position: one coordinate computation and one ds_write_b128
+      // per block instead of sixteen of each (the same products in the same order: bit-identical).
 #pragma unroll
       for (int i = 0; i < RB2MAX; ++i) {
+        const int m = 16 * (rb2_0 + i) + c;
+        if (m < G * P2) {
+          const int g = m / P2, pos = m - g * P2;
+          const int y = pos / p.W2, x = pos - y * p.W2;
+          f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = 16 * (rb2_0 + i) + 4 * q + r;
-          if (m < G * P2) {
-            const int g = m / P2, pos = m - g * P2;
-            const int y = pos / p.W2, x = pos - y * p.W2;
-            a2[g * p.a2_frame + ((y + 1) * s2w + (x + 1)) * C2P + 16 * cb2 + c] = fmaxf(acc[i][r] + bias2, 0.0f);
-          }
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][r] + bias2v[r], 0.0f);
+          *reinterpret_cast<f32x4*>(a2 + g * p.a2_frame + ((y + 1) * s2w + (x + 1)) * C2P + 16 * cb2 + 4 * q) = v;
         }
       }
     }
     __syncthreads();
+    const unsigned long long t3 = cs_tick(p);
 
     // ---------------- phase 3: conv3 implicit GEMM + average pool, wave owns 32 output channels -------
     {
@@ -276,6 +318,14 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
         }
       }
     }
+    if (p.dbg) {
+      const unsigned long long t4 = cs_tick(p);
+      ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += 1;
+    }
+  }
+  if (p.dbg && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) p.dbg[(size_t)blockIdx.x * 8 + i] = ph[i];
   }
 }
 
@@ -295,7 +345,27 @@ hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t 
   int grid = 256 * per_cu;
   if (const char* e = getenv("AVSEP_CONV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer A/B switch
   if (grid > ngroups) grid = ngroups;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, s, p);
+  static const bool dbg = getenv("AVSEP_CONV_DBG") != nullptr;
+  if (!dbg) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, s, p);
+    return hipGetLastError();
+  }
+  static unsigned long long* buf = nullptr;
+  if (!buf && hipMalloc(reinterpret_cast<void**>(&buf), 8192 * 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+  ConvStackParams q = p;
+  q.dbg = buf;
+  (void)hipMemsetAsync(buf, 0, 8192 * 8 * sizeof(unsigned long long), s);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, s, q);
+  (void)hipStreamSynchronize(s);
+  static int shown = 0;
+  if (shown++ < 3) {
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    (void)hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum[4] = {0, 0, 0, 0}, passes = 0;
+    for (int b = 0; b < grid; ++b) { for (int i = 0; i < 4; ++i) sum[i] += (double)h[b * 8 + i]; passes += (double)h[b * 8 + 4]; }
+    fprintf(stderr, "[conv dbg] G=%d NW=%d grid %d, %.0f passes: mean per pass: stage raw %.2f  conv1 %.2f  conv2 %.2f  conv3+pool %.2f us\n",
+            G, NW, grid, passes, sum[0] / passes / 100, sum[1] / passes / 100, sum[2] / passes / 100, sum[3] / passes / 100);
+  }
   return hipGetLastError();
 }
 
