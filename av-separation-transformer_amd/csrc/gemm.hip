@@ -1134,6 +1134,12 @@ Tile pick_ln_tile(const GemmParams& p) {
     bool found = false;
     for (const Tile& t : cands)
       if (!found && blocks(t) >= tln) { pick = t; found = true; }
+    // 32 rows x 64 columns: every A row block is fetched and normalised for half as many column tiles (the LN-fused
+    // prologue is an L2 burst of the workgroup's whole A and W slabs: 97 -> 73 MB per 2016x768x256 launch) while the row
+    // parallelism stays; only where that still leaves >= 2 workgroups per CU (+0.8 % on the 32-clip step, same-run A/B)
+    static const long tln64 = getenv("AVSEP_TLN64") ? atol(getenv("AVSEP_TLN64")) : 512;
+    const Tile wide{32, 64, 64};
+    if (!found && blocks(wide) >= tln64) pick = wide;
   }
   return pick;
 }
@@ -1161,6 +1167,7 @@ hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
   if (t.bk == 64) {
     if (t.bm == 64 && t.bn == 64 && nk <= 4) return launch_ln_nk<64, 64, 64>(p, nk, s);
     if (t.bm == 64 && t.bn == 32 && nk <= 4) return launch_ln_nk<64, 32, 64>(p, nk, s);
+    if (t.bm == 32 && t.bn == 64 && nk <= 4) return launch_ln_nk<32, 64, 64>(p, nk, s);
     return launch_ln_nk<32, 32, 64>(p, nk, s);
   }
   return launch_ln_nk<32, 32, 32>(p, nk, s);
