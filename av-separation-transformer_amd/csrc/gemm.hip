@@ -69,11 +69,24 @@ __device__ __forceinline__ float act_t(float v) {
   return v;
 }
 
+// erf / exp expand to dozens of instructions per element.  Inlined into the unrolled epilogue, hipcc interleaves the
+// chains of all WBM*WBN blocks and the 128x64 tile needs 213 registers -- two workgroups per CU instead of three
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor and the resident-workgroup census both showed 2) -- for code that runs
+// once per tile.  Out of line, one float4 at a time, the kernel stays at 146.
+template <int ACT>
+__device__ __attribute__((noinline)) f32x4 act4_outofline(f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = act_t<ACT>(v[e]);
+  return v;
+}
+
 // Straight-line epilogue for N % 4 == 0 (see the note on gemm_epilogue): every load of the tile is UNCONDITIONAL
 // (out-of-range rows / columns are clamped to the tile's last valid row / float4, a missing bias or residual reads the
 // same addresses of whatever pointer is valid and is discarded by a select), then the arithmetic, then the stores.
-// (Issuing these loads BEFORE the K loop, behind the first chunks, was measured too: -15 % on the 32-clip step -- they
-// sit in the same in-order queue as the staging loads of the loop, which then wait for cold residual rows.)
+// (Issuing these loads EARLIER was measured three ways, all losses: before the K loop, behind the first chunks, -15 % on
+// the 32-clip step (they sit in the same in-order queue as the loop's staging loads, which then wait for cold residual
+// rows); conditionally before the last chunk inside the tail loop, -4...-9 %; before a peeled last chunk in straight-line
+// code, -3.5 % cfg2 / -8 % cfg3 and cfg5 -- profiles/r02_ab_epilogue_early_loads.txt.)
 template <int WBM, int WBN>
 struct EpiOperands {
   f32x4 bv[WBN], rv[WBM][WBN];
@@ -109,13 +122,19 @@ __device__ __forceinline__ void epilogue_finish(const GemmParams& p, const f32x4
 #pragma unroll
   for (int i = 0; i < WBM; ++i)
 #pragma unroll
-    for (int j = 0; j < WBN; ++j)
+    for (int j = 0; j < WBN; ++j) {
+      f32x4 x;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = has_b ? acc[i][j][e] + o.bv[j][e] : acc[i][j][e];
-        x = act_t<ACT>(x);
-        o.rv[i][j][e] = has_r ? x + o.rv[i][j][e] : x;
+      for (int e = 0; e < 4; ++e) x[e] = has_b ? acc[i][j][e] + o.bv[j][e] : acc[i][j][e];
+      if (ACT == ACT_GELU || ACT == ACT_SIGMOID) {
+        x = act4_outofline<ACT>(x);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = act_t<ACT>(x[e]);
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o.rv[i][j][e] = has_r ? x[e] + o.rv[i][j][e] : x[e];
+    }
 #pragma unroll
   for (int i = 0; i < WBM; ++i)
 #pragma unroll
@@ -276,8 +295,9 @@ __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int slot) {
   if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
+// (launch bound for the fragment-prefetch instance: 3 waves per SIMD = 168 registers; it sits at 170 otherwise)
 template <int BM, int BN, int BK, int AMODE, bool PF = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams pin) {
+__global__ __launch_bounds__(256, PF ? 3 : 1) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
   dbg_stamp(p, 0);
   if (p.ksplit > 1) {                      // block-uniform: slice blockIdx.y of the contraction
@@ -1061,6 +1081,14 @@ hipError_t launch32_t(const GemmParams& p, hipStream_t s) {
 template <int BM, int BN, int BK, int AMODE, bool PF = false>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  if (p.dbg) {   // diagnostics: what the runtime says about residency of this instance
+    int nb = 0;
+    hipFuncAttributes fa{};
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gemm_kernel<BM, BN, BK, AMODE, PF>), 256, 0);
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemm_kernel<BM, BN, BK, AMODE, PF>));
+    fprintf(stderr, "[gemm dbg] instance <%d,%d,%d,%d,%d>: occupancy API %d workgroups / CU, numRegs %d, static LDS %zu B, scratch %zu B\n",
+            BM, BN, BK, AMODE, (int)PF, nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
+  }
   hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE, PF>), dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   return hipGetLastError();
 }
@@ -1223,7 +1251,7 @@ hipError_t launch_gemm_dbg(const GemmParams& p_in, hipStream_t s) {
   if (e != hipSuccess) return e;
   (void)hipStreamSynchronize(s);
   static int shown = 0;
-  static const bool all = getenv("AVSEP_GEMM_DBG") && !strcmp(getenv("AVSEP_GEMM_DBG"), "all");
+  static const bool all = getenv("AVSEP_GEMM_DBG") && (!strcmp(getenv("AVSEP_GEMM_DBG"), "all") || !strcmp(getenv("AVSEP_GEMM_DBG"), "cu"));
   ++shown;
   if (all ? shown > 400 : shown % 16 != 9) return hipSuccess;   // "all": every launch (capped); else one report per 16
   std::vector<unsigned long long> h(cap * 8);
@@ -1255,6 +1283,22 @@ hipError_t launch_gemm_dbg(const GemmParams& p_in, hipStream_t s) {
     fprintf(stderr, "%zu ", c);
   }
   fprintf(stderr, "\n");
+  if (getenv("AVSEP_GEMM_DBG") && !strcmp(getenv("AVSEP_GEMM_DBG"), "cu")) {
+    // every workgroup that ran on the CU of workgroup 0 (HW_ID cu / sh / se fields + XCC id), in start order
+    const unsigned long long key0 = (h[5] & 0xff00ull) | (h[5] >> 32 << 16);
+    std::vector<size_t> ids;
+    for (size_t b = 0; b < cap; ++b) {
+      const unsigned long long* r = &h[b * 8];
+      if (r[0] && r[4] && (((r[5] & 0xff00ull) | (r[5] >> 32 << 16)) == key0)) ids.push_back(b);
+    }
+    std::sort(ids.begin(), ids.end(), [&](size_t a, size_t b) { return h[a * 8] < h[b * 8]; });
+    fprintf(stderr, "[gemm dbg] one CU, %zu workgroups (us from launch start): id  start | prologue end | loop end | stores issued | drained\n", ids.size());
+    for (size_t b : ids) {
+      const unsigned long long* r = &h[b * 8];
+      fprintf(stderr, "[gemm dbg]   %6zu  %8.2f %8.2f %8.2f %8.2f %8.2f\n", b, (r[0] - t0) / 100.0, (r[1] - t0) / 100.0, (r[2] - t0) / 100.0,
+              (r[3] - t0) / 100.0, (r[4] - t0) / 100.0);
+    }
+  }
   return hipSuccess;
 }
 
