@@ -386,6 +386,20 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
     p.ln_gamma = g; p.ln_beta = be; p.ln_eps = 1e-5f;
     return run_gemm(c, p, s);
   }
+  // Large M, staged form: one statistics launch (mean, 1/std per row; it reads x once and writes 8 bytes per row), and
+  // the GEMM normalises its A tile on the way to LDS -- the normalised tensor is never written or re-read.  ln_buf
+  // holds the (M, 2) statistics.
+  // Measured NEGATIVE end to end (profiles/r02_ab_layernorm_staged.txt: cfg3 -2.5 %, cfg5 -2 %): the stand-alone
+  // LayerNorm already runs at 5.5 TB/s (12 us at M = 16064, d = 512), and the normalisation arithmetic in front of
+  // the tile's LDS writes lengthens every K step of the GEMM by more than the 6 us per LayerNorm it saves.  The form
+  // stays available (avsep_op_ln_linear form 2, bit-identical) behind this developer switch.
+  static const bool staged = getenv("AVSEP_LN_STAGED") != nullptr;
+  if (staged && gemm_ln_staged_supported(d)) {
+    RCK(profiled(c, "layernorm_kernel", 6.0 * M * d, 1.0 * M * d * 4 + 8.0 * M, s,
+                 [&] { return launch_layernorm_stats(x, ln_buf, M, d, 1e-5f, s); }));
+    p.ln_gamma = g; p.ln_beta = be; p.ln_eps = 1e-5f; p.ln_stats = ln_buf;
+    return run_gemm(c, p, s);
+  }
   RCK(run_layernorm(c, x, g, be, ln_buf, M, d, s));
   p.A = ln_buf;
   return run_gemm(c, p, s);
@@ -1094,6 +1108,32 @@ int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, fl
                        void* stream) {
   if (!x || !gamma || !beta || !y) return fail(AVSEP_EINVAL, "null pointer");
   HCK(launch_layernorm(x, gamma, beta, y, M, d, eps, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
+                       float* y, float* scratch, int M, int N, int K, int act, float eps, int form, void* stream) {
+  if (!x || !gamma || !beta || !w || !y || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32) return fail(AVSEP_EINVAL, "K must be a multiple of 32");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmParams p = linear_params(x, K, w, K, bias, y, N, M, N, act);
+  if (form == 0) {                       // LayerNorm launch, then the plain GEMM on the normalised rows
+    if (!scratch) return fail(AVSEP_EINVAL, "form 0 needs M*K floats of scratch");
+    HCK(launch_layernorm(x, gamma, beta, scratch, M, K, eps, s));
+    p.A = scratch;
+  } else if (form == 1) {                // statistics and normalisation inside the GEMM (short K)
+    if (!gemm_ln_supported(K)) return fail(AVSEP_EINVAL, "in-kernel LayerNorm form: K is not supported");
+    p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps;
+  } else if (form == 2) {                // statistics launch, normalisation while the GEMM stages A
+    if (!scratch) return fail(AVSEP_EINVAL, "form 2 needs 2*M floats of scratch");
+    if (!gemm_ln_staged_supported(K)) return fail(AVSEP_EINVAL, "staged LayerNorm form: K is not supported");
+    HCK(launch_layernorm_stats(x, scratch, M, K, eps, s));
+    p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.ln_stats = scratch;
+  } else {
+    return fail(AVSEP_EINVAL, "form must be 0, 1 or 2");
+  }
+  HCK(launch_gemm(p, s));
   return AVSEP_OK;
 }
 

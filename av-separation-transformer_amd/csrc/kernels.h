@@ -17,7 +17,8 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
 }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
-enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2, AMODE_FRAMES = 3 };
+enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2, AMODE_FRAMES = 3, AMODE_LN = 4 };
+enum { LN_KMAX = 512 };   // widest LayerNorm the staged form (AMODE_LN) keeps gamma / beta in LDS for
 
 // C[M,N] = epilogue( A'[M,K] * W[N,K]^T ), fp32 in / fp32 accumulate on the matrix cores.
 // A' is A itself (PLAIN), a 3-tap shifted view of a (B,T,Kt) sequence tensor (TAPS3: Conv1d k=3 p=1 as one
@@ -51,9 +52,13 @@ struct GemmParams {
   unsigned long long* dbg;   // developer diagnostics (AVSEP_GEMM_DBG): per-workgroup phase stamps, null otherwise
   // Fused LayerNorm prologue (PLAIN mode, K == normalised width): A' = (A - mean_row) * rstd_row * gamma + beta,
   // row statistics computed in-kernel by a pre-pass over the block's rows (nn.LayerNorm, eps ln_eps).
+  // With ln_stats (row m: mean at [2m], 1/sqrt(var+eps) at [2m+1], from launch_layernorm_stats) the statistics are not
+  // recomputed: A' is formed while the tile is staged to LDS (AMODE_LN, any tile, K <= LN_KMAX) -- the form for large M,
+  // where the in-kernel pre-pass of every column tile over the same rows would cost more than one statistics launch.
   const float* ln_gamma;
   const float* ln_beta;
   float ln_eps;
+  const float* ln_stats;
   // Split-K (weight gradients: K = rows >> M, N): gridDim.y = ksplit slices of kchunk columns each (kchunk % 64 == 0),
   // slice z reads A/W columns [z*kchunk, ...) and writes its partial product to C + z*cstride; the caller sums the
   // slices with a column reduction (deterministic, no atomics).  PLAIN mode, no bias/act/residual.  0/1 = off.
@@ -71,6 +76,10 @@ bool gemm_ln_supported(int K);                          // can launch_gemm() fus
 
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int d, float eps,
                             hipStream_t s);
+// row statistics of nn.LayerNorm only: stats[2m] = mean, stats[2m+1] = 1/sqrt(biased var + eps), the values
+// layernorm_kernel normalises with (same reduction order)
+hipError_t launch_layernorm_stats(const float* x, float* stats, int M, int d, float eps, hipStream_t s);
+bool gemm_ln_staged_supported(int K);                   // can launch_gemm() take ln_stats for a LayerNorm over K columns?
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                             float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s);
 hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,

@@ -13,7 +13,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // nn.LayerNorm (model.py:143,162-163 and the norm1/norm2 of TransformerEncoderLayer): one wavefront per
 // row, the row held in registers (VEC float4 per lane), two-pass mean / biased variance like ATen.
-template <int VEC>
+template <int VEC, bool STATS_ONLY = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gam,
                                                         const float* __restrict__ bet, float* __restrict__ y,
                                                         int M, int d, float eps) {
@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
   const float var = wave_sum(sq) / (float)d;
   const float rstd = 1.0f / sqrtf(var + eps);
+  if (STATS_ONLY) {   // y = (M, 2): the LayerNorm is applied by the GEMM that consumes x (gemm.hip AMODE_LN)
+    if (lane == 0) *reinterpret_cast<float2*>(y + 2 * (size_t)row) = make_float2(mean, rstd);
+    return;
+  }
   float* yr = y + (size_t)row * d;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
@@ -231,6 +235,18 @@ hipError_t launch_layernorm(const float* x, const float* g, const float* b, floa
   else if (vec <= 2) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, s, x, g, b, y, M, d, eps);
   else if (vec <= 4) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, g, b, y, M, d, eps);
   else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, g, b, y, M, d, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm_stats(const float* x, float* stats, int M, int d, float eps, hipStream_t s) {
+  if (M <= 0 || d <= 0 || (d & 3) || d > 2048) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+  const int vec = (d + 255) / 256;
+  const float* none = nullptr;
+  if (vec <= 1) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, none, none, stats, M, d, eps);
+  else if (vec <= 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, none, none, stats, M, d, eps);
+  else if (vec <= 4) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, none, none, stats, M, d, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<8, true>), grid, block, 0, s, x, none, none, stats, M, d, eps);
   return hipGetLastError();
 }
 

@@ -133,6 +133,13 @@ int avsep_op_linear(const float* x, const float* w, const float* bias, const flo
                     int N, int K, int act, void* stream);
 int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                        float eps, void* stream);
+/* y = act(LayerNorm(x) W^T + b), the pair every pre-norm block of the model is made of (model.py:48-52 norm_first
+ * layers, 145-149, 201): x (M,K), w (N,K).  `form` picks how the engine may run it -- all three are the same
+ * function: 0 = LayerNorm launch into scratch (M*K floats) + GEMM; 1 = statistics and normalisation inside the GEMM
+ * (K <= 256; what small batches use); 2 = a statistics launch into scratch (2*M floats: mean, 1/std per row) and a
+ * GEMM that normalises its A tile on the way to LDS (K <= 512; what large batches use; bit-identical to form 0). */
+int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
+                       float* y, float* scratch, int M, int N, int K, int act, float eps, int form, void* stream);
 /* softmax(q k^T) v per (batch, head); q is expected pre-scaled.  q (B,Lq,ldq) etc. with head h at
  * column offset h*dh; out (B,Lq,ldo). */
 int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,

@@ -313,6 +313,86 @@ def test_op_linear_tiles_bit_identical(lib, dev):
         assert torch.equal(y, ref), tile
 
 
+@pytest.mark.parametrize("tile,M,N,K,rounds", [("128x64x32", 8200, 1596, 128, "2"), ("128x64x32", 8200, 1596, 192, "2"),
+                                               ("64x64x32", 4100, 1596, 256, "2"), ("128x64x32", 5000, 1280, 64, "1"),
+                                               ("64x64x32", 3001, 644, 128, "1.2")])
+def test_op_linear_persistent_form_is_bit_identical(lib, dev, tile, M, N, K, rounds):
+    """The persistent developer form of the plain GEMM (AVSEP_PERSIST: a resident workgroup walks its tiles and
+    prefetches the next tile's first chunks under the current tile's last ones; measured slower, so off by default)
+    has the same staging and MFMA order as the one-tile kernel: the two forms agree bit for bit -- ragged last row/column tiles, workgroups with one tile and with several, K
+    chunk counts that do and do not admit the persistent form (192 = 6 chunks with ring depth 2 does, with 4 not)."""
+    import os
+    from av_separation._native import check
+    x, w = t(seeded.tensor(11, "x", (M, K), -2, 2), dev), t(seeded.tensor(11, "w", (N, K), -0.3, 0.3), dev)
+    b, r = t(seeded.tensor(11, "b", (N,), -1, 1), dev), t(seeded.tensor(11, "r", (M, N), -1, 1), dev)
+    outs = []
+    try:
+        os.environ["AVSEP_GEMM_TILE"] = tile
+        os.environ["AVSEP_PERSIST_ROUNDS"] = rounds
+        os.environ["AVSEP_PERSIST"] = "1"
+        for off in (False, True):
+            if off:
+                os.environ.pop("AVSEP_PERSIST")
+            y = torch.full((M, N), float("nan"), device=dev)
+            check(lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2,
+                                      _stream()))
+            outs.append(y)
+    finally:
+        for k in ("AVSEP_GEMM_TILE", "AVSEP_PERSIST_ROUNDS", "AVSEP_PERSIST"):
+            os.environ.pop(k, None)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.functional.gelu(x.double() @ w.double().T + b.double()) + r.double()
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,act", [(700, 384, 512, 1), (1001, 260, 256, 2), (333, 96, 64, 0), (2100, 1536, 512, 0),
+                                       (129, 64, 480, 3)])
+def test_op_ln_linear_forms_agree(lib, dev, M, N, K, act):
+    """LayerNorm -> Linear in its three forms: form 2 (statistics launch + normalisation while the GEMM stages A: what
+    large batches run) is BIT-identical to form 0 (LayerNorm launch + GEMM) on every tile; form 1 (statistics inside
+    the GEMM, one-pass sums) agrees to rounding; all agree with float64."""
+    import os
+    from av_separation._native import check
+    x = seeded.tensor(13, "x", (M, K), -3, 5)
+    w = seeded.tensor(13, "w", (N, K), -0.2, 0.2)
+    g_, be_, b_ = seeded.tensor(13, "g", (K,), 0.5, 1.5), seeded.tensor(13, "be", (K,), -1, 1), seeded.tensor(13, "b", (N,), -1, 1)
+    xd, wd, gd, bed, bd = (t(a, dev) for a in (x, w, g_, be_, b_))
+    scratch = torch.empty(M * K, device=dev)
+
+    def run(form):
+        y = torch.full((M, N), float("nan"), device=dev)
+        check(lib.avsep_op_ln_linear(xd.data_ptr(), gd.data_ptr(), bed.data_ptr(), wd.data_ptr(), bd.data_ptr(),
+                                     y.data_ptr(), scratch.data_ptr(), M, N, K, act, 1e-5, form, _stream()))
+        return y
+
+    ln = onp.layer_norm(x.astype(np.float64), g_.astype(np.float64), be_.astype(np.float64))
+    ref = torch.from_numpy(ln @ w.astype(np.float64).T + b_.astype(np.float64))
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.nn.functional.gelu(ref), 3: torch.sigmoid(ref)}[act]
+    try:
+        for tile in (None, "32x32x32", "64x32x32", "64x64x32", "128x64x32"):
+            if tile:
+                os.environ["AVSEP_GEMM_TILE"] = tile
+            y0, y2 = run(0), run(2)
+            assert torch.isfinite(y0).all()
+            assert torch.equal(y0, y2), tile
+            assert (y0.double().cpu() - ref).abs().max().item() < 2e-5
+    finally:
+        os.environ.pop("AVSEP_GEMM_TILE", None)
+    if K <= 256:
+        y1 = run(1)
+        assert (y1.double().cpu() - ref).abs().max().item() < 2e-5
+
+
+def test_op_ln_linear_rejects_bad_forms(lib, dev):
+    y = torch.empty(64 * 1024, device=dev)
+    p_ = y.data_ptr()
+    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 1024, 0, 1e-5, 2, _stream()) == -1   # K > 512
+    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 512, 0, 1e-5, 1, _stream()) == -1    # K > 256
+    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, None, 4, 4, 64, 0, 1e-5, 2, _stream()) == -1    # no scratch
+    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 64, 0, 1e-5, 7, _stream()) == -1
+
+
 def test_op_linear_rejects_bad_k(lib, dev):
     y = torch.empty(4, 4, device=dev)
     assert lib.avsep_op_linear(y.data_ptr(), y.data_ptr(), None, None, y.data_ptr(), 4, 4, 30, 0, _stream()) == -1
