@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 //     read is 16 lanes x 16 different rows at one column), V rows [key][64] linear (its fragment read is 16 lanes x one
 //     row); double-buffered, global -> registers before the stage's MFMAs, registers -> LDS after them, one barrier.
 //   * no wave leaves early (barriers): waves without queries compute on clamped rows and store nothing.
-template <int QT, int KT>
-__global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restrict__ q, int ldq,
+template <int QT, int KT, bool DROP>
+__global__ __launch_bounds__(256, DROP ? 1 : (QT == 2 ? 3 : 4)) void attention_lds_kernel(const float* __restrict__ q, int ldq,
                                                             const float* __restrict__ k, int ldk,
                                                             const float* __restrict__ v, int ldv,
                                                             float* __restrict__ o, int ldo, int nhead, int Lq, int Lk,
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restr
           }
           lrun[t] = lrun[t] * alpha + psum;
           mrun[t] = mnew;
-          if (drop_p > 0.0f) {
+          if (DROP && drop_p > 0.0f) {   // DROP = false: the inference instance carries none of this
             const float keep_scale = 1.0f / (1.0f - drop_p);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -537,11 +537,18 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
   const bool no_lds_now = getenv("AVSEP_ATTN_NO_LDS_NOW") != nullptr;      // ... per call (the bit-identity test)
   if (reg && nb == 4 && Lk >= 128 && !no_lds && !no_lds_now) {
     // long sequences: K / V through LDS, shared by the workgroup's four waves (bit-identical to the kernels below)
-    if (two) {
-      hipLaunchKernelGGL((attention_lds_kernel<2, 2>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead,
-                         Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
+    const bool drop = drop_p > 0.0f;
+    if (two && drop) {
+      hipLaunchKernelGGL((attention_lds_kernel<2, 2, true>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,
+                         nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
+    } else if (two) {
+      hipLaunchKernelGGL((attention_lds_kernel<2, 2, false>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,
+                         nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
+    } else if (drop) {
+      hipLaunchKernelGGL((attention_lds_kernel<1, 2, true>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt,
+                         qscale, lse, drop_p, drop_seed);
     } else {
-      hipLaunchKernelGGL((attention_lds_kernel<1, 2>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt,
+      hipLaunchKernelGGL((attention_lds_kernel<1, 2, false>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt,
                          qscale, lse, drop_p, drop_seed);
     }
     return hipGetLastError();

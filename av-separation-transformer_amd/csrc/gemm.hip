@@ -298,8 +298,8 @@ __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int slot) {
 // (launch bound for the fragment-prefetch instance: 3 waves per SIMD = 168 registers; it sits at 170 otherwise.  The
 // staged-LayerNorm instances whose LDS image admits three workgroups per CU get the same bound: 128x64 sits at 186
 // without it, and with it spills 24 registers around -- not inside -- the K loop.)
-template <int BM, int BN, int BK, int AMODE, bool PF = false>
-__global__ __launch_bounds__(256, (PF || (AMODE == AMODE_LN && (BM + BN) * BK <= 6144)) ? 3 : 1) void gemm_kernel(const GemmParams pin) {
+template <int BM, int BN, int BK, int AMODE, bool PF = false, int RING = 0>
+__global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + BN) * BK <= 6144)) ? 3 : 1) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
   dbg_stamp(p, 0);
   if (p.ksplit > 1) {                      // block-uniform: slice blockIdx.y of the contraction
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, (PF || (AMODE == AMODE_LN && (BM + BN) * BK <=
   // Register prefetch ring (even depth).  Measured on MI355X (profiles/r01b_*): neither a deeper ring nor a
   // larger BK moves the M ~ 2k shapes -- small tiles sit at the L2 -> CU feed limit (8-11 flop per byte),
   // big tiles lack workgroups -- so the ring stays shallow and cheap in registers.
-  constexpr int D = (APASS + BPASS <= 4) ? 4 : 2;
+  constexpr int D = RING ? RING : (APASS + BPASS <= 4) ? 4 : 2;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
   // AMODE_LN: gamma | beta of the fused LayerNorm (K <= LN_KMAX floats each) sit behind the two tile buffers
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK + (AMODE == AMODE_LN ? 2 * LN_KMAX : 0)];
@@ -1300,18 +1300,18 @@ bool try_launch_persist(const GemmParams& p, hipStream_t s, hipError_t* err) {
   return true;
 }
 
-template <int BM, int BN, int BK, int AMODE, bool PF = false>
+template <int BM, int BN, int BK, int AMODE, bool PF = false, int RING = 0>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   if (p.dbg) {   // diagnostics: what the runtime says about residency of this instance
     int nb = 0;
     hipFuncAttributes fa{};
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gemm_kernel<BM, BN, BK, AMODE, PF>), 256, 0);
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemm_kernel<BM, BN, BK, AMODE, PF>));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(gemm_kernel<BM, BN, BK, AMODE, PF, RING>), 256, 0);
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemm_kernel<BM, BN, BK, AMODE, PF, RING>));
     fprintf(stderr, "[gemm dbg] instance <%d,%d,%d,%d,%d>: occupancy API %d workgroups / CU, numRegs %d, static LDS %zu B, scratch %zu B\n",
             BM, BN, BK, AMODE, (int)PF, nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE, PF>), dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE, PF, RING>), dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -1586,6 +1586,8 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
     }
   }
   if (fragment_prefetch(t, p)) return launch_t<64, 64, 32, AMODE_PLAIN, true>(p, s);
+  if (getenv("AVSEP_6464_RING2") && t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN)   // developer A/B
+    return launch_t<64, 64, 32, AMODE_PLAIN, false, 2>(p, s);
 #define AVSEP_CASE(BM_, BN_, BK_, AM_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
 #define AVSEP_MODES(BM_, BN_, BK_) \
