@@ -1438,7 +1438,9 @@ bool gemm_ln_supported(int K) {
 
 // long contractions on the 64x64 tile: see mfma_chunk
 bool fragment_prefetch(const Tile& t, const GemmParams& p) {
-  static const int kmin = getenv("AVSEP_PF_KMIN") ? atoi(getenv("AVSEP_PF_KMIN")) : 1024;   // developer sweep
+  // off by default since the ring-2 instance (4 workgroups per CU) beats it at every K measured; AVSEP_PF_KMIN=1024
+  // restores the round-1 choice
+  static const int kmin = getenv("AVSEP_PF_KMIN") ? atoi(getenv("AVSEP_PF_KMIN")) : 1 << 30;   // developer sweep
   return t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && p.K >= kmin;
 }
 
@@ -1456,15 +1458,17 @@ const char* gemm_instance_name(const GemmParams& p) {
   }
   const Tile t = pick_tile(p);
   if (p.ln_stats) {
-    snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false>", t.bm, t.bn, t.bk, (int)AMODE_LN);
+    snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false, 0>", t.bm, t.bn, t.bk, (int)AMODE_LN);
     return buf;
   }
   if (is_g32(t)) snprintf(buf, sizeof buf, "gemm32_kernel<%d, %d, %d, %s>", t.bm, t.bn, p.amode, g32_prefetch() ? "true" : "false");
   else if (fragment_prefetch(t, p) && persist_grid<64, 64, 32, true>(p)) snprintf(buf, sizeof buf, "gemm_persist_kernel<64, 64, 32, true>");
   else if (!fragment_prefetch(t, p) && t.bm == 128 && t.bn == 64 && t.bk == 32 && persist_grid<128, 64, 32, false>(p)) snprintf(buf, sizeof buf, "gemm_persist_kernel<128, 64, 32, false>");
   else if (!fragment_prefetch(t, p) && t.bm == 64 && t.bn == 64 && t.bk == 32 && persist_grid<64, 64, 32, false>(p)) snprintf(buf, sizeof buf, "gemm_persist_kernel<64, 64, 32, false>");
-  else if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true>");
-  else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false>", t.bm, t.bn, t.bk, p.amode);   // as rocprofv3 prints it
+  else if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true, 0>");
+  else if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !getenv("AVSEP_6464_RING4"))
+    snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, false, 2>");
+  else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false, 0>", t.bm, t.bn, t.bk, p.amode);   // as rocprofv3 prints it
   return buf;
 }
 
@@ -1586,7 +1590,10 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
     }
   }
   if (fragment_prefetch(t, p)) return launch_t<64, 64, 32, AMODE_PLAIN, true>(p, s);
-  if (getenv("AVSEP_6464_RING2") && t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN)   // developer A/B
+  // 64x64x32, plain A: register ring of depth 2 instead of 4 -> 104 registers, 4 workgroups per CU instead of 3
+  // (profiles/r02_ab_ring2_64x64.txt: +1..3 % on the N = 512 shapes, and with it the fragment-prefetch instance no
+  // longer pays for its registers at K = 2048: 269.6 vs 275.4 us).  AVSEP_6464_RING4 = the old instance.
+  if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !getenv("AVSEP_6464_RING4"))
     return launch_t<64, 64, 32, AMODE_PLAIN, false, 2>(p, s);
 #define AVSEP_CASE(BM_, BN_, BK_, AM_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
