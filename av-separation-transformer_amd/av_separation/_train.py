@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -92,6 +93,46 @@ def _colsum(a, b=None):
     return o0, o1
 
 
+# ------------------------------------------------------------------------------- weight gradients beside the chain
+# The backward pass is a dependent chain of activation gradients (dX of one layer feeds the layer below); the weight and
+# bias gradients hang off it and nothing in the backward consumes them.  At the training batch (16 clips: M = 4016 rows)
+# neither kind of kernel fills 256 CUs, so the parameter gradients of a Linear are launched on a second stream, beside
+# the chain, and the two streams are joined once, when the backward pass ends (autograd engine callback), before
+# anything can read a ``.grad``.  Only for LEAF parameters whose ``.grad`` is still None: autograd then just stores the
+# returned tensor (no kernel touches it on the main stream).  Accumulation into an existing ``.grad`` (a second
+# backward, GradBuckets' bucket views in data-parallel runs) and non-leaf weights (the conv layers' reshaped kernels)
+# take the in-line path.  AVSEP_TRAIN_NO_SIDE_STREAM=1 switches it off (developer A/B).
+_SIDE = {}
+SIDE_STREAM_WGRAD = os.environ.get("AVSEP_TRAIN_NO_SIDE_STREAM") is None
+
+
+def _side(device):
+    st = _SIDE.get(device.index)
+    if st is None:
+        st = _SIDE[device.index] = {"stream": torch.cuda.Stream(device=device), "joined": True}
+    return st
+
+
+def _beside_chain(dev, params):
+    """The second stream if every tensor of ``params`` may take its gradient from it (see above), else None."""
+    if not SIDE_STREAM_WGRAD or not torch.cuda.is_available():
+        return None
+    for q in params:
+        if q is None or not q.is_leaf or q.grad is not None or q._backward_hooks:
+            return None
+    return _side(dev)
+
+
+def _join_at_end_of_backward(st, main):
+    if st["joined"]:
+        st["joined"] = False
+
+        def join():
+            main.wait_stream(st["stream"])
+            st["joined"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
 # ----------------------------------------------------------------------------------------------- autograd ops
 def _wgrad(dyt, xt):
     """dW [N, K] from the transposed operands dY^T [N, R], X^T [K, R] (split over the rows R when N*K is small)."""
@@ -119,6 +160,19 @@ def _wgrad_direct(dy, x):
     return dw
 
 
+def _wgrad_bias_direct(dy, x):
+    """(dW [N, K], db [N]) from one launch: views of one buffer (the bias gradient rides the weight-gradient kernel)."""
+    R, N = dy.shape
+    K = x.shape[1]
+    lib = _lib()
+    buf = torch.empty(N * K + N, device=dy.device)
+    ns = lib.avsep_op_wgrad_bias_direct_scratch_floats(N, K, R)
+    scratch = torch.empty(ns, device=dy.device) if ns else None
+    _ck(lib.avsep_op_wgrad_bias_direct(dy.data_ptr(), N, x.data_ptr(), K, buf.data_ptr(),
+                                       scratch.data_ptr() if ns else None, N, K, R, _st(dy)), "wgrad_bias_direct")
+    return buf[:N * K].view(N, K), buf[N * K:]
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x w^T + b) + res;  act in {none, relu}; res: same-shape residual (grad flows) or constant rows with
     period `rperiod` (positional encoding, no grad)."""
@@ -131,6 +185,7 @@ class LinearFn(torch.autograd.Function):
         ctx.act, ctx.res_grad = act, (res is not None and rperiod <= 0)
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.has_b = b is not None
+        ctx.bias = b if isinstance(b, torch.nn.Parameter) else None      # identity only (leaf / .grad checks in backward)
         return y
 
     @staticmethod
@@ -151,14 +206,37 @@ class LinearFn(torch.autograd.Function):
             dpp = dpre if Np == N else F.pad(dpre, (0, Np - N))          # zero K-padding (layout only)
             wt = _transpose(w, Np)                                         # [K, Np] = w^T
             dx = _gemm(dpp, wt, None, None, 0, ACT_NONE)                   # dY W
-        if ctx.needs_input_grad[1]:
-            if N % 4 == 0:
-                dw = _wgrad_direct(dpre, x)                                                # dY^T X  [N, K], no copies
-            else:                                                                          # e.g. 3 x 257 mask channels
-                Mp = (M + 63) // 64 * 64                                                  # zero rows: layout only
-                dw = _wgrad(_transpose(dpre, Mp), _transpose(x, Mp))
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            db, _ = _colsum(dpre)
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
+
+        def param_grads():
+            gw = gb = None
+            if want_w and want_b and N % 4 == 0:
+                return _wgrad_bias_direct(dpre, x)
+            if want_w:
+                if N % 4 == 0:
+                    gw = _wgrad_direct(dpre, x)                                            # dY^T X  [N, K], no copies
+                else:                                                                      # e.g. 3 x 257 mask channels
+                    Mp = (M + 63) // 64 * 64                                              # zero rows: layout only
+                    gw = _wgrad(_transpose(dpre, Mp), _transpose(x, Mp))
+            if want_b:
+                gb, _ = _colsum(dpre)
+            return gw, gb
+
+        owners = ([w] if want_w else []) + ([ctx.bias] if want_b else [])
+        st = _beside_chain(dy.device, owners) if owners and dy.is_cuda else None
+        if st is None:
+            dw, db = param_grads()
+        else:
+            main, side = torch.cuda.current_stream(dy.device), st["stream"]
+            side.wait_stream(main)                                       # dpre (and x, long since) are ready
+            with torch.cuda.stream(side):
+                dw, db = param_grads()
+            for tns in (dpre, x):                                        # their memory may not be reused under the side stream
+                tns.record_stream(side)
+            for tns in (dw, db):                                         # allocated in the side stream's pool, read on main
+                if tns is not None:
+                    tns.record_stream(main)
+            _join_at_end_of_backward(st, main)
         dres = dy if (ctx.res_grad and ctx.needs_input_grad[4]) else None
         return dx, dw, db, None, dres, None
 

@@ -547,6 +547,9 @@ struct WgradParams {
   float* dw;         // [N][K] (+ z * N*K per slice)
   int R, N, K, ldy, ldx;
   int rchunk;        // rows per slice (multiple of 32), gridDim.y slices
+  int bias;          // 1: also the bias gradient db[n] = sum_r dY[r][n], written behind each slice's N*K weight gradients
+                     //    (slice stride N*K + N) by the workgroups of the first K tile -- the column sums of the dY
+                     //    chunks they stage anyway, instead of two more launches per layer (colreduce)
 };
 
 template <int BM, int BN>
@@ -567,7 +570,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int r_begin = blockIdx.y * p.rchunk;
   const int r_end = min(p.R, r_begin + p.rchunk);
   const int nk = (r_end - r_begin + BK - 1) / BK;
-  float* out = p.dw + (size_t)blockIdx.y * p.N * p.K;
+  float* out = p.dw + (size_t)blockIdx.y * ((size_t)p.N * p.K + (p.bias ? p.N : 0));
+  const bool do_bias = p.bias && bn == 0;            // block-uniform
+  f32x4 bsum[AL];
+#pragma unroll
+  for (int l = 0; l < AL; ++l) bsum[l] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // staging: load l of this thread covers r-row kr and float4 column cv of the tile
   int a_kr[AL], a_col[AL], b_kr[BL], b_col[BL];
@@ -605,6 +612,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int l = 0; l < AL; ++l) {
       const int idx = tid + 256 * l, kr = idx / AV, mrow = 4 * (idx % AV);
+      if (do_bias) bsum[l] += ra[slot][l];            // every chunk is stored exactly once; rows >= r_end hold zeros
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = mrow + e;
@@ -659,6 +667,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         if (kc + 2 < nk) store_chunk(0, 0);
         __syncthreads();
       }
+    }
+  }
+  if (do_bias) {
+    // thread (kr, cv) holds the sum over its chunks' rows kr of columns 4cv..4cv+3: the 32 kr partials of a column are
+    // summed through LDS (free after the K loop's last barrier) in a fixed order
+    float* red = lds;                                  // [BK][BM]
+#pragma unroll
+    for (int l = 0; l < AL; ++l) *reinterpret_cast<f32x4*>(red + 4 * (tid + 256 * l)) = bsum[l];
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.N) {                  // N % 4 == 0: an in-range column was never a clamped duplicate
+      float t = 0.0f;
+#pragma unroll
+      for (int kr = 0; kr < BK; ++kr) t += red[kr * BM + tid];
+      out[(size_t)p.N * p.K + m0 + tid] = t;
     }
   }
   GemmParams q{};   // float4 rows (K % 4 == 0 is a precondition of this kernel)
@@ -1629,9 +1651,9 @@ int wgrad_slices(int N, int K, int R) {
 }
 
 hipError_t launch_wgrad(const float* dy, int ldy, const float* x, int ldx, float* out, int N, int K, int R, int slices,
-                        hipStream_t s) {
+                        bool with_bias, hipStream_t s) {
   if (N <= 0 || K <= 0 || R <= 0 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || slices < 1) return hipErrorInvalidValue;
-  WgradParams p{dy, x, out, R, N, K, ldy, ldx, 0};
+  WgradParams p{dy, x, out, R, N, K, ldy, ldx, 0, with_bias ? 1 : 0};
   p.rchunk = slices > 1 ? (((R + slices - 1) / slices + 31) / 32 * 32) : ((R + 31) / 32 * 32);
   const long tiles64 = (long)((N + 63) / 64) * ((K + 63) / 64);
   if (tiles64 >= 256) {

@@ -69,8 +69,9 @@ struct GemmParams {
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
+// with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)
 hipError_t launch_wgrad(const float* dy, int ldy, const float* x, int ldx, float* out, int N, int K, int R, int slices,
-                        hipStream_t s);
+                        bool with_bias, hipStream_t s);
 const char* gemm_instance_name(const GemmParams& p);
 bool gemm_ln_supported(int K);                          // can launch_gemm() fuse a LayerNorm over K columns?   // template instance launch_gemm() will pick
 

@@ -105,10 +105,31 @@ int avsep_op_wgrad_direct(const float* dy, int ldy, const float* x, int ldx, flo
   const int sl = wgrad_slices(N, K, R);
   if (sl > 1) {
     if (!scratch) return fail(AVSEP_EINVAL, "wgrad_direct needs avsep_op_wgrad_direct_scratch_floats() floats of scratch");
-    TCK(launch_wgrad(dy, ldy, x, ldx, scratch, N, K, R, sl, S(stream)));
+    TCK(launch_wgrad(dy, ldy, x, ldx, scratch, N, K, R, sl, false, S(stream)));
     TCK(launch_sum_slices(scratch, dw, sl, (size_t)N * K, S(stream)));
   } else {
-    TCK(launch_wgrad(dy, ldy, x, ldx, dw, N, K, R, 1, S(stream)));
+    TCK(launch_wgrad(dy, ldy, x, ldx, dw, N, K, R, 1, false, S(stream)));
+  }
+  return AVSEP_OK;
+}
+
+int64_t avsep_op_wgrad_bias_direct_scratch_floats(int N, int K, int R) {
+  const int sl = wgrad_slices(N, K, R);
+  return sl > 1 ? (int64_t)sl * ((int64_t)N * K + N) : 0;
+}
+
+int avsep_op_wgrad_bias_direct(const float* dy, int ldy, const float* x, int ldx, float* dwb, float* scratch, int N,
+                               int K, int R, void* stream) {
+  if (!dy || !x || !dwb || N <= 0 || K <= 0 || R <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if ((N & 3) || (K & 3) || (ldy & 3) || (ldx & 3))
+    return fail(AVSEP_EINVAL, "wgrad_bias_direct needs N, K and both row strides to be multiples of 4");
+  const int sl = wgrad_slices(N, K, R);
+  if (sl > 1) {
+    if (!scratch) return fail(AVSEP_EINVAL, "wgrad_bias_direct needs avsep_op_wgrad_bias_direct_scratch_floats() floats of scratch");
+    TCK(launch_wgrad(dy, ldy, x, ldx, scratch, N, K, R, sl, true, S(stream)));
+    TCK(launch_sum_slices(scratch, dwb, sl, (size_t)N * K + N, S(stream)));
+  } else {
+    TCK(launch_wgrad(dy, ldy, x, ldx, dwb, N, K, R, 1, true, S(stream)));
   }
   return AVSEP_OK;
 }

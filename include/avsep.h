@@ -186,6 +186,12 @@ int avsep_op_wgrad(const float* dyt, const float* xt, float* dw, float* scratch,
 int64_t avsep_op_wgrad_direct_scratch_floats(int N, int K, int R);
 int avsep_op_wgrad_direct(const float* dy, int ldy, const float* x, int ldx, float* dw, float* scratch, int N, int K,
                           int R, void* stream);
+/* The same launch also producing the bias gradient db[n] = sum_r dy[r][n] (the workgroups of the first K tile add up the
+ * dy chunks they stage anyway -- two launches per layer less than a separate column reduction): dwb holds N*K weight
+ * gradients followed by N bias gradients. */
+int64_t avsep_op_wgrad_bias_direct_scratch_floats(int N, int K, int R);
+int avsep_op_wgrad_bias_direct(const float* dy, int ldy, const float* x, int ldx, float* dwb, float* scratch, int N,
+                               int K, int R, void* stream);
 
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                              int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,
