@@ -1640,11 +1640,25 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
 
 // dW = dY^T X straight from the row-major activations (no transposes).  Returns the number of r-slices used through
 // *slices (1 = dw written directly; > 1 = `partial` holds the slices, the caller sums them).
-int wgrad_slices(int N, int K, int R) {
+// Tile and r-slices of the weight-gradient launch (tools/wgrad_sweep.py, profiles/r02_wgrad_sweep.txt).  One slice
+// walks all R rows serially (160 us at R = 4016 whatever the tile count), so the contraction is cut until ~1024
+// workgroups exist; 64x64 tiles from 128 tiles up (or 64 with a long contraction), 32x32 below.
+// (AVSEP_WGRAD_TILE / AVSEP_WGRAD_SLICES: developer sweeps)
+static int wgrad_tile(int N, int K, int R) {
+  if (const char* e = getenv("AVSEP_WGRAD_TILE")) return atoi(e) == 64 ? 64 : 32;
   const long tiles64 = (long)((N + 63) / 64) * ((K + 63) / 64);
-  const long tiles = tiles64 >= 256 ? tiles64 : (long)((N + 31) / 32) * ((K + 31) / 32);
-  if (tiles >= 512 || R < 1024) return 1;
-  long want = std::min<long>((1024 + tiles - 1) / tiles, R / 256);
+  return (tiles64 >= 128 || (tiles64 >= 64 && R >= 2048)) ? 64 : 32;
+}
+int wgrad_slices(int N, int K, int R) {
+  const int bt = wgrad_tile(N, K, R);
+  const long tiles = (long)((N + bt - 1) / bt) * ((K + bt - 1) / bt);
+  long want;
+  if (const char* e = getenv("AVSEP_WGRAD_SLICES")) {
+    want = atol(e);
+  } else {
+    if (tiles >= 1024 || R < 1024) return 1;
+    want = std::min<long>(1024 / tiles, R / 256);
+  }
   if (want < 2) return 1;
   const int rchunk = (int)(((R + want - 1) / want + 31) / 32 * 32);
   return (R + rchunk - 1) / rchunk;
@@ -1656,7 +1670,7 @@ hipError_t launch_wgrad(const float* dy, int ldy, const float* x, int ldx, float
   WgradParams p{dy, x, out, R, N, K, ldy, ldx, 0, with_bias ? 1 : 0};
   p.rchunk = slices > 1 ? (((R + slices - 1) / slices + 31) / 32 * 32) : ((R + 31) / 32 * 32);
   const long tiles64 = (long)((N + 63) / 64) * ((K + 63) / 64);
-  if (tiles64 >= 256) {
+  if (wgrad_tile(N, K, R) == 64) {
     hipLaunchKernelGGL((wgrad_kernel<64, 64>), dim3((unsigned)tiles64, slices), dim3(256), 0, s, p);
   } else {
     const long tiles = (long)((N + 31) / 32) * ((K + 31) / 32);
