@@ -96,29 +96,33 @@ __device__ __forceinline__ bool epilogue_is_fast(const GemmParams& p) {      // 
   return !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3)) && !p.C2 && !p.epi_general && p.mag_F == 0;
 }
 
-template <int WBM, int WBN>
+// HAS_R = false: no residual / positional rows -- no second operand is fetched at all.  (The first straight-line version
+// fetched the C tile itself as a stand-in to keep one code path: 32 KB per 128x64 tile of never-used, HBM-cold reads
+// that the stores then waited behind -- the QKV / FFN-1 / decoder GEMMs, 70 % of the large configs' flops, have no
+// residual.  profiles/r02_ab_epilogue_no_residual_fetch.txt)
+template <int WBM, int WBN, bool HAS_R>
 __device__ __forceinline__ void epilogue_load(const GemmParams& p, EpiOperands<WBM, WBN>& o, int mbase, int nbase, int fr,
                                               int fq) {
-  const bool has_b = p.bias != nullptr, has_r = p.R != nullptr;            // block-uniform
+  const bool has_b = p.bias != nullptr;                                     // block-uniform
   const float* bsrc = has_b ? p.bias : p.W;                               // W: at least N*K >= N floats, always readable
-  const float* rsrc = has_r ? p.R : p.C;
-  const int ldr = has_r ? p.ldr : p.ldc;
 #pragma unroll
   for (int j = 0; j < WBN; ++j) o.bv[j] = *reinterpret_cast<const f32x4*>(bsrc + min(nbase + 16 * j + 4 * fq, p.N - 4));
+  if (HAS_R) {
 #pragma unroll
-  for (int i = 0; i < WBM; ++i) {
-    const int mc = min(mbase + 16 * i + fr, p.M - 1);
-    const int rr = (has_r && p.rperiod > 0) ? (mc % p.rperiod) : mc;
+    for (int i = 0; i < WBM; ++i) {
+      const int mc = min(mbase + 16 * i + fr, p.M - 1);
+      const int rr = p.rperiod > 0 ? (mc % p.rperiod) : mc;
 #pragma unroll
-    for (int j = 0; j < WBN; ++j)
-      o.rv[i][j] = *reinterpret_cast<const f32x4*>(rsrc + (size_t)rr * ldr + min(nbase + 16 * j + 4 * fq, p.N - 4));
+      for (int j = 0; j < WBN; ++j)
+        o.rv[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + min(nbase + 16 * j + 4 * fq, p.N - 4));
+    }
   }
 }
 
-template <int WBM, int WBN, int ACT>
+template <int WBM, int WBN, int ACT, bool HAS_R>
 __device__ __forceinline__ void epilogue_finish(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], EpiOperands<WBM, WBN>& o,
                                                 int mbase, int nbase, int fr, int fq) {
-  const bool has_b = p.bias != nullptr, has_r = p.R != nullptr;
+  const bool has_b = p.bias != nullptr;
 #pragma unroll
   for (int i = 0; i < WBM; ++i)
 #pragma unroll
@@ -133,7 +137,7 @@ __device__ __forceinline__ void epilogue_finish(const GemmParams& p, const f32x4
         for (int e = 0; e < 4; ++e) x[e] = act_t<ACT>(x[e]);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o.rv[i][j][e] = has_r ? x[e] + o.rv[i][j][e] : x[e];
+      for (int e = 0; e < 4; ++e) o.rv[i][j][e] = HAS_R ? x[e] + o.rv[i][j][e] : x[e];
     }
 #pragma unroll
   for (int i = 0; i < WBM; ++i)
@@ -144,14 +148,14 @@ __device__ __forceinline__ void epilogue_finish(const GemmParams& p, const f32x4
     }
 }
 
-template <int WBM, int WBN>
+template <int WBM, int WBN, bool HAS_R>
 __device__ __forceinline__ void epilogue_finish_act(const GemmParams& p, const f32x4 (&acc)[WBM][WBN],
                                                     EpiOperands<WBM, WBN>& o, int mbase, int nbase, int fr, int fq) {
   switch (p.act) {                                // block-uniform: one straight-line expansion per activation
-    case ACT_RELU: epilogue_finish<WBM, WBN, ACT_RELU>(p, acc, o, mbase, nbase, fr, fq); break;
-    case ACT_GELU: epilogue_finish<WBM, WBN, ACT_GELU>(p, acc, o, mbase, nbase, fr, fq); break;
-    case ACT_SIGMOID: epilogue_finish<WBM, WBN, ACT_SIGMOID>(p, acc, o, mbase, nbase, fr, fq); break;
-    default: epilogue_finish<WBM, WBN, ACT_NONE>(p, acc, o, mbase, nbase, fr, fq); break;
+    case ACT_RELU: epilogue_finish<WBM, WBN, ACT_RELU, HAS_R>(p, acc, o, mbase, nbase, fr, fq); break;
+    case ACT_GELU: epilogue_finish<WBM, WBN, ACT_GELU, HAS_R>(p, acc, o, mbase, nbase, fr, fq); break;
+    case ACT_SIGMOID: epilogue_finish<WBM, WBN, ACT_SIGMOID, HAS_R>(p, acc, o, mbase, nbase, fr, fq); break;
+    default: epilogue_finish<WBM, WBN, ACT_NONE, HAS_R>(p, acc, o, mbase, nbase, fr, fq); break;
   }
 }
 
@@ -189,8 +193,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
   const bool v2 = !(p.N & 1) && !(p.ldc & 1);
   if (epilogue_is_fast(p)) {                      // every GEMM of the model but the mask head
     EpiOperands<WBM, WBN> o;
-    epilogue_load<WBM, WBN>(p, o, m0 + mw, n0 + nw, fr, fq);
-    epilogue_finish_act<WBM, WBN>(p, acc, o, m0 + mw, n0 + nw, fr, fq);
+    if (p.R) {                                    // block-uniform: two straight-line expansions
+      epilogue_load<WBM, WBN, true>(p, o, m0 + mw, n0 + nw, fr, fq);
+      epilogue_finish_act<WBM, WBN, true>(p, acc, o, m0 + mw, n0 + nw, fr, fq);
+    } else {
+      epilogue_load<WBM, WBN, false>(p, o, m0 + mw, n0 + nw, fr, fq);
+      epilogue_finish_act<WBM, WBN, false>(p, acc, o, m0 + mw, n0 + nw, fr, fq);
+    }
     return;
   }
   // ---- general path: N not a multiple of 4 and / or the mask head's second output (separated = masks * mixture,
