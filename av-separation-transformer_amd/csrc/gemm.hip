@@ -1370,16 +1370,22 @@ Tile pick_tile(const GemmParams& p) {
   // yields >= 8 per CU (cuts L2 traffic on the very large problems; never faster than 64x64 below that)
   const long slices = p.ksplit > 1 ? p.ksplit : 1;
   auto blocks = [&](int bm, int bn) { return slices * ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  static const long t64 = getenv("AVSEP_T64") ? atol(getenv("AVSEP_T64")) : 512;       // developer sweeps
+  // developer sweeps.  t64 = 448: the M = 4016 (training batch) x 512 outputs give 504 tiles of 64x64, 4-6 % faster than
+  // 64x32 there (profiles/r02_gemm_tile_sweep.txt); no inference shape falls between 448 and 512
+  static const long t64 = getenv("AVSEP_T64") ? atol(getenv("AVSEP_T64")) : 448;
   static const long t6432 = getenv("AVSEP_T6432") ? atol(getenv("AVSEP_T6432")) : 512;
   // measured (profiles/r02_gemm_tile_sweep.txt): the 32x32x2 large-tile kernel is bit-identical but 3-8 % SLOWER than the
   // 128x64 / 64x64 16x16x4 tiles on every cfg3-5 shape, so it is off unless a developer asks for it (AVSEP_T128)
+  // 128x64 from 1000 tiles (profiles/r02_gemm_tile_sweep.txt: since the residual-free epilogue it also wins the
+  // N = 512 shapes of M = 16 k, 1008 tiles); the mask head (N % 4 != 0, two outputs: block-by-block epilogue) keeps 2048
+  static const long t12864 = getenv("AVSEP_T12864") ? atol(getenv("AVSEP_T12864")) : 1000;
   static const long t128 = getenv("AVSEP_T128") ? atol(getenv("AVSEP_T128")) : 1L << 40;
   static const long t256 = getenv("AVSEP_T256") ? atol(getenv("AVSEP_T256")) : 1L << 40;
   Tile pick{32, 32, 32};
   const bool g32_ok = (p.amode == AMODE_PLAIN || p.amode == AMODE_TAPS3) && slices == 1 && p.mag_F == 0;
   if (g32_ok && blocks(256, 128) >= t256) pick = Tile{256, 128, 32};
   else if (g32_ok && blocks(128, 128) >= t128) pick = Tile{128, 128, 32};
+  else if (blocks(128, 64) >= t12864 && !(p.N & 3) && !p.C2) pick = Tile{128, 64, 32};
   else if (blocks(128, 64) >= 2048) pick = Tile{128, 64, 32};
   else if (blocks(64, 64) >= t64) pick = Tile{64, 64, 32};
   else if (blocks(64, 32) >= t6432) pick = Tile{64, 32, 32};

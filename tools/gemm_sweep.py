@@ -9,7 +9,8 @@ SHAPES = [(2016, 256, 256), (2016, 256, 1024), (2016, 768, 256), (2016, 1024, 25
           (2016, 514, 512), (1600, 256, 256), (1600, 768, 256), (1600, 1024, 256), (1600, 256, 1024),
           (1600, 256, 128), (3200, 512, 512), (3200, 2048, 512), (3200, 512, 2048),
           (16064, 512, 512), (16064, 1536, 512), (16064, 2048, 512), (16064, 512, 2048), (16064, 514, 1024),
-          (16032, 4096, 512)]
+          (16032, 4096, 512), (4016, 512, 512), (4016, 1536, 512), (4016, 2048, 512), (4016, 512, 2048), (8032, 512, 512),
+          (8032, 2048, 512), (8032, 512, 2048)]
 if os.environ.get("SWEEP_BIG"):
     SHAPES = [s_ for s_ in SHAPES if s_[0] >= 3200]
 
