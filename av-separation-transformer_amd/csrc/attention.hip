@@ -24,6 +24,29 @@ namespace {
 // exp(x) for x <= 0 with a compensated argument: x*log2(e) is split into its rounded product and the exact
 // rounding error (fma) plus the low part of log2(e), so the relative error stays ~1 ulp even for |x| ~ 100
 // (plain exp2(x*log2e) loses |x|*6e-8).  One v_exp_f32 + 5 VALU.
+// Reductions over the four lanes {c, c+16, c+32, c+48} that hold one query's partial results (the four 16-lane rows of
+// a wave).  The shuffle form (xor 16, xor 32) compiles to ds_bpermute_b32 -- a round trip through the LDS crossbar (its
+// latency sits in the middle of the QK^T -> softmax -> PV chain of every key tile, and it shares lgkmcnt with the K / V
+// fragment reads).  gfx950's v_permlane16_swap / v_permlane32_swap exchange rows inside the VALU: swapping a value with
+// itself leaves (row 0|0|2|2, row 1|1|3|3) resp. (low half twice, high half twice), and combining the pair gives every
+// lane the reduction -- the same values as the shuffle form (max and the two-term sums are commutative), bit for bit.
+__device__ __forceinline__ float rows_max(float v) {
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  u = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ float exp_neg(float x) {
   const float L2E_HI = 1.44269502162933349609f, L2E_LO = 1.92596299112661746e-08f;
   x = fmaxf(x, -120.0f);          // exp2(-173) is exactly 0 on v_exp_f32; keeps -inf (masked keys, first tile) finite
@@ -150,8 +173,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         st[t][r] = key < Lk ? st[t][r] : -INFINITY;
         tmax = fmaxf(tmax, st[t][r]);
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      tmax = rows_max(tmax);
       const float mnew = fmaxf(mrun[t], tmax);        // finite: tile 0 always holds key 0
       const float alpha = exp_neg(mrun[t] - mnew);     // 0 on the first tile (mrun = -inf)
       float psum = 0.0f;
@@ -189,8 +211,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     float l = lrun[t];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    l = rows_sum(l);
     const float inv = 1.0f / l;
     const int qo = (qw * QT + t) * 16 + c;
     if (lse && g == 0 && qo < Lq) lse[(size_t)bh * Lq + qo] = mrun[t] + logf(l);   // training: softmax statistics
@@ -343,8 +364,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : (QT == 2 ? 3 : 4)) void attention_l
             stt[t][r] = key < Lk ? stt[t][r] : -INFINITY;
             tmax = fmaxf(tmax, stt[t][r]);
           }
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+          tmax = rows_max(tmax);
           const float mnew = fmaxf(mrun[t], tmax);
           const float alpha = exp_neg(mrun[t] - mnew);
           float psum = 0.0f;
@@ -384,8 +404,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : (QT == 2 ? 3 : 4)) void attention_l
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     float l = lrun[t];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    l = rows_sum(l);
     const float inv = 1.0f / l;
     const int qo = (qw * QT + t) * 16 + c;
     if (lse && g == 0 && qo < Lq) lse[(size_t)bh * Lq + qo] = mrun[t] + logf(l);
@@ -464,8 +483,7 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const float* __res
       st[kt][r] = key < Lk ? st[kt][r] : -INFINITY;
       mrow = fmaxf(mrow, st[kt][r]);
     }
-  mrow = fmaxf(mrow, __shfl_xor(mrow, 16));
-  mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+  mrow = rows_max(mrow);
   float lrun = 0.0f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
@@ -484,8 +502,7 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const float* __res
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
         acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][blk], st[kt][r], acc[blk], 0, 0, 0);
-  lrun += __shfl_xor(lrun, 16);
-  lrun += __shfl_xor(lrun, 32);
+  lrun = rows_sum(lrun);
   const float inv = 1.0f / lrun;
   const int qo = qt * 16 + c;
   if (qo < Lq) {
