@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 //     row); double-buffered, global -> registers before the stage's MFMAs, registers -> LDS after them, one barrier.
 //   * no wave leaves early (barriers): waves without queries compute on clamped rows and store nothing.
 template <int QT, int KT, bool DROP>
-__global__ __launch_bounds__(256, DROP ? 1 : (QT == 2 ? 3 : 4)) void attention_lds_kernel(const float* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256, QT == 4 ? 2 : DROP ? 1 : (QT == 2 ? 3 : 4)) void attention_lds_kernel(const float* __restrict__ q, int ldq,
                                                             const float* __restrict__ k, int ldk,
                                                             const float* __restrict__ v, int ldv,
                                                             float* __restrict__ o, int ldo, int nhead, int Lq, int Lk,
@@ -540,7 +540,8 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
   const int nb = (dh + 15) / 16;
   const bool reg = (dh == 16 * nb);
   // two query tiles per wave once the sequence is long enough to keep >= 2 workgroups per CU that way
-  static const int qt_env = getenv("AVSEP_ATTN_QT") ? atoi(getenv("AVSEP_ATTN_QT")) : 0;   // developer A/B switch
+  const char* qt_s = getenv("AVSEP_ATTN_QT");                      // developer A/B switch, read per call (bit-identity test)
+  const int qt_env = qt_s ? atoi(qt_s) : 0;
   const long wgs2 = (long)B * nhead * (((nqt + 1) / 2 + 3) / 4);
   const bool two = qt_env ? qt_env == 2 : (reg && nb == 4 && wgs2 >= 512);
 #define AVSEP_ATT(NB_)                                                                                              \
@@ -555,6 +556,16 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
   if (reg && nb == 4 && Lk >= 128 && !no_lds && !no_lds_now) {
     // long sequences: K / V through LDS, shared by the workgroup's four waves (bit-identical to the kernels below)
     const bool drop = drop_p > 0.0f;
+    // Four query tiles per wave (inference): one workgroup covers 256 queries, so L = 251 is ONE workgroup per (clip, head)
+    // and the 512 workgroups of configs 3 / 5 are exactly one round at two workgroups per CU -- with two tiles per wave
+    // they are 1024 workgroups on 768 slots, a second round one third full.  (profiles/r02_attention_bench.txt)
+    const long wgs4 = (long)B * nhead * (((nqt + 3) / 4 + 3) / 4);
+    const bool four = qt_env ? qt_env == 4 : false;
+    if (four && !drop) {
+      hipLaunchKernelGGL((attention_lds_kernel<4, 2, false>), dim3((unsigned)wgs4), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,
+                         nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
+      return hipGetLastError();
+    }
     if (two && drop) {
       hipLaunchKernelGGL((attention_lds_kernel<2, 2, true>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,
                          nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);

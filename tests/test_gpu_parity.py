@@ -451,17 +451,23 @@ def test_op_attention_lds_variant_is_bit_identical(lib, dev, B, h, Lq, Lk):
     kd = t(seeded.tensor(5, "k", (B, Lk, d), -1.5, 1.5), dev)
     vd = t(seeded.tensor(5, "v", (B, Lk, d), -2, 2), dev)
     outs = []
-    for env in (None, "1"):
-        if env:
-            os.environ["AVSEP_ATTN_NO_LDS_NOW"] = env
-        else:
-            os.environ.pop("AVSEP_ATTN_NO_LDS_NOW", None)
-        o = torch.full((B, Lq, d), float("nan"), device=dev)
-        check(lib.avsep_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d, B, h, dh,
-                                     Lq, Lk, _stream()))
-        outs.append(o)
-    os.environ.pop("AVSEP_ATTN_NO_LDS_NOW", None)
-    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    try:
+        # register-streaming kernel, then the LDS kernel with 1 / 2 / 4 query tiles per wave (the launcher's own choice
+        # is one of these): a query tile's arithmetic does not depend on how many tiles share its wave
+        for env in ({"AVSEP_ATTN_NO_LDS_NOW": "1"}, {"AVSEP_ATTN_QT": "1"}, {"AVSEP_ATTN_QT": "2"}, {"AVSEP_ATTN_QT": "4"}, {}):
+            for k_ in ("AVSEP_ATTN_NO_LDS_NOW", "AVSEP_ATTN_QT"):
+                os.environ.pop(k_, None)
+            os.environ.update(env)
+            o = torch.full((B, Lq, d), float("nan"), device=dev)
+            check(lib.avsep_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d, B, h, dh,
+                                         Lq, Lk, _stream()))
+            outs.append(o)
+    finally:
+        for k_ in ("AVSEP_ATTN_NO_LDS_NOW", "AVSEP_ATTN_QT"):
+            os.environ.pop(k_, None)
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
 
 
 @pytest.mark.parametrize("B,N,T,d", [(2, 10, 32, 64), (2, 50, 63, 256), (1, 12, 5, 32), (3, 1, 7, 64),
