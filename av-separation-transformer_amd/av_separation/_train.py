@@ -95,15 +95,17 @@ def _colsum(a, b=None):
 
 # ------------------------------------------------------------------------------- weight gradients beside the chain
 # The backward pass is a dependent chain of activation gradients (dX of one layer feeds the layer below); the weight and
-# bias gradients hang off it and nothing in the backward consumes them.  At the training batch (16 clips: M = 4016 rows)
-# neither kind of kernel fills 256 CUs, so the parameter gradients of a Linear are launched on a second stream, beside
-# the chain, and the two streams are joined once, when the backward pass ends (autograd engine callback), before
-# anything can read a ``.grad``.  Only for LEAF parameters whose ``.grad`` is still None: autograd then just stores the
-# returned tensor (no kernel touches it on the main stream).  Accumulation into an existing ``.grad`` (a second
-# backward, GradBuckets' bucket views in data-parallel runs) and non-leaf weights (the conv layers' reshaped kernels)
-# take the in-line path.  AVSEP_TRAIN_NO_SIDE_STREAM=1 switches it off (developer A/B).
+# bias gradients hang off it and nothing in the backward consumes them.  They CAN be launched on a second stream, beside
+# the chain, the two streams being joined once when the backward pass ends (autograd engine callback), before anything
+# can read a ``.grad``: only for LEAF parameters whose ``.grad`` is still None (autograd then just stores the returned
+# tensor, no kernel touches it on the main stream); accumulation into an existing ``.grad`` (a second backward,
+# GradBuckets' bucket views in data-parallel runs) and non-leaf weights (the conv layers' reshaped kernels) always take
+# the in-line path.  Measured on the cfg4 step (profiles/r02_ab_train_side_stream.txt): +2 % while the bias gradient was
+# two more launches per layer, -1.5 % since it rides the weight-gradient kernel -- the step's host enqueue time (13.5 ms
+# of 17.5) grows by 1.5 ms with the stream switches, which costs more than the overlap returns.  So it is OFF unless
+# AVSEP_TRAIN_SIDE_STREAM=1 (or ``_train.SIDE_STREAM_WGRAD = True``); tests/test_train_gpu.py keeps it bit-identical.
 _SIDE = {}
-SIDE_STREAM_WGRAD = os.environ.get("AVSEP_TRAIN_NO_SIDE_STREAM") is None
+SIDE_STREAM_WGRAD = os.environ.get("AVSEP_TRAIN_SIDE_STREAM") is not None
 
 
 def _side(device):

@@ -121,6 +121,47 @@ def test_training_step_reduces_loss_and_eval_sees_new_weights():
     assert float((masks_after - masks_before).abs().max()) > 1e-2
 
 
+def test_side_stream_parameter_gradients_are_bit_identical():
+    """The optional second-stream form of the Linear layers' parameter gradients (_train.SIDE_STREAM_WGRAD) launches the
+    same kernels on another stream and joins at the end of the backward pass: every gradient must equal the in-line
+    path's bit for bit, also when read immediately after backward() and over repeated steps (stream-ordering check)."""
+    import av_separation as av
+    from av_separation import _train as tr
+    from av_separation.losses import SeparationLoss
+    dev = torch.device("cuda:0")
+    ds = av.SyntheticAVDataset(num_samples=8, sample_rate=8000, duration=1.0, n_fft=256, hop_length=128, num_frames=10,
+                               frame_h=16, frame_w=16)
+    items = [ds[i] for i in range(8)]
+    mixed = torch.stack([x["mixed_spec"] for x in items]).to(dev)
+    lips = torch.stack([x["lip_frames"] for x in items]).to(dev)
+    tg = torch.stack([x["clean_specs"] for x in items]).to(dev)
+    crit = SeparationLoss(0.5)
+    grads = {}
+    old = tr.SIDE_STREAM_WGRAD
+    try:
+        for side in (False, True):
+            tr.SIDE_STREAM_WGRAD = side
+            torch.manual_seed(3)
+            m = av.AVSeparationTransformer(freq_bins=129, d_model=128, nhead=4, num_encoder_layers=2,
+                                           num_fusion_layers=2, num_speakers=2, dropout=0.0).to(dev).train()
+            per_step = []
+            for _ in range(3):
+                m.zero_grad(set_to_none=True)
+                sep, _ = m(mixed, lips)
+                crit(sep, tg).backward()
+                per_step.append({n: p.grad.clone() for n, p in m.named_parameters()})   # read right after backward()
+                with torch.no_grad():
+                    for p in m.parameters():
+                        p.sub_(1e-3 * p.grad)
+            grads[side] = per_step
+    finally:
+        tr.SIDE_STREAM_WGRAD = old
+    for a, b in zip(grads[False], grads[True]):
+        assert a.keys() == b.keys()
+        for n in a:
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_dropout_training_is_self_consistent():
     """dropout > 0 (the reference's default 0.1): masks cannot match torch's RNG stream, so check what must hold
     anyway: same seed -> same output, different seed -> different; keep rate and 1/(1-p) scaling of the mask;

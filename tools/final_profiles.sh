@@ -21,6 +21,10 @@ echo "rocprof done"
 cd $R && bash tools/pmc_bench.sh > $O/${TAG}_pmc_hbm_traffic.txt 2>&1; cp $R/gpurun_out/pmc_bench/pmc_hbm_traffic.json $O/pmc_hbm_traffic.json
 bash tools/pmc_mfma.sh > $O/${TAG}_pmc_mfma_cfg2.txt 2>&1
 echo "pmc done"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload cfg3 --no-cpu --no-profile --inflight 1 --steps 20 --warmup 3 > /dev/null 2>&1
+cp $(find $O/kt -name "*kernel_stats.csv") $O/${TAG}_bench_cfg3_kernel_stats.csv; rm -rf $O/kt
+cd $R
 for w in cfg3 cfg5; do timeout -k 10 500 python bench.py --workload $w --steps 20 --warmup 3 --cpu-seconds 6 > $O/${TAG}_bench_${w}.json 2>/dev/null; echo "bench $w done"; done
 timeout -k 10 300 python bench.py --mode train --steps 10 --warmup 3 --cpu-seconds 4 > $O/${TAG}_bench_train_cfg4.json 2>/dev/null
 cd /tmp
@@ -34,6 +38,10 @@ AVSEP_GEMM_DBG=all python tools/one_fwd.py cfg2 2 2>&1 | grep "gemm dbg" | grep 
 tools/clock_probe.sh auto 64x64x32 128x128x32 > $O/${TAG}_clock_probe.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/placement.hip -o /tmp/placement 2>/dev/null && /tmp/placement > $O/${TAG}_workgroup_placement.txt
 (python tools/inflight_bench.py; INFLIGHT_SHARED=1 python tools/inflight_bench.py) 2>&1 | grep replicas > $O/${TAG}_steps_in_flight.txt
+python tools/attn_bench.py 2>/dev/null | grep -v Warn > $O/${TAG}_attention_kernel_bench.txt
+python tools/ln_bench.py 2>/dev/null | grep -v Warn > $O/${TAG}_layernorm_kernel_bench.txt
+python tools/wgrad_sweep.py 2>/dev/null | grep -v Warn > $O/${TAG}_wgrad_sweep.txt
+bash tools/pmc_gemm.sh 2>&1 | grep -v Warn > $O/${TAG}_pmc_gemm_large_shapes.txt
 python tools/chain_bench.py 2>/dev/null > $O/${TAG}_chain_bench.txt
 python tools/stage_bench.py 2>/dev/null | grep -v Warn > $O/${TAG}_stage_bench.txt
 ls -la $O
