@@ -5,6 +5,11 @@
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd $R
+# HBM traffic first: bench.py fills roofline.traffic from profiles/pmc_hbm_traffic.json only when its build id matches the
+# loaded library, so the PMC passes of THIS build must be in place before the bench line is taken
+bash tools/pmc_bench.sh > $O/${TAG}_pmc_hbm_traffic.txt 2>&1; cp $R/gpurun_out/pmc_bench/pmc_hbm_traffic.json $O/pmc_hbm_traffic.json
+cp $O/pmc_hbm_traffic.json $R/profiles/pmc_hbm_traffic.json
+echo "pmc traffic done"
 python bench.py --stream > $O/${TAG}_bench_cfg2.json 2>$O/bench.err
 echo "bench cfg2 done"
 cd /tmp; export TMPDIR=/tmp
@@ -18,7 +23,7 @@ cp $(find $O/kt -name "*kernel_stats.csv") $O/${TAG}_bench_cfg2_graph_only_kerne
 python3 $R/tools/trace_step.py $(find $O/kt -name "*kernel_trace.csv") > $O/${TAG}_step_timeline.txt 2>&1
 rm -rf $O/kt
 echo "rocprof done"
-cd $R && bash tools/pmc_bench.sh > $O/${TAG}_pmc_hbm_traffic.txt 2>&1; cp $R/gpurun_out/pmc_bench/pmc_hbm_traffic.json $O/pmc_hbm_traffic.json
+cd $R
 bash tools/pmc_mfma.sh > $O/${TAG}_pmc_mfma_cfg2.txt 2>&1
 echo "pmc done"
 cd /tmp
