@@ -294,7 +294,9 @@ __device__ __forceinline__ void mfma_chunk(const float* a, const float* b, const
 // ds_read_b128 (16-lane groups = 16 rows x one logical slot) for 128-, 256- and 512-byte rows.
 template <int SLOTS>
 __device__ __forceinline__ int swz(int row) {
-  return SLOTS == 8 ? ((row >> 1) & 7) : (row & 15);
+  // 64-byte rows (SLOTS == 4): 16 rows x one slot span four 16-bank groups four times over -> rows r, r+4, r+8, r+12 take
+  // four different slots
+  return SLOTS == 4 ? ((row >> 2) & 3) : SLOTS == 8 ? ((row >> 1) & 7) : (row & 15);
 }
 
 // Developer diagnostics (AVSEP_GEMM_DBG=1): one lane per workgroup stamps the 100 MHz wall clock at entry, after the
@@ -1626,6 +1628,8 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
       if (try_launch_persist<64, 64, 32, false>(p, s, &pe)) return pe;
     }
   }
+  if (t.bm == 128 && t.bn == 64 && t.bk == 16 && p.amode == AMODE_PLAIN)   // developer instance: four workgroups per CU
+    return launch_t<128, 64, 16, AMODE_PLAIN, false, 2>(p, s);
   if (fragment_prefetch(t, p)) return launch_t<64, 64, 32, AMODE_PLAIN, true>(p, s);
   // 64x64x32, plain A: register ring of depth 2 instead of 4 -> 104 registers, 4 workgroups per CU instead of 3
   // (profiles/r02_ab_ring2_64x64.txt: +1..3 % on the N = 512 shapes, and with it the fragment-prefetch instance no

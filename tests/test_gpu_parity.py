@@ -299,7 +299,7 @@ def test_op_linear_tiles_bit_identical(lib, dev):
     b, r = t(seeded.tensor(7, "b", (N,), -1, 1), dev), t(seeded.tensor(7, "r", (M, N), -1, 1), dev)
     outs = {}
     try:
-        for tile in ("32x32x32", "32x32x64", "64x32x64", "64x64x32", "64x64x32/ring4", "128x64x32", "128x128x32", "256x128x32"):
+        for tile in ("32x32x32", "32x32x64", "64x32x64", "64x64x32", "64x64x32/ring4", "128x64x32", "128x64x16", "128x128x32", "256x128x32"):
             os.environ["AVSEP_GEMM_TILE"] = tile.split("/")[0]
             os.environ.pop("AVSEP_6464_RING4", None)
             if tile.endswith("/ring4"):       # the deeper register ring the 64x64 tile used before (3 workgroups per CU)

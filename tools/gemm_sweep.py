@@ -4,7 +4,7 @@ workload.  Tiles are forced through the AVSEP_GEMM_TILE developer override, one 
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))
-TILES = ["256x128x32", "128x128x32", "128x128x32/nopf", "128x64x32", "64x64x32", "64x64x64", "64x32x32", "64x32x64", "32x32x32", "32x32x64"]
+TILES = ["256x128x32", "128x128x32", "128x128x32/nopf", "128x64x32", "128x64x16", "64x64x32", "64x64x64", "64x32x32", "64x32x64", "32x32x32", "32x32x64"]
 SHAPES = [(2016, 256, 256), (2016, 256, 1024), (2016, 768, 256), (2016, 1024, 256), (2016, 512, 256),
           (2016, 514, 512), (1600, 256, 256), (1600, 768, 256), (1600, 1024, 256), (1600, 256, 1024),
           (1600, 256, 128), (3200, 512, 512), (3200, 2048, 512), (3200, 512, 2048),
