@@ -57,6 +57,24 @@ __device__ __forceinline__ float exp_neg(float x) {
   return fmaf(e, r * 0.69314718055994530942f, e);
 }
 
+// exp_neg on a pair with packed fp32 VALU (v_pk_mul / v_pk_fma issue two lanes' worth of IEEE operations per instruction
+// at the scalar instruction's cost): the same operations in the same order as exp_neg, so the same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp_neg2(f32x2 x) {
+  const f32x2 HI = {1.44269502162933349609f, 1.44269502162933349609f};
+  const f32x2 LO = {1.92596299112661746e-08f, 1.92596299112661746e-08f};
+  const f32x2 LN2 = {0.69314718055994530942f, 0.69314718055994530942f};
+  x[0] = fmaxf(x[0], -120.0f);
+  x[1] = fmaxf(x[1], -120.0f);
+  const f32x2 t = x * HI;
+  f32x2 r = __builtin_elementwise_fma(x, HI, -t);
+  r = __builtin_elementwise_fma(x, LO, r);
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(t[0]);
+  e[1] = __builtin_amdgcn_exp2f(t[1]);
+  return __builtin_elementwise_fma(e, r * LN2, e);
+}
+
 // NB = ceil(dh / 16).  REG = (dh == 16*NB): the fast path with unpredicated vector loads; otherwise the head
 // is zero-extended to 16*NB (k >= dh contributes 0 to S, rows dv >= dh of O^T are never stored).
 // QT = 16-query tiles per wave.  With QT = 2 every K / V fragment fetched from L2 feeds two score tiles and two
@@ -355,24 +373,23 @@ __global__ __launch_bounds__(256, QT == 4 ? 2 : DROP ? 1 : (QT == 2 ? 3 : 4)) vo
 #pragma unroll
             for (int t = 0; t < QT; ++t) stt[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[s][j], qf[t][s][j], stt[t], 0, 0, 0);
         float pr[QT][4];
+        const bool ragged = (kt + 1) * 16 > Lk;         // block-uniform: only the last tile can hold keys >= Lk
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-          float tmax = -INFINITY;
+          if (ragged) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + 4 * g + r;
-            stt[t][r] = key < Lk ? stt[t][r] : -INFINITY;
-            tmax = fmaxf(tmax, stt[t][r]);
+            for (int r = 0; r < 4; ++r) stt[t][r] = kt * 16 + 4 * g + r < Lk ? stt[t][r] : -INFINITY;
           }
+          float tmax = fmaxf(fmaxf(fmaxf(fmaxf(-INFINITY, stt[t][0]), stt[t][1]), stt[t][2]), stt[t][3]);
           tmax = rows_max(tmax);
           const float mnew = fmaxf(mrun[t], tmax);
           const float alpha = exp_neg(mrun[t] - mnew);
-          float psum = 0.0f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            pr[t][r] = exp_neg(stt[t][r] - mnew);
-            psum += pr[t][r];
-          }
+          // the four probabilities as two packed pairs (same operations, same order, same bits as exp_neg per element)
+          const f32x2 m2 = {mnew, mnew};
+          const f32x2 p01 = exp_neg2(f32x2{stt[t][0], stt[t][1]} - m2);
+          const f32x2 p23 = exp_neg2(f32x2{stt[t][2], stt[t][3]} - m2);
+          pr[t][0] = p01[0]; pr[t][1] = p01[1]; pr[t][2] = p23[0]; pr[t][3] = p23[1];
+          const float psum = (((0.0f + pr[t][0]) + pr[t][1]) + pr[t][2]) + pr[t][3];
           lrun[t] = lrun[t] * alpha + psum;
           mrun[t] = mnew;
           if (DROP && drop_p > 0.0f) {   // DROP = false: the inference instance carries none of this
@@ -384,8 +401,12 @@ __global__ __launch_bounds__(256, QT == 4 ? 2 : DROP ? 1 : (QT == 2 ? 3 : 4)) vo
               pr[t][r] = dropout_keep(drop_seed, e, drop_p) ? pr[t][r] * keep_scale : 0.0f;
             }
           }
+          const f32x2 a2 = {alpha, alpha};
 #pragma unroll
-          for (int i = 0; i < NB; ++i) acc[t][i] *= alpha;
+          for (int i = 0; i < NB; ++i) {                // v_pk_mul_f32 on the accumulator's register pairs
+            const f32x2 lo = f32x2{acc[t][i][0], acc[t][i][1]} * a2, hi = f32x2{acc[t][i][2], acc[t][i][3]} * a2;
+            acc[t][i] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
