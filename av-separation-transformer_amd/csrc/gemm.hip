@@ -666,7 +666,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     store_chunk(0, 0);
     if (nk > 1) load_chunk(1, 1);
     __syncthreads();
-    for (int kc = 0; kc < nk; kc += 2) {
+    // Steady state (as in gemm_kernel): pairs of chunks in which every refill exists, so the loads are unconditional and
+    // the compiler can count them -- with the guarded form alone every ds_write of the older ring slot waited for ALL
+    // outstanding loads (vmcnt(0)), i.e. one memory round trip per chunk: PMC had the matrix pipes 34-50 % busy with
+    // LDS and its bank conflicts NOT what the waves waited for (profiles/r02_wgrad_staging_experiment.txt).
+    int kc = 0;
+    for (; kc + 4 <= nk; kc += 2) {
+      load_chunk(kc + 2, 0);
+      mfma_chunk<BK, WBM, WBN>(As, Bs, a_off, a_swz, b_off, b_swz, fq, acc);
+      store_chunk(1, 1);
+      __syncthreads();
+      load_chunk(kc + 3, 1);
+      mfma_chunk<BK, WBM, WBN>(As + BM * BK, Bs + BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+      store_chunk(0, 0);
+      __syncthreads();
+    }
+    for (; kc < nk; kc += 2) {
       // even chunk: LDS buffer 0, ring slot 0 free -> prefetch chunk kc+2
       if (kc + 2 < nk) load_chunk(kc + 2, 0);
       mfma_chunk<BK, WBM, WBN>(As, Bs, a_off, a_swz, b_off, b_swz, fq, acc);
