@@ -30,6 +30,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -135,6 +136,79 @@ def _join_at_end_of_backward(st, main):
         torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
+# ------------------------------------------------------------------------------------ W^T of the Linear weights
+# dX = dY W needs W^T (the GEMM's second operand is K-contiguous).  One transposition launch in front of every layer's
+# activation-gradient GEMM is 76 launches of ~5 us on the backward's chain per cfg4 step; instead every LEAF weight that
+# went through LinearFn.forward is kept in a per-device table and ONE launch (avsep_op_transpose_many) refreshes all
+# their transposes at the first backward after a forward.  The buffers persist across steps (same size as the weights).
+class _WtTable:
+    def __init__(self, device):
+        self.device = device
+        self.index = {}            # id(weight) -> position
+        self.weights, self.bufs, self.ptrs = [], [], []
+        self.table = None          # device bytes: avsep_transpose_desc[n]
+        self.stale = True          # a forward ran since the last refresh
+        self.max_rp = self.max_c = 1
+
+    def register(self, w):
+        i = self.index.get(id(w))
+        if i is None or self.ptrs[i] != w.data_ptr() or self.weights[i]() is not w:
+            if i is None:
+                i = len(self.weights)
+                self.index[id(w)] = i
+                self.weights.append(None); self.bufs.append(None); self.ptrs.append(0)
+            n, k = w.shape
+            self.weights[i] = weakref.ref(w)
+            self.bufs[i] = torch.empty(k, _up32(n), device=w.device, dtype=torch.float32)
+            self.ptrs[i] = w.data_ptr()
+            self.table = None
+        self.stale = True
+
+    def get(self, w):
+        """W^T [K, up32(N)] of a registered weight (refreshing every entry if a forward ran since), else None."""
+        i = self.index.get(id(w))
+        if i is None or self.ptrs[i] != w.data_ptr() or self.weights[i]() is not w:
+            return None
+        if self.stale:
+            self._refresh()
+        return self.bufs[i]
+
+    def _refresh(self):
+        import numpy as np
+        for i, r in enumerate(self.weights):               # weights that died with their model: drop the buffers
+            if r is not None and r() is None and self.bufs[i] is not None:
+                self.bufs[i] = None
+                self.table = None
+        live = [(r(), b) for r, b in zip(self.weights, self.bufs) if r is not None and r() is not None and b is not None]
+        if not live:
+            self.stale = False
+            return
+        if self.table is None or self.table.shape[0] != 32 * len(live):
+            desc = np.zeros(len(live), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("R", "<i4"), ("C", "<i4"),
+                                                        ("Rp", "<i4"), ("pad", "<i4")]))
+            for j, (w, b) in enumerate(live):
+                desc[j] = (w.data_ptr(), b.data_ptr(), w.shape[0], w.shape[1], b.shape[1], 0)
+            self.max_rp = max(int(b.shape[1]) for _, b in live)
+            self.max_c = max(int(w.shape[1]) for w, _ in live)
+            self.table = torch.from_numpy(desc.view(np.uint8).copy()).to(self.device)
+            self.n = len(live)
+        _ck(_lib().avsep_op_transpose_many(self.table.data_ptr(), self.n, self.max_rp, self.max_c,
+                                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+            "avsep_op_transpose_many")
+        self.stale = False
+
+
+_WT = {}
+BATCHED_WT = os.environ.get("AVSEP_TRAIN_NO_BATCHED_WT") is None      # developer A/B switch
+
+
+def _wt_table(device):
+    t = _WT.get(device.index)
+    if t is None:
+        t = _WT[device.index] = _WtTable(device)
+    return t
+
+
 # ----------------------------------------------------------------------------------------------- autograd ops
 def _wgrad(dyt, xt):
     """dW [N, K] from the transposed operands dY^T [N, R], X^T [K, R] (split over the rows R when N*K is small)."""
@@ -188,6 +262,8 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.has_b = b is not None
         ctx.bias = b if isinstance(b, torch.nn.Parameter) else None      # identity only (leaf / .grad checks in backward)
+        if BATCHED_WT and w.is_cuda and w.is_leaf and ctx.needs_input_grad[0]:
+            _wt_table(w.device).register(w)
         return y
 
     @staticmethod
@@ -206,7 +282,9 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Np = _up32(N)
             dpp = dpre if Np == N else F.pad(dpre, (0, Np - N))          # zero K-padding (layout only)
-            wt = _transpose(w, Np)                                         # [K, Np] = w^T
+            wt = _wt_table(w.device).get(w) if (BATCHED_WT and w.is_cuda and w.is_leaf) else None
+            if wt is None:
+                wt = _transpose(w, Np)                                     # [K, Np] = w^T
             dx = _gemm(dpp, wt, None, None, 0, ACT_NONE)                   # dY W
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
 

@@ -93,6 +93,9 @@ hipError_t launch_attention_bwd(const float* q, int ldq, const float* k, int ldk
 hipError_t launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s);
 // training-path kernels (train_ops.hip)
 hipError_t launch_transpose2d(const float* x, float* y, int R, int C, int Rp, hipStream_t s);
+// one launch for a device-resident table of transpositions (layout = avsep_transpose_desc of include/avsep.h)
+struct TransposeDesc { const float* src; float* dst; int R, C, Rp, pad; };
+hipError_t launch_transpose_many(const TransposeDesc* table_dev, int n, int max_rp, int max_c, hipStream_t s);
 hipError_t launch_im2col1d(const float* x, float* col, int M, int T, int C, hipStream_t s);
 hipError_t launch_col2im1d(const float* dcol, float* dx, int M, int T, int C, hipStream_t s);
 hipError_t launch_im2col2d(const float* x, float* col, int I, int H, int W, int C, int Ho, int Wo, int Kp, hipStream_t s);

@@ -166,6 +166,13 @@ int avsep_op_transpose(const float* x, float* y, int R, int C, int Rp, void* str
   return AVSEP_OK;
 }
 
+int avsep_op_transpose_many(const void* table_dev, int n, int max_rp, int max_c, void* stream) {
+  if (!table_dev || n <= 0 || max_rp <= 0 || max_c <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  static_assert(sizeof(TransposeDesc) == 32, "avsep_transpose_desc layout");
+  TCK(launch_transpose_many(static_cast<const TransposeDesc*>(table_dev), n, max_rp, max_c, S(stream)));
+  return AVSEP_OK;
+}
+
 int avsep_op_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, void* stream) {
   if (!x || !y || B <= 0 || F <= 0 || T <= 0 || Fp < F) return fail(AVSEP_EINVAL, "bad argument");
   TCK(launch_transpose_pad(x, y, B, F, T, Fp, S(stream)));

@@ -35,6 +35,28 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
   }
 }
 
+// The same transposition for a whole table of matrices in ONE launch (blockIdx.z = table entry): the W^T operands of
+// every Linear layer's activation-gradient GEMM are made once per training step instead of one ~5 us launch in front of
+// each of them (76 per cfg4 step).
+__global__ __launch_bounds__(256) void transpose_many_kernel(const TransposeDesc* __restrict__ table) {
+  __shared__ float tile[32][33];
+  const TransposeDesc d = table[blockIdx.z];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  if (r0 >= d.Rp || c0 >= d.C) return;                 // block-uniform: the grid is sized for the largest entry
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < d.R && c < d.C) ? d.src[(size_t)r * d.C + c] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < d.C && r < d.Rp) d.dst[(size_t)c * d.Rp + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 // Conv1d(k3,p1) im2col on sequence rows: x [B*T][C] -> col [B*T][3*C], col[m][tap*C + c] = x[m+tap-1][c] inside
 // the same sequence, else 0 (model.py:38,40).
 __global__ __launch_bounds__(256) void im2col1d_kernel(const float* __restrict__ x, float* __restrict__ col, int M,
@@ -483,6 +505,11 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 // ------------------------------------------------------------------------------------------ launchers
 hipError_t launch_transpose2d(const float* x, float* y, int R, int C, int Rp, hipStream_t s) {
   hipLaunchKernelGGL(transpose2d_kernel, dim3((Rp + 31) / 32, (C + 31) / 32), dim3(256), 0, s, x, y, R, C, Rp);
+  return hipGetLastError();
+}
+hipError_t launch_transpose_many(const TransposeDesc* table_dev, int n, int max_rp, int max_c, hipStream_t s) {
+  if (n <= 0 || n > 65535 || max_rp <= 0 || max_c <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(transpose_many_kernel, dim3((max_rp + 31) / 32, (max_c + 31) / 32, n), dim3(256), 0, s, table_dev);
   return hipGetLastError();
 }
 hipError_t launch_im2col1d(const float* x, float* col, int M, int T, int C, hipStream_t s) {

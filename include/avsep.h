@@ -205,6 +205,11 @@ int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, con
                            float qscale, float drop_p, uint64_t drop_seed, void* stream);
 /* y[c][r] = x[r][c] (x [R][C] -> y [C][Rp], zero for r >= R) */
 int avsep_op_transpose(const float* x, float* y, int R, int C, int Rp, void* stream);
+/* The same for n matrices in one launch: `table` is a DEVICE array of n descriptors {src, dst, R, C, Rp, pad} (32 bytes
+ * each, below); max_rp / max_c = the largest Rp / C in the table (grid size).  The training path makes the W^T operands
+ * of all Linear layers' activation-gradient GEMMs with one call per step. */
+typedef struct avsep_transpose_desc { const float* src; float* dst; int R, C, Rp, pad; } avsep_transpose_desc;
+int avsep_op_transpose_many(const void* table, int n, int max_rp, int max_c, void* stream);
 /* (B,F,T) -> (B,T,Fp), zero padded: the layout pass in front of the first Conv1d */
 int avsep_op_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, void* stream);
 /* Conv1d k3 p1 / Conv2d k3 s2 p1 as im2col (+ GEMM) and their adjoints */
