@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "avsep_op_linear_ex", "avsep_op_attention_train", "avsep_op_attention_bwd", "avsep_op_transpose",
     "avsep_op_transpose_pad", "avsep_op_im2col1d", "avsep_op_col2im1d", "avsep_op_im2col2d", "avsep_op_col2im2d",
     "avsep_op_colreduce_scratch_floats", "avsep_op_colreduce", "avsep_op_bn_train_fwd", "avsep_op_bn_train_bwd",
-    "avsep_op_act_fwd", "avsep_op_act_bwd", "avsep_op_mul_mixed", "avsep_op_add_rows", "avsep_read_stamps", "avsep_op_dropout", "avsep_op_wgrad_scratch_floats", "avsep_op_wgrad", "avsep_op_wgrad_direct_scratch_floats",
+    "avsep_op_act_fwd", "avsep_op_act_bwd", "avsep_op_mul_mixed", "avsep_op_add_rows", "avsep_read_stamps", "avsep_op_dropout", "avsep_op_dropout_add", "avsep_op_wgrad_scratch_floats", "avsep_op_wgrad", "avsep_op_wgrad_direct_scratch_floats",
     "avsep_op_wgrad_direct", "avsep_op_wgrad_bias_direct_scratch_floats", "avsep_op_wgrad_bias_direct", "avsep_op_transpose_many",
     "avsep_op_bn_stats", "avsep_op_bn_apply", "avsep_op_bn_bwd_sums", "avsep_op_bn_bwd_dx", "avsep_op_avgpool_fwd", "avsep_op_avgpool_bwd",
     "avsep_op_interp_linear_bwd", "avsep_op_layernorm_bwd",
@@ -90,6 +90,7 @@ def load():
                                            f, u64, p]
     lib.avsep_read_stamps.argtypes = [p, C.POINTER(C.c_uint64), i]
     lib.avsep_op_dropout.argtypes = [fp, fp, i64, f, u64, p]
+    lib.avsep_op_dropout_add.argtypes = [fp, fp, fp, i64, f, u64, p]
     lib.avsep_op_wgrad_scratch_floats.argtypes = [i, i, i]
     lib.avsep_op_wgrad_scratch_floats.restype = C.c_int64
     lib.avsep_op_wgrad.argtypes = [fp, fp, fp, fp, i, i, i, p]

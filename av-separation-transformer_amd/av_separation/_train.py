@@ -559,6 +559,29 @@ class DropoutFn(torch.autograd.Function):
         return dx, None, None
 
 
+class DropoutAddFn(torch.autograd.Function):
+    """res + dropout(x) in one launch; d/dres = dy as it is, d/dx = the dropout op on dy (same mask)."""
+
+    @staticmethod
+    def forward(ctx, x, res, p, seed):
+        x, res = _c(x), _c(res)
+        y = torch.empty_like(x)
+        _ck(_lib().avsep_op_dropout_add(x.data_ptr(), res.data_ptr(), y.data_ptr(), x.numel(), p, seed, _st(x)),
+            "dropout_add")
+        ctx.meta = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            _ck(_lib().avsep_op_dropout(dy.data_ptr(), dx.data_ptr(), dy.numel(), p, seed, _st(dy)), "dropout(bwd)")
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None
+
+
 class AddFn(torch.autograd.Function):
     """x + y (same shape), for residual branches that pass through dropout first."""
 
@@ -721,9 +744,14 @@ def make_drop(module, probs, seed=None, group=None):
     return _Drop(seed, active)
 
 
+FUSED_DROPOUT_ADD = os.environ.get("AVSEP_TRAIN_NO_DROPOUT_ADD") is None    # developer A/B switch (same values either way)
+
+
 def _residual_linear(x_res, inp, w, b, p, drop):
     """x_res + dropout(inp w^T + b): the residual rides the GEMM epilogue unless dropout sits in between."""
     if drop.p(p) > 0:
+        if FUSED_DROPOUT_ADD:
+            return DropoutAddFn.apply(LinearFn.apply(inp, w, b, ACT_NONE, None, 0), x_res, drop.p(p), drop.seed())
         return AddFn.apply(x_res, drop(LinearFn.apply(inp, w, b, ACT_NONE, None, 0), p))
     return LinearFn.apply(inp, w, b, ACT_NONE, x_res, 0)
 

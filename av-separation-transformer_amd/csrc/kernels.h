@@ -91,6 +91,8 @@ hipError_t launch_attention_bwd(const float* q, int ldq, const float* k, int ldk
                                 float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh,
                                 int Lq, int Lk, float qscale, float drop_p, unsigned long long drop_seed, hipStream_t s);
 hipError_t launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s);
+hipError_t launch_dropout_add(const float* x, const float* r, float* y, size_t n, float p, unsigned long long seed,
+                              hipStream_t s);   // y = r + dropout(x)
 // training-path kernels (train_ops.hip)
 hipError_t launch_transpose2d(const float* x, float* y, int R, int C, int Rp, hipStream_t s);
 // one launch for a device-resident table of transpositions (layout = avsep_transpose_desc of include/avsep.h)

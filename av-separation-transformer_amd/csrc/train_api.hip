@@ -149,6 +149,13 @@ int avsep_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed
   return AVSEP_OK;
 }
 
+int avsep_op_dropout_add(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed,
+                         void* stream) {
+  if (!x || !residual || !y || n <= 0 || p < 0.0f || p >= 1.0f) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_dropout_add(x, residual, y, (size_t)n, p, seed, S(stream)));
+  return AVSEP_OK;
+}
+
 int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                            int ldo, const float* d_out, int lddo, const float* lse, float* dvec, float* dq, int lddq,
                            float* dk, int lddk, float* dv, int lddv, int B, int nhead, int dh, int Lq, int Lk,

@@ -367,6 +367,25 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   reinterpret_cast<T*>(y)[idx] = v;
 }
 
+// y = r + dropout(x): the residual add behind dropout1 / dropout2 of a transformer block in the dropout's launch (same
+// two roundings as the separate kernels: the rescaled value, then the sum)
+template <int V>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                          float* __restrict__ y, size_t nv, float p,
+                                                          unsigned long long seed) {
+  typedef typename VecT<V>::type T;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nv) return;
+  T v = reinterpret_cast<const T*>(x)[idx];
+  T w = reinterpret_cast<const T*>(r)[idx];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const float d = dropout_keep(seed, idx * V + e, p) ? lane_of<V>(v, e) / (1.0f - p) : 0.0f;
+    lane_of<V>(v, e) = lane_of<V>(w, e) + d;
+  }
+  reinterpret_cast<T*>(y)[idx] = v;
+}
+
 // y[m][c] = x[m][c] + r[m % period][c]   (x + pe[:, :L], model.py:300, when it cannot ride a GEMM epilogue); C % V == 0
 template <int V>
 __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x, const float* __restrict__ r,
@@ -602,6 +621,12 @@ hipError_t launch_mul_mixed(const float* a, const float* xt, float* out, size_t 
 hipError_t launch_dropout(const float* x, float* y, size_t n, float p, unsigned long long seed, hipStream_t s) {
   if (vec4_ok(n, x, y)) hipLaunchKernelGGL((dropout_kernel<4>), dim3(nblk(n / 4)), dim3(256), 0, s, x, y, n / 4, p, seed);
   else hipLaunchKernelGGL((dropout_kernel<1>), dim3(nblk(n)), dim3(256), 0, s, x, y, n, p, seed);
+  return hipGetLastError();
+}
+hipError_t launch_dropout_add(const float* x, const float* r, float* y, size_t n, float p, unsigned long long seed,
+                              hipStream_t s) {
+  if (vec4_ok(n, x, y, r)) hipLaunchKernelGGL((dropout_add_kernel<4>), dim3(nblk(n / 4)), dim3(256), 0, s, x, r, y, n / 4, p, seed);
+  else hipLaunchKernelGGL((dropout_add_kernel<1>), dim3(nblk(n)), dim3(256), 0, s, x, r, y, n, p, seed);
   return hipGetLastError();
 }
 hipError_t launch_add_rows(const float* x, const float* r, float* y, size_t M, int C, int period, hipStream_t s) {

@@ -198,6 +198,9 @@ int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, c
                              uint64_t drop_seed, void* stream);
 /* inverted dropout y = keep ? x/(1-p) : 0 with the same stateless mask; its backward is the same call on dy */
 int avsep_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* y = residual + dropout(x) in one launch (dropout1 / dropout2 + residual add of a transformer block) */
+int avsep_op_dropout_add(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed,
+                         void* stream);
 /* gradients of softmax((qscale q) k^T) v w.r.t. q, k, v; dvec: B*nhead*Lq floats of scratch; dh % 16 == 0 */
 int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                            int ldo, const float* d_out, int lddo, const float* lse, float* dvec, float* dq, int lddq,
