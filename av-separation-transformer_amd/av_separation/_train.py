@@ -179,6 +179,13 @@ class _WtTable:
             if r is not None and r() is None and self.bufs[i] is not None:
                 self.bufs[i] = None
                 self.table = None
+        for i, r in enumerate(self.weights):               # a weight whose storage was replaced since it registered
+            w = r() if r is not None else None             # (p.data = ..., .to()): never hand its old pointer to the kernel
+            if w is not None and self.bufs[i] is not None and self.ptrs[i] != w.data_ptr():
+                self.ptrs[i] = w.data_ptr()
+                if tuple(self.bufs[i].shape) != (w.shape[1], _up32(w.shape[0])):
+                    self.bufs[i] = torch.empty(w.shape[1], _up32(w.shape[0]), device=w.device, dtype=torch.float32)
+                self.table = None
         live = [(r(), b) for r, b in zip(self.weights, self.bufs) if r is not None and r() is not None and b is not None]
         if not live:
             self.stale = False

@@ -162,6 +162,49 @@ def test_side_stream_parameter_gradients_are_bit_identical():
             assert torch.equal(a[n], b[n]), n
 
 
+def test_batched_weight_transposes_match_per_layer_ones_and_follow_storage_changes():
+    """W^T of all Linear weights comes from one launch per step (_train._WtTable).  Gradients must equal the per-layer
+    transposition path bit for bit, across optimizer updates, and after a parameter's storage is replaced between steps
+    (the table must pick up the new pointer, not read the old one)."""
+    import av_separation as av
+    from av_separation import _train as tr
+    from av_separation.losses import SeparationLoss
+    dev = torch.device("cuda:0")
+    ds = av.SyntheticAVDataset(num_samples=4, sample_rate=8000, duration=1.0, n_fft=256, hop_length=128, num_frames=10,
+                               frame_h=16, frame_w=16)
+    items = [ds[i] for i in range(4)]
+    mixed = torch.stack([x["mixed_spec"] for x in items]).to(dev)
+    lips = torch.stack([x["lip_frames"] for x in items]).to(dev)
+    tg = torch.stack([x["clean_specs"] for x in items]).to(dev)
+    crit = SeparationLoss(0.5)
+    grads = {}
+    old = tr.BATCHED_WT
+    try:
+        for batched in (False, True):
+            tr.BATCHED_WT = batched
+            torch.manual_seed(5)
+            m = av.AVSeparationTransformer(freq_bins=129, d_model=128, nhead=4, num_encoder_layers=2,
+                                           num_fusion_layers=1, num_speakers=2, dropout=0.0).to(dev).train()
+            per_step = []
+            for step in range(3):
+                if step == 2:                                  # replace one weight's storage between steps
+                    w = dict(m.named_parameters())["audio_encoder.transformer.layers.0.linear1.weight"]
+                    w.data = w.data.clone()
+                m.zero_grad(set_to_none=True)
+                sep, _ = m(mixed, lips)
+                crit(sep, tg).backward()
+                per_step.append({n: p.grad.clone() for n, p in m.named_parameters()})
+                with torch.no_grad():
+                    for p in m.parameters():
+                        p.sub_(1e-3 * p.grad)
+            grads[batched] = per_step
+    finally:
+        tr.BATCHED_WT = old
+    for a, b in zip(grads[False], grads[True]):
+        for n in a:
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_dropout_training_is_self_consistent():
     """dropout > 0 (the reference's default 0.1): masks cannot match torch's RNG stream, so check what must hold
     anyway: same seed -> same output, different seed -> different; keep rate and 1/(1-p) scaling of the mask;
