@@ -112,7 +112,7 @@ SIDE_STREAM_WGRAD = os.environ.get("AVSEP_TRAIN_SIDE_STREAM") is not None
 def _side(device):
     st = _SIDE.get(device.index)
     if st is None:
-        st = _SIDE[device.index] = {"stream": torch.cuda.Stream(device=device), "joined": True}
+        st = _SIDE[device.index] = {"stream": torch.cuda.Stream(device=device), "task": None}
     return st
 
 
@@ -127,12 +127,17 @@ def _beside_chain(dev, params):
 
 
 def _join_at_end_of_backward(st, main):
-    if st["joined"]:
-        st["joined"] = False
+    """Queue the join of the two streams ONCE per backward pass.  The pass is identified by autograd's graph-task id, not
+    by a flag the callback resets: a backward that raises never runs its final callbacks, and a flag left behind by it
+    would make every later backward skip the join (gradients read while the side stream still writes them)."""
+    task = torch._C._current_graph_task_id()
+    if task == -1 or st["task"] != task:
+        st["task"] = task
 
         def join():
             main.wait_stream(st["stream"])
-            st["joined"] = True
+            if st["task"] == task:
+                st["task"] = None
         torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
@@ -149,10 +154,26 @@ class _WtTable:
         self.table = None          # device bytes: avsep_transpose_desc[n]
         self.stale = True          # a forward ran since the last refresh
         self.max_rp = self.max_c = 1
+        self.n = 0
+
+    def _usable(self, w):
+        """Only what avsep_op_transpose_many may be handed: a contiguous float32 matrix living on THIS table's device.
+        nn.Module.to() / .cpu() / .half() / .double() swap ``p.data`` on the same Parameter object, so identity and a
+        live weak reference say nothing about where -- or what -- the storage is now."""
+        return (w.dim() == 2 and w.device == self.device and w.dtype == torch.float32 and w.is_contiguous())
+
+    def _drop(self, i):
+        if self.bufs[i] is not None:
+            self.bufs[i] = None
+            self.table = None
 
     def register(self, w):
         i = self.index.get(id(w))
-        if i is None or self.ptrs[i] != w.data_ptr() or self.weights[i]() is not w:
+        if not self._usable(w):
+            if i is not None and self.weights[i] is not None and self.weights[i]() is w:
+                self._drop(i)                               # get() then answers None: the caller transposes by itself
+            return
+        if i is None or self.bufs[i] is None or self.ptrs[i] != w.data_ptr() or self.weights[i]() is not w:
             if i is None:
                 i = len(self.weights)
                 self.index[id(w)] = i
@@ -167,26 +188,45 @@ class _WtTable:
     def get(self, w):
         """W^T [K, up32(N)] of a registered weight (refreshing every entry if a forward ran since), else None."""
         i = self.index.get(id(w))
-        if i is None or self.ptrs[i] != w.data_ptr() or self.weights[i]() is not w:
+        if (i is None or self.bufs[i] is None or self.ptrs[i] != w.data_ptr() or self.weights[i]() is not w
+                or not self._usable(w)):
             return None
         if self.stale:
             self._refresh()
-        return self.bufs[i]
+        return self.bufs[i]                                 # None if the refresh had to drop the entry
 
-    def _refresh(self):
-        import numpy as np
-        for i, r in enumerate(self.weights):               # weights that died with their model: drop the buffers
-            if r is not None and r() is None and self.bufs[i] is not None:
-                self.bufs[i] = None
-                self.table = None
-        for i, r in enumerate(self.weights):               # a weight whose storage was replaced since it registered
-            w = r() if r is not None else None             # (p.data = ..., .to()): never hand its old pointer to the kernel
-            if w is not None and self.bufs[i] is not None and self.ptrs[i] != w.data_ptr():
+    def _compact(self):
+        """Forget the slots of weights that died with their model (their ids may be reused by anything)."""
+        keep = [i for i, r in enumerate(self.weights) if r is not None and r() is not None]
+        if len(keep) == len(self.weights):
+            return
+        self.weights = [self.weights[i] for i in keep]
+        self.bufs = [self.bufs[i] for i in keep]
+        self.ptrs = [self.ptrs[i] for i in keep]
+        self.index = {id(r()): j for j, r in enumerate(self.weights)}
+        self.table = None
+
+    def _descriptors(self):
+        """The entries the next launch may touch: (weight, buffer) pairs, after dropping every entry whose weight has
+        left this device, changed dtype or layout, or whose storage was replaced by one of another shape."""
+        self._compact()
+        for i, r in enumerate(self.weights):
+            w = r()
+            if self.bufs[i] is None:
+                continue
+            if not self._usable(w):                         # .cpu() / .to('cuda:1') / .half() / .double() / a strided view
+                self._drop(i)
+                continue
+            if self.ptrs[i] != w.data_ptr():                # storage replaced on the same device (p.data = ...)
                 self.ptrs[i] = w.data_ptr()
                 if tuple(self.bufs[i].shape) != (w.shape[1], _up32(w.shape[0])):
                     self.bufs[i] = torch.empty(w.shape[1], _up32(w.shape[0]), device=w.device, dtype=torch.float32)
                 self.table = None
-        live = [(r(), b) for r, b in zip(self.weights, self.bufs) if r is not None and r() is not None and b is not None]
+        return [(r(), b) for r, b in zip(self.weights, self.bufs) if b is not None]
+
+    def _refresh(self):
+        import numpy as np
+        live = self._descriptors()
         if not live:
             self.stale = False
             return

@@ -77,8 +77,10 @@ class GradBuckets:
     round one link at a time; and the shard is where a sharded optimizer / gradient norm would hook in.
     Buckets are padded to a multiple of G elements.  Use ``zero_grad()`` of this object (it keeps the views)."""
 
-    def __init__(self, params, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, group=None):
+    def __init__(self, params, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, group=None, timing: bool = False):
         self.group = group
+        self.timing = timing                   # record per-bucket spans of the two collectives (bucket_times_ms())
+        self._times = []
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
@@ -116,10 +118,24 @@ class GradBuckets:
         for b in self.buckets:
             b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
 
+    def _mark(self, b, key):
+        """Timing mark: a device event on the current stream (collectives are stream-ordered through Work.wait()), or
+        the host clock when the exchange is host-staged."""
+        if not self.timing:
+            return
+        if b["flat"].is_cuda and not _staged(b["flat"], self.group):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            b[key] = ev
+        else:
+            import time
+            b[key] = time.perf_counter()
+
     def _launch(self, b):
         b["launched"] = True
         if self.world == 1:
             return
+        self._mark(b, "t_rs0")
         if _staged(b["flat"], self.group):                  # gloo + device tensor (CPU-hosted tests): synchronous
             h, hs = b["flat"].detach().cpu(), torch.empty(b["shard"].numel())
             dist.reduce_scatter_tensor(hs, h, group=self.group)
@@ -152,17 +168,41 @@ class GradBuckets:
         for b in self.buckets:                              # in launch order: the early buckets are done first
             if b["work"] is not None:
                 b["work"].wait()
+            self._mark(b, "t_rs1")
             b["shard"].mul_(1.0 / self.world)
+            self._mark(b, "t_ag0")
             if _staged(b["flat"], self.group):
                 hs, h = b["shard"].detach().cpu(), torch.empty(b["flat"].numel())
                 dist.all_gather_into_tensor(h, hs, group=self.group)
                 b["flat"].copy_(h)
+                self._mark(b, "t_ag1")
             else:
-                gathers.append(dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True))
-        for w in gathers:
+                gathers.append((b, dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True)))
+        for b, w in gathers:
             w.wait()
+            self._mark(b, "t_ag1")
         self.exposed_wait_s = time.perf_counter() - t0
+        if self.timing:
+            self._times = [{k: b.get(k) for k in ("t_rs0", "t_rs1", "t_ag0", "t_ag1")} | {"bytes": b["flat"].numel() * 4}
+                           for b in self.buckets]
         self._begin()
+
+    def bucket_times_ms(self):
+        """Per bucket of the LAST finish() (timing=True): span from the launch of its reduce-scatter (inside the backward)
+        to its completion on the compute stream, and the span of its all-gather.  Device-event times for RCCL, host
+        times when the exchange is host-staged.  Synchronises the events it reads."""
+        out = []
+        for t in self._times:
+            def span(a, b):
+                if a is None or b is None:
+                    return None
+                if isinstance(a, float):
+                    return round((b - a) * 1e3, 4)
+                b.synchronize()
+                return round(a.elapsed_time(b), 4)
+            out.append({"bytes": t["bytes"], "reduce_scatter_span_ms": span(t["t_rs0"], t["t_rs1"]),
+                        "all_gather_span_ms": span(t["t_ag0"], t["t_ag1"])})
+        return out
 
     def zero_grad(self):
         for b in self.buckets:
@@ -193,7 +233,7 @@ class DataParallel(nn.Module):
     """
 
     def __init__(self, module: nn.Module, group=None, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0,
-                 sync_bn: bool = True):
+                 sync_bn: bool = True, timing: bool = False):
         super().__init__()
         self.module = module
         group = group if group is not None else dist.group.WORLD
@@ -215,7 +255,7 @@ class DataParallel(nn.Module):
         old = getattr(module, "_dp_buckets", None)
         if old is not None:               # re-wrapping the same module: the previous hooks would count arrivals twice
             old.close()
-        self.buckets = GradBuckets(module.parameters(), bucket_mb, first_bucket_mb, group)
+        self.buckets = GradBuckets(module.parameters(), bucket_mb, first_bucket_mb, group, timing=timing)
         object.__setattr__(module, "_dp_buckets", self.buckets)
 
     def forward(self, mixed_spec, lip_frames):

@@ -88,6 +88,68 @@ def max_over_ranks(dist, seconds, dev):
     return float(t.item())
 
 
+def gather_ranks(dist, obj):
+    """One python object per rank, on every rank (outside the timed region)."""
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def device_identity(dev):
+    """What tells two GPUs of a node apart: name, PCI domain:bus:device, uuid (whatever this torch build exposes)."""
+    p = torch.cuda.get_device_properties(dev)
+    pci = None
+    if hasattr(p, "pci_bus_id"):
+        pci = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}"
+    return {"index": dev.index, "name": p.name, "pci": pci, "uuid": str(getattr(p, "uuid", "")) or None,
+            "pid": os.getpid()}
+
+
+def duplicate_devices(idents):
+    """Pairs of ranks that report the same physical device (same uuid, or same PCI address when no uuid is exposed):
+    a rank that landed on a neighbour's GPU would otherwise be invisible in the one aggregated number."""
+    seen, dup = {}, []
+    for r, d in enumerate(idents):
+        key = d.get("uuid") or d.get("pci")
+        if key is None:
+            continue
+        if key in seen:
+            dup.append((seen[key], r, key))
+        else:
+            seen[key] = r
+    return dup
+
+
+def timed_rounds(dist, dev, rounds, run_round):
+    """R rounds of EXACTLY K steps, each bracketed by barrier + device synchronisation on both sides and reduced with MAX
+    over ranks; returns the per-round seconds (max over ranks) and this rank's own per-round seconds.  The median round
+    is the reported one: a single 8 ms region right after start-up is one sample of a device still settling its clocks
+    (the driver's --steps 20 --warmup 5 run of round 2 read 12 % below a 200-step run of the same build)."""
+    mine, worst = [], []
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_round()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        mine.append(dt)
+        worst.append(max_over_ranks(dist, dt, dev))
+    return worst, mine
+
+
+def median(xs):
+    s_ = sorted(xs)
+    n = len(s_)
+    return s_[n // 2] if n % 2 else 0.5 * (s_[n // 2 - 1] + s_[n // 2])
+
+
 def spawn_ranks(n, argv):
     """Launcher half of `python bench.py --gpus N` (N > 1, no torchrun around it): run
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
@@ -117,10 +179,19 @@ def selftest_launch(rank, world, a):
     dist.barrier()
     elapsed = max_over_ranks(dist, 0.010 * (rank + 1), torch.device("cpu"))     # pretend rank r took 10*(r+1) ms
     clips = list(shard_range(rank, world, 4))
+    per_rank = gather_ranks(dist, 10.0 * (rank + 1))
+    # pretend devices: distinct unless the test asks for two ranks on one GPU
+    same = os.environ.get("AVSEP_SELFTEST_SAME_DEVICE") == "1"
+    idents = gather_ranks(dist, {"index": 0 if same else rank, "name": "selftest", "pci": f"0000:{0 if same else rank:02x}:00",
+                                 "uuid": None, "pid": os.getpid()})
+    dup = duplicate_devices(idents)
     dist.barrier()
     dist.destroy_process_group()
+    if dup:
+        raise SystemExit(f"ranks share a device: {dup}")
     if rank == 0:
-        print(json.dumps({"selftest": "launch", "n_gpus": world, "elapsed_max": elapsed, "rank0_clips": clips}))
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "elapsed_max": elapsed, "rank0_clips": clips,
+                          "per_rank_ms": per_rank, "devices": idents, "world_size": world}))
 
 
 def host_cpu_info():
@@ -233,6 +304,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="forward mode: independent steps kept in flight at once, each on its own stream with its own "
                          "batch, output and workspace buffers (1 = strictly one step after the other)")
+    ap.add_argument("--rounds", type=int, default=9,
+                    help="timed rounds of exactly --steps steps each (barrier + synchronize on both sides of every round); "
+                         "the MEDIAN round is reported as value / ms_per_step, min and max beside it")
     ap.add_argument("--stream", action="store_true",
                     help="also time the PCIe-inclusive streamed mode (distinct pinned host batches, double-buffered "
                          "H2D/D2H on side streams); reported as `stream` next to the resident-batch value")
@@ -308,28 +382,29 @@ def main():
             with torch.cuda.stream(st["stream"]):
                 model.run_static(st["mixed"], st["lips"], st["masks"], st["sep"], graph=graph, slot=i % nsets)
 
+    # every in-flight slot is a native context of its own (own packed weights, workspace, graph): before anything is
+    # timed, each one must reproduce slot 0's outputs on slot 0's batch bit for bit
+    slots_equal = True
     with torch.no_grad():
         run_steps(max(a.warmup, R), R)             # W warm-up steps (at least one per buffer set: graph capture)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(a.steps, R)                      # EXACTLY K steps
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        if dist is not None:
-            dist.barrier()
-        elapsed = max_over_ranks(dist, t1 - t0, dev)
-        # the same K steps strictly one after the other on one stream (the latency view), for the record
-        single = None
+        for r in range(1, R):
+            chk_m, chk_s = torch.empty_like(masks), torch.empty_like(sep)
+            with torch.cuda.stream(sets[r]["stream"]):
+                model.run_static(mixed, lips, chk_m, chk_s, graph=False, slot=r)
+            torch.cuda.synchronize()
+            slots_equal = slots_equal and bool(torch.equal(chk_m, masks) and torch.equal(chk_s, sep))
+        if not slots_equal:
+            raise SystemExit("an in-flight slot does not reproduce slot 0's outputs: refusing to time it")
+        nrounds = max(1, a.rounds)
+        worst, mine = timed_rounds(dist, dev, nrounds, lambda: run_steps(a.steps, R))     # each round: EXACTLY K steps
+        elapsed = median(worst)
+        # the same K steps strictly one after the other on one stream (the latency view; the figure to compare rounds by)
+        single = single_rounds = None
         if R > 1:
             run_steps(max(2, a.warmup), 1)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_steps(a.steps, 1)
-            torch.cuda.synchronize()
-            single = max_over_ranks(dist, time.perf_counter() - t0, dev)
+            single_rounds, _ = timed_rounds(dist, dev, max(1, min(nrounds, 5)), lambda: run_steps(a.steps, 1))
+            single = median(single_rounds)
 
     with torch.cuda.stream(stream), torch.no_grad():
         # ---- per-kernel roofline, live: eager forwards with every launch bracketed by HIP events
@@ -392,7 +467,8 @@ def main():
         pass
 
     out = {
-        "metric": "separated clips/sec (2-spk, 1s@8kHz, d=256) forward, fp32",
+        "metric": "separated clips/sec (2-spk, 1s@8kHz, d=256) forward, fp32" +
+                  (f", throughput with {R} steps in flight" if R > 1 else ""),
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -403,15 +479,32 @@ def main():
                    "launch": ("hipGraph replay" if graph else "eager") +
                              (f", {R} independent steps in flight (one stream + batch / output / workspace set each)" if R > 1
                               else ", one step after the other"),
-                   "steps_in_flight": R, "parallelism": f"replica x{world} (clip shards)"},
+                   "steps_in_flight": R, "slots_bit_equal_on_one_batch": slots_equal,
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                   "parallelism": f"replica x{world} (clip shards)"},
+        "timing": {"rounds": nrounds, "steps_per_round": a.steps, "reported": "median round (max over ranks per round)",
+                   "ms_per_step_min": round(min(worst) / a.steps * 1e3, 4),
+                   "ms_per_step_max": round(max(worst) / a.steps * 1e3, 4),
+                   "ms_per_step_rounds": [round(w / a.steps * 1e3, 4) for w in worst]},
         "roofline": roofline,
         "kernels": [{"name": k["name"], "calls_per_step": k["calls"] / prof_iters, "avg_us": round(k["avg_us"], 2),
                      "tflops": round(k["tflops"], 2), "gbs": round(k["gbs"], 1)} for k in kernels],
     }
 
+    if dist is not None:
+        # what each rank ran on and how long IT took: a slow rank, or two ranks on one device, must not hide in the aggregate
+        idents = gather_ranks(dist, device_identity(dev))
+        out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                        "per_rank_ms": [round(x * 1e3, 4) for x in gather_ranks(dist, median(mine))],
+                        "devices": idents}
+        dup = duplicate_devices(idents)
+        if dup and not rehearsal:
+            raise SystemExit(f"ranks share a physical device (rank, rank, id): {dup}")
+        out["ranks"]["duplicate_devices"] = dup
     if single is not None:
         out["one_step_at_a_time"] = {"value": round(world * B * a.steps / single, 2), "unit": "clips/s",
                                      "ms_per_step": round(single / a.steps * 1e3, 4),
+                                     "ms_per_step_rounds": [round(w / a.steps * 1e3, 4) for w in single_rounds],
                                      "note": "same K steps on ONE stream, each waiting for the previous one (step latency)"}
     if rank == 0 and world == 1 and a.stream:
         out["stream"] = stream_leg(model, ds, B, dev, a.stream_steps, inflight=max(2, R))
@@ -448,7 +541,7 @@ def train_main(a, av, dev, dist, rank, world):
     _, N, H, W = lips.shape
     S = mk["num_speakers"]
     crit = SeparationLoss(0.5)
-    dp = parallel.DataParallel(model) if dist is not None else None
+    dp = parallel.DataParallel(model, timing=True) if dist is not None else None
     opt = torch.optim.Adam(model.parameters(), lr=3e-4, fused=True)
     losses, bwd_events, exposed = [], [], []
 
@@ -476,19 +569,16 @@ def train_main(a, av, dev, dist, rank, world):
     for _ in range(max(1, a.warmup)):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    bwd_events.clear()
-    exposed.clear()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
-    elapsed = max_over_ranks(dist, t1 - t0, dev)
+
+    def one_round():
+        bwd_events.clear()
+        exposed.clear()
+        for _ in range(a.steps):
+            step()
+
+    nrounds = max(1, min(a.rounds, 5))
+    worst, mine = timed_rounds(dist, dev, nrounds, one_round)       # each round: EXACTLY K steps, sync on both sides
+    elapsed = median(worst)
     gflop_clip = 3 * flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
     value = world * B * a.steps / elapsed
     tf = value / world * gflop_clip / 1e3
@@ -518,8 +608,21 @@ def train_main(a, av, dev, dist, rank, world):
                      "gradient_mb": round(4 * nparam / 1e6, 1),
                      "buckets": len(dp.buckets.buckets) if dp is not None else 0,
                      "form": "reduce-scatter (from backward hooks) + 1/G on the shard + all-gather" if dp is not None
-                     else "single rank: no exchange"},
+                     else "single rank: no exchange",
+                     # last step of the last round: launch-to-completion span of every bucket's reduce-scatter (it starts
+                     # inside the backward, so the span includes the backward it overlaps) and of its all-gather
+                     "per_bucket": dp.buckets.bucket_times_ms() if dp is not None else []},
+        "timing": {"rounds": nrounds, "steps_per_round": a.steps, "reported": "median round (max over ranks per round)",
+                   "ms_per_step_rounds": [round(w / a.steps * 1e3, 3) for w in worst]},
     }
+    if dist is not None:
+        idents = gather_ranks(dist, device_identity(dev))
+        out["ranks"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                        "per_rank_ms": [round(x * 1e3, 3) for x in gather_ranks(dist, median(mine))], "devices": idents}
+        dup = duplicate_devices(idents)
+        if dup and os.environ.get("AVSEP_BENCH_REHEARSAL") != "1":
+            raise SystemExit(f"ranks share a physical device (rank, rank, id): {dup}")
+        out["ranks"]["duplicate_devices"] = dup
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_train_baseline(model, mixed, lips, targets, mk, B, a.dropout, a.cpu_seconds)
     if dist is not None:

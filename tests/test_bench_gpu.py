@@ -42,13 +42,17 @@ def test_bench_single_gpu_contract_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["gpu_masks_max_abs_err_vs_cpu"] < 4e-6
     assert cb["threads"] == cb["cores"] and cb["host_cores"] >= 1 and cb["cpu_model"]
     assert rf["library_build_id"] and (rf["traffic"] is None or "traffic_note" not in rf)
+    tm = out["timing"]
+    assert tm["rounds"] >= 9 and len(tm["ms_per_step_rounds"]) == tm["rounds"] and tm["steps_per_round"] == 20
+    assert tm["ms_per_step_min"] <= out["ms_per_step"] <= tm["ms_per_step_max"]
+    assert out["config"]["slots_bit_equal_on_one_batch"] is True and "in flight" in out["metric"]
 
 
 @pytest.mark.parametrize("mode,launcher", [("forward", "self"), ("forward", "torchrun"), ("train", "self")])
 def test_bench_two_rank_rehearsal(mode, launcher):
     """`self`: plain `python bench.py --gpus 2` (the driver's observed form) -- bench.py spawns its own ranks;
     `torchrun`: launched under torch.distributed.run (the contract's documented form)."""
-    args = ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    args = ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--rounds", "3"]
     if launcher == "torchrun":
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
@@ -65,6 +69,16 @@ def test_bench_two_rank_rehearsal(mode, launcher):
     per = 2 if mode == "train" else 32
     assert out["config"]["global_batch"] == 2 * per
     assert abs(out["value"] - 2 * per / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]
+    # N > 1 observability: what every rank ran on and how long it took by itself
+    rk = out["ranks"]
+    assert rk["world_size"] == 2 and len(rk["per_rank_ms"]) == 2 and len(rk["devices"]) == 2
+    assert all(d["name"] and d["pid"] for d in rk["devices"]) and rk["devices"][0]["pid"] != rk["devices"][1]["pid"]
+    assert len(rk["duplicate_devices"]) == 1          # the rehearsal puts both ranks on the one GPU -- and says so
+    assert max(rk["per_rank_ms"]) <= out["ms_per_step"] * out["steps"] * 1.001
+    if mode == "train":
+        pb = out["exchange"]["per_bucket"]
+        assert len(pb) == out["exchange"]["buckets"] >= 1
+        assert all(b["reduce_scatter_span_ms"] is not None and b["all_gather_span_ms"] is not None for b in pb)
 
 
 def _rccl_worker(rank, world, port, out):

@@ -49,10 +49,11 @@ def test_two_rank_sharding_and_max_time(tmp_path):
     assert abs(world * batch * 1 / r["tmax"] - 3200.0) < 1e-6
 
 
-def _bench(args, env_extra=None):
+def _bench(args, env_extra=None, env_full=None):
+    """env_full: the child's whole environment (the way to REMOVE variables); env_extra: additions to this one's."""
     import json
     import subprocess
-    env = dict(os.environ)
+    env = dict(os.environ) if env_full is None else dict(env_full)
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=600)
@@ -64,10 +65,30 @@ def test_plain_bench_gpus2_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun around it (how the driver calls it): the parent spawns one worker
     per rank before any GPU call and relays rank 0's single JSON line; --selftest-launch stops short of the GPU work."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    rc, lines, err = _bench(["--gpus", "2", "--selftest-launch"], env)
+    rc, lines, err = _bench(["--gpus", "2", "--selftest-launch"], env_full=env)
     assert rc == 0, err[-2000:]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2
     assert abs(lines[0]["elapsed_max"] - 0.020) < 1e-12 and lines[0]["rank0_clips"] == [0, 1, 2, 3]
+    # per-rank reporting of the N > 1 line: every rank's own time and device identity, gathered on rank 0
+    assert lines[0]["per_rank_ms"] == [10.0, 20.0] and lines[0]["world_size"] == 2
+    assert [d["pci"] for d in lines[0]["devices"]] == ["0000:00:00", "0000:01:00"]
+    assert lines[0]["devices"][0]["pid"] != lines[0]["devices"][1]["pid"]
+
+
+def test_two_ranks_on_one_device_is_an_error():
+    rc, lines, err = _bench(["--gpus", "2", "--selftest-launch"], {"AVSEP_SELFTEST_SAME_DEVICE": "1"})
+    assert rc != 0 and not lines and "share a device" in err
+
+
+def test_duplicate_device_detection():
+    import bench
+    a = {"uuid": "GPU-1", "pci": "0000:05:00"}
+    b = {"uuid": "GPU-2", "pci": "0000:06:00"}
+    assert bench.duplicate_devices([a, b]) == []
+    assert bench.duplicate_devices([a, b, dict(a)]) == [(0, 2, "GPU-1")]
+    assert bench.duplicate_devices([{"uuid": None, "pci": "0000:05:00"}, {"uuid": None, "pci": "0000:05:00"}]) == [(0, 1, "0000:05:00")]
+    assert bench.duplicate_devices([{"uuid": None, "pci": None}, {"uuid": None, "pci": None}]) == []
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5
 
 
 def test_plain_bench_propagates_a_worker_failure():

@@ -205,6 +205,43 @@ def test_batched_weight_transposes_match_per_layer_ones_and_follow_storage_chang
             assert torch.equal(a[n], b[n]), n
 
 
+def test_weight_table_survives_a_model_leaving_the_device():
+    """A model that trained on the device and is then moved off it (or cast) stays alive: its Parameters keep their
+    identity while ``p.data`` now lives elsewhere.  The next backward of ANOTHER model on the device refreshes the whole
+    W^T table in one launch -- which must not contain those rows any more (host pointer / wrong dtype = GPU fault)."""
+    import av_separation as av
+    from av_separation import _train as tr
+    dev = torch.device("cuda:0")
+    cfg = dict(freq_bins=33, d_model=64, nhead=4, num_encoder_layers=1, num_fusion_layers=1, num_speakers=2, dropout=0.0)
+    mixed, lips = torch.rand(2, 33, 12, device=dev) + 0.1, torch.rand(2, 4, 8, 8, device=dev)
+
+    def step(m):
+        m.zero_grad(set_to_none=True)
+        sep, _ = m(mixed, lips)
+        sep.square().mean().backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    torch.manual_seed(1)
+    a = av.AVSeparationTransformer(**cfg).to(dev).train()
+    torch.manual_seed(2)
+    b = av.AVSeparationTransformer(**cfg).to(dev).train()
+    step(a)
+    ref = step(b)
+    table = tr._wt_table(dev)
+    n_both = len(table._descriptors())
+    a.cpu()                                          # same Parameter objects, storages now in host memory
+    got = step(b)
+    torch.cuda.synchronize()
+    assert all(torch.equal(ref[n], got[n]) for n in ref)
+    live = table._descriptors()
+    assert 0 < len(live) < n_both and all(w.device == dev and w.dtype == torch.float32 for w, _ in live)
+    a.to(dev).double()                               # back on the device, but float64 now
+    got = step(b)
+    torch.cuda.synchronize()
+    assert all(torch.equal(ref[n], got[n]) for n in ref)
+    assert all(w.dtype == torch.float32 for w, _ in table._descriptors())
+
+
 def test_dropout_training_is_self_consistent():
     """dropout > 0 (the reference's default 0.1): masks cannot match torch's RNG stream, so check what must hold
     anyway: same seed -> same output, different seed -> different; keep rate and 1/(1-p) scaling of the mask;
