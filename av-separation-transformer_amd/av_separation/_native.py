@@ -9,7 +9,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AVSEP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libavsep_hip.so")
+_LIBDIR = os.path.join(os.path.dirname(_HERE), "lib")
+# The developer build of the same sources (make dev): tile overrides, A/B switches, diagnostics and the kernel instances that
+# were measured slower.  AVSEP_LIB=dev makes it the library of the whole process (tools/ sweeps); the bit-identity tests
+# open it NEXT to the product library with load_dev().
+DEV_LIB_PATH = os.path.join(_LIBDIR, "libavsep_hip_dev.so")
+_want = os.environ.get("AVSEP_LIB")
+LIB_PATH = DEV_LIB_PATH if _want == "dev" else (_want or os.path.join(_LIBDIR, "libavsep_hip.so"))
 
 # every symbol include/avsep.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
@@ -17,7 +23,7 @@ ABI_SYMBOLS = (
     "avsep_finalize_weights", "avsep_workspace_bytes", "avsep_forward", "avsep_forward_graph",
     "avsep_audio_encoder", "avsep_visual_encoder", "avsep_fusion", "avsep_decoder",
     "avsep_set_debug_taps", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_layernorm", "avsep_op_ln_linear",
-    "avsep_op_attention", "avsep_op_interp_linear", "avsep_stft_basis_floats", "avsep_stft_basis", "avsep_op_stft_mag",
+    "avsep_op_attention", "avsep_op_linear_pair", "avsep_op_attention_pair", "avsep_op_interp_linear", "avsep_stft_basis_floats", "avsep_stft_basis", "avsep_op_stft_mag",
     # training ops
     "avsep_op_linear_ex", "avsep_op_attention_train", "avsep_op_attention_bwd", "avsep_op_transpose",
     "avsep_op_transpose_pad", "avsep_op_im2col1d", "avsep_op_col2im1d", "avsep_op_im2col2d", "avsep_op_col2im2d",
@@ -36,19 +42,32 @@ class AvsepConfig(C.Structure):
 
 
 _lib = None
+_dev = None
 
 
 def load():
     """Load (once) and type the shared library; raise loudly when it is not built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+def load_dev():
+    """The developer build as a second handle (own static state, own contexts): for op-level tests and tools only."""
+    global _dev
+    if _dev is None:
+        _dev = _open(DEV_LIB_PATH)
+    return _dev
+
+
+def _open(path):
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build the HIP extension first "
+            f"{path} is missing: build the HIP extension first "
             "(`python -c 'import __graft_entry__ as g; g.build()'` at the repo root, or "
             "`make -C av-separation-transformer_amd/csrc`).  There is no fallback path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     p, i, i64, sz, fp = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_void_p
     lib.avsep_abi_version.restype = i
     lib.avsep_last_error.restype = C.c_char_p
@@ -78,6 +97,8 @@ def load():
     lib.avsep_op_ln_linear.argtypes = [fp, fp, fp, fp, fp, fp, fp, i, i, i, i, C.c_float, i, p]
     lib.avsep_op_attention.argtypes = [fp, i, fp, i, fp, i, fp, i, i, i, i, i, i, p]
     lib.avsep_op_interp_linear.argtypes = [fp, fp, i, i, i, i, p]
+    lib.avsep_op_linear_pair.argtypes = [fp, fp, fp, fp, fp, fp, fp, i, fp, fp, fp, fp, fp, fp, fp, i, i, i, i, C.c_float, p]
+    lib.avsep_op_attention_pair.argtypes = [fp, fp, fp, fp, i, i, i, i, fp, fp, fp, fp, i, i, i, i, i, i, p]
     lib.avsep_stft_basis_floats.argtypes = [i]
     lib.avsep_stft_basis_floats.restype = i64
     lib.avsep_stft_basis.argtypes = [fp, i, p]
@@ -129,8 +150,7 @@ def load():
         if fn.restype is C.c_int and name not in ("avsep_abi_version", "avsep_build_id"):
             fn.restype = i
     if lib.avsep_abi_version() != 1:
-        raise RuntimeError("libavsep_hip.so ABI version mismatch")
-    _lib = lib
+        raise RuntimeError(f"{path}: ABI version mismatch")
     return lib
 
 

@@ -18,6 +18,7 @@
 // nothing for an LDS stage to win here.
 #include "kernels.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -442,20 +443,30 @@ __global__ __launch_bounds__(256, QT == 4 ? 2 : DROP ? 1 : (QT == 2 ? 3 : 4)) vo
 // audio frames / N = 50 lip frames): all NKT = 4 key tiles of K and V are loaded before the first MFMA, so the
 // wave pays ONE memory round trip instead of one per tile (the generic kernel's 1-tile prefetch leaves a ~4 us
 // latency chain at this size), and the softmax is the plain two-pass one over registers.
+// Two problems may ride in one launch (pa: workgroups [0, blocks_a), pb: the rest) -- the self-attention of the audio and
+// of the visual encoder layer i, which are independent and each fill only half of the chip's CUs (B * nhead = 128
+// workgroups at the 32-clip batch).  A single problem is launched with blocks_a = gridDim.x.
 template <int NB, int NKT>
-__global__ __launch_bounds__(256) void attention_short_kernel(const float* __restrict__ q, int ldq,
-                                                              const float* __restrict__ k, int ldk,
-                                                              const float* __restrict__ v, int ldv,
-                                                              float* __restrict__ o, int ldo, int nhead, int Lq,
-                                                              int Lk, int nqt) {
+__global__ __launch_bounds__(256) void attention_short_kernel(const AttnProblem pa, const AttnProblem pb, int blocks_a,
+                                                              int nhead) {
   constexpr int DH = 16 * NB;
+  const bool second = (int)blockIdx.x >= blocks_a;                      // block-uniform
+  // field-wise scalar selects (a reference to one of two kernel arguments would send both through scratch memory)
+  const float* __restrict__ q = second ? pb.q : pa.q;
+  const float* __restrict__ k = second ? pb.k : pa.k;
+  const float* __restrict__ v = second ? pb.v : pa.v;
+  float* __restrict__ o = second ? pb.o : pa.o;
+  const int ldq = second ? pb.ldq : pa.ldq, ldk = second ? pb.ldk : pa.ldk, ldv = second ? pb.ldv : pa.ldv;
+  const int ldo = second ? pb.ldo : pa.ldo, Lq = second ? pb.Lq : pa.Lq, Lk = second ? pb.Lk : pa.Lk;
+  const int nqt = (Lq + 15) >> 4;
+  const int blk = second ? (int)blockIdx.x - blocks_a : (int)blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int c = lane & 15;
   const int g = lane >> 4;
   const int wg_per_head = (nqt + 3) >> 2;
-  const int bh = blockIdx.x / wg_per_head;
-  const int qt = (blockIdx.x - bh * wg_per_head) * 4 + wave;
+  const int bh = blk / wg_per_head;
+  const int qt = (blk - bh * wg_per_head) * 4 + wave;
   if (qt >= nqt) return;
   const int b = bh / nhead, h = bh - b * nhead;
   const float* qb = q + (size_t)b * Lq * ldq + h * DH;
@@ -536,6 +547,43 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const float* __res
 
 }  // namespace
 
+// the one-round-trip kernel: dh = 64 and 49..64 keys
+static bool short_ok(int dh, int Lk) {
+  static const bool no_short = dev_env("AVSEP_NO_SHORT_ATTN") != nullptr;   // developer A/B switch
+  return dh == 64 && Lk > 48 && Lk <= 64 && !no_short;
+}
+
+bool attention_pair_merges(int dh, int Lk_a, int Lk_b) { return short_ok(dh, Lk_a) && short_ok(dh, Lk_b); }
+
+// mirrors the dispatch of launch_attention_ex for inference calls (no LSE, no dropout, qscale 1)
+const char* attention_instance_name(int dh, int Lq, int Lk, int B, int nhead) {
+  static thread_local char buf[64];
+  if (short_ok(dh, Lk)) return "attention_short_kernel<4, 4>";
+  const int nb = (dh + 15) / 16, nqt = (Lq + 15) / 16;
+  const bool reg = dh == 16 * nb;
+  const long wgs2 = (long)B * nhead * (((nqt + 1) / 2 + 3) / 4);
+  const char* qt_s = dev_env("AVSEP_ATTN_QT");
+  const int qt_env = qt_s ? atoi(qt_s) : 0;
+  const bool two = qt_env ? qt_env == 2 : (reg && nb == 4 && wgs2 >= 512);
+  const bool lds = reg && nb == 4 && Lk >= 128 && !dev_env("AVSEP_ATTN_NO_LDS") && !dev_env("AVSEP_ATTN_NO_LDS_NOW");
+  if (lds) snprintf(buf, sizeof buf, "attention_lds_kernel<%d, 2, false>", qt_env == 4 ? 4 : two ? 2 : 1);
+  else snprintf(buf, sizeof buf, "attention_kernel<%d, %s, %d>", nb, reg ? "true" : "false", (two && reg && nb == 4) ? 2 : 1);
+  return buf;
+}
+
+hipError_t launch_attention_pair(const AttnProblem& a, const AttnProblem& b, int nhead, int dh, hipStream_t s) {
+  if (a.B <= 0 || b.B <= 0 || nhead <= 0 || a.Lq <= 0 || a.Lk <= 0 || b.Lq <= 0 || b.Lk <= 0) return hipErrorInvalidValue;
+  if ((a.ldq | a.ldk | a.ldv | a.ldo | b.ldq | b.ldk | b.ldv | b.ldo) & 3) return hipErrorInvalidValue;
+  if (short_ok(dh, a.Lk) && short_ok(dh, b.Lk)) {
+    const int ba = a.B * nhead * ((((a.Lq + 15) >> 4) + 3) >> 2), bb = b.B * nhead * ((((b.Lq + 15) >> 4) + 3) >> 2);
+    hipLaunchKernelGGL((attention_short_kernel<4, 4>), dim3((unsigned)(ba + bb)), dim3(256), 0, s, a, b, ba, nhead);
+    return hipGetLastError();
+  }
+  hipError_t e = launch_attention(a.q, a.ldq, a.k, a.ldk, a.v, a.ldv, a.o, a.ldo, a.B, nhead, dh, a.Lq, a.Lk, s);
+  if (e != hipSuccess) return e;
+  return launch_attention(b.q, b.ldq, b.k, b.ldk, b.v, b.ldv, b.o, b.ldo, b.B, nhead, dh, b.Lq, b.Lk, s);
+}
+
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                             int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s) {
   return launch_attention_ex(q, ldq, k, ldk, v, ldv, o, ldo, B, nhead, dh, Lq, Lk, 1.0f, nullptr, 0.0f, 0ull, s);
@@ -552,16 +600,15 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
   const int wg_per_head = (nqt + 3) / 4;
   const dim3 grid((unsigned)(B * nhead * wg_per_head)), block(256);
   if (dh <= 0 || dh > 128 || (dh & 3)) return hipErrorInvalidValue;
-  static const bool no_short = getenv("AVSEP_NO_SHORT_ATTN") != nullptr;   // developer A/B switch
-  if (dh == 64 && Lk > 48 && Lk <= 64 && !no_short && !lse && qscale == 1.0f && drop_p == 0.0f) {
-    hipLaunchKernelGGL((attention_short_kernel<4, 4>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq,
-                       Lk, nqt);
+  if (short_ok(dh, Lk) && !lse && qscale == 1.0f && drop_p == 0.0f) {
+    const AttnProblem pa{q, k, v, o, ldq, ldk, ldv, ldo, B, Lq, Lk};
+    hipLaunchKernelGGL((attention_short_kernel<4, 4>), grid, block, 0, s, pa, pa, (int)grid.x, nhead);
     return hipGetLastError();
   }
   const int nb = (dh + 15) / 16;
   const bool reg = (dh == 16 * nb);
   // two query tiles per wave once the sequence is long enough to keep >= 2 workgroups per CU that way
-  const char* qt_s = getenv("AVSEP_ATTN_QT");                      // developer A/B switch, read per call (bit-identity test)
+  const char* qt_s = dev_env("AVSEP_ATTN_QT");                     // developer A/B switch, read per call (bit-identity test)
   const int qt_env = qt_s ? atoi(qt_s) : 0;
   const long wgs2 = (long)B * nhead * (((nqt + 1) / 2 + 3) / 4);
   const bool two = qt_env ? qt_env == 2 : (reg && nb == 4 && wgs2 >= 512);
@@ -572,14 +619,15 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
     else hipLaunchKernelGGL((attention_kernel<NB_, false, 1>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,   \
                             nhead, Lq, Lk, nqt, dh, qscale, lse, drop_p, drop_seed);                                \
   }
-  static const bool no_lds = getenv("AVSEP_ATTN_NO_LDS") != nullptr;       // developer A/B switch (whole process)
-  const bool no_lds_now = getenv("AVSEP_ATTN_NO_LDS_NOW") != nullptr;      // ... per call (the bit-identity test)
+  static const bool no_lds = dev_env("AVSEP_ATTN_NO_LDS") != nullptr;      // developer A/B switch (whole process)
+  const bool no_lds_now = dev_env("AVSEP_ATTN_NO_LDS_NOW") != nullptr;     // ... per call (the bit-identity test)
   if (reg && nb == 4 && Lk >= 128 && !no_lds && !no_lds_now) {
     // long sequences: K / V through LDS, shared by the workgroup's four waves (bit-identical to the kernels below)
     const bool drop = drop_p > 0.0f;
     // Four query tiles per wave (inference): one workgroup covers 256 queries, so L = 251 is ONE workgroup per (clip, head)
     // and the 512 workgroups of configs 3 / 5 are exactly one round at two workgroups per CU -- with two tiles per wave
     // they are 1024 workgroups on 768 slots, a second round one third full.  (profiles/r02_attention_bench.txt)
+#ifdef AVSEP_DEV   // developer instance: measured without gain (profiles/r02_attention_bench.txt)
     const long wgs4 = (long)B * nhead * (((nqt + 3) / 4 + 3) / 4);
     const bool four = qt_env ? qt_env == 4 : false;
     if (four && !drop) {
@@ -587,6 +635,7 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
                          nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
       return hipGetLastError();
     }
+#endif
     if (two && drop) {
       hipLaunchKernelGGL((attention_lds_kernel<2, 2, true>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,
                          nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);

@@ -107,7 +107,8 @@ struct avsep_ctx {
   hipStream_t side = nullptr;                      // eager forwards: the visual branch's stream
   hipEvent_t ev_fork = nullptr, ev_vdone = nullptr, ev_adone = nullptr, ev_tdone = nullptr;
   bool no_fused_conv = false;                      // developer A/B switch (AVSEP_NO_FUSED_CONV)
-  bool tail_split = true;                          // fusion+decoder: half the batch per stream after the join
+  bool paired = true;                              // encoder layers of both branches in shared launches (forward_paired)
+  bool tail_split = true;                          // two-stream schedule: fusion+decoder, half the batch per stream after the join
   std::vector<GraphEntry> graphs;
   // live per-kernel profiler (HIP events around every launch, on the launch's own stream)
   struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
@@ -347,12 +348,13 @@ int profiled(avsep_ctx* c, const char* name, double flops, double bytes, hipStre
 // kalg: algorithmic K (un-padded) for the flop count
 int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
   const double k = kalg > 0 ? kalg : p.K;
-  const double flops = 2.0 * p.M * p.N * k;
-  double a_bytes = (double)p.M * k * 4;
+  const double rows = (double)p.M + (p.alt.M > 0 ? p.alt.M : 0);          // both problems of a pair launch
+  const double flops = 2.0 * rows * p.N * k;
+  double a_bytes = rows * k * 4;
   if (p.amode == AMODE_TAPS3) a_bytes /= 3;                      // each input row feeds 3 taps
   if (p.amode == AMODE_CONV2D) a_bytes = a_bytes / 9 * 4;        // stride-2 3x3: each input pixel read once
-  double bytes = a_bytes + (double)p.N * k * 4 + (double)p.M * p.N * 4 * (p.C2 ? 2 : 1);
-  if (p.R) bytes += (double)(p.rperiod > 0 ? p.rperiod : p.M) * p.N * 4;
+  double bytes = a_bytes + (double)p.N * k * 4 * (p.alt.M > 0 ? 2 : 1) + rows * p.N * 4 * (p.C2 ? 2 : 1);
+  if (p.R) bytes += (p.rperiod > 0 ? (double)p.rperiod : rows) * p.N * 4;
   if (p.C2) bytes += (double)p.M * p.F * 4;
   return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm(p, s); });
 }
@@ -364,7 +366,7 @@ int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk
                   int ldo, int B, int Lq, int Lk, hipStream_t s) {
   const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh;
   const double bytes = 4.0 * B * c->d * (2.0 * Lq + 2.0 * Lk);
-  return profiled(c, "attention_kernel", flops, bytes, s,
+  return profiled(c, attention_instance_name(c->dh, Lq, Lk, B, c->h), flops, bytes, s,
                   [&] { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, s); });
 }
 
@@ -381,7 +383,7 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
   p.amode = AMODE_PLAIN;
   p.act = act;
   const long big_tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  static const bool no_fuse = getenv("AVSEP_NO_LN_FUSE") != nullptr;   // developer A/B switch
+  static const bool no_fuse = dev_env("AVSEP_NO_LN_FUSE") != nullptr;   // developer A/B switch
   if (!no_fuse && gemm_ln_supported(d) && big_tiles < 1024) {
     p.ln_gamma = g; p.ln_beta = be; p.ln_eps = 1e-5f;
     return run_gemm(c, p, s);
@@ -393,7 +395,7 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
   // LayerNorm already runs at 5.5 TB/s (12 us at M = 16064, d = 512), and the normalisation arithmetic in front of
   // the tile's LDS writes lengthens every K step of the GEMM by more than the 6 us per LayerNorm it saves.  The form
   // stays available (avsep_op_ln_linear form 2, bit-identical) behind this developer switch.
-  static const bool staged = getenv("AVSEP_LN_STAGED") != nullptr;
+  static const bool staged = dev_env("AVSEP_LN_STAGED") != nullptr;
   if (staged && gemm_ln_staged_supported(d)) {
     RCK(profiled(c, "layernorm_kernel", 6.0 * M * d, 1.0 * M * d * 4 + 8.0 * M, s,
                  [&] { return launch_layernorm_stats(x, ln_buf, M, d, 1e-5f, s); }));
@@ -406,6 +408,46 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
 }
 
 // ------------------------------------------------------------------------------------------ building blocks
+GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
+                         int M, int N, int act);
+
+// The second problem of a pair launch (kernels.h GemmParams::alt): p1 differs from p0 in operands and row count only.
+GemmParams pair_params(const GemmParams& p0, const GemmParams& p1) {
+  GemmParams p = p0;
+  p.alt.A = p1.A; p.alt.W = p1.W; p.alt.bias = p1.bias; p.alt.R = p1.R; p.alt.rperiod = p1.rperiod;
+  p.alt.ln_gamma = p1.ln_gamma; p.alt.ln_beta = p1.ln_beta; p.alt.C = p1.C; p.alt.M = p1.M;
+  return p;
+}
+int run_gemm_pair(avsep_ctx* c, const GemmParams& p0, const GemmParams& p1, hipStream_t s) {
+  const GemmParams p = pair_params(p0, p1);       // for the instance name and the flop / byte accounting
+  const double rows = (double)p0.M + p1.M;
+  const double flops = 2.0 * rows * p.N * p.K;
+  double bytes = rows * p.K * 4 + 2.0 * p.N * p.K * 4 + rows * p.N * 4;
+  if (p.R) bytes += rows * p.N * 4;
+  return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm_pair(p0, p1, s); });
+}
+
+// y = act(LayerNorm(x) W^T + b) for the audio and the visual instance of the same layer in one launch (two LayerNorm
+// launches in front of it where the LayerNorm is not fused, d_model > 256 or a large batch)
+struct LnLin { const float *x, *g, *be; float* ln_buf; const float *W, *bias; float* y; int M; };
+int run_ln_linear_pair(avsep_ctx* c, const LnLin& a, const LnLin& v, int N, int act, hipStream_t s) {
+  const int d = c->d;
+  GemmParams pa = linear_params(a.x, d, a.W, d, a.bias, a.y, N, a.M, N, act);
+  GemmParams pv = linear_params(v.x, d, v.W, d, v.bias, v.y, N, v.M, N, act);
+  const long big_tiles = (long)((a.M + 63) / 64 + (v.M + 63) / 64) * ((N + 63) / 64);
+  static const bool no_fuse = dev_env("AVSEP_NO_LN_FUSE") != nullptr;   // developer A/B switch
+  if (!no_fuse && gemm_ln_supported(d) && big_tiles < 1024) {
+    pa.ln_gamma = a.g; pa.ln_beta = a.be; pa.ln_eps = 1e-5f;
+    pv.ln_gamma = v.g; pv.ln_beta = v.be; pv.ln_eps = 1e-5f;
+    return run_gemm_pair(c, pa, pv, s);
+  }
+  RCK(run_layernorm(c, a.x, a.g, a.be, a.ln_buf, a.M, d, s));
+  RCK(run_layernorm(c, v.x, v.g, v.be, v.ln_buf, v.M, d, s));
+  pa.A = a.ln_buf;
+  pv.A = v.ln_buf;
+  return run_gemm_pair(c, pa, pv, s);
+}
+
 GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
                          int M, int N, int act) {
   GemmParams p{};
@@ -433,6 +475,41 @@ int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* 
   return AVSEP_OK;
 }
 
+// Layer i of the audio encoder (rows B*La) and of the visual encoder (rows B*Lv) side by side: the two are independent
+// and have the same weight shapes (model.py:48-52 / 97-101), so each of the five kernels of a layer is launched ONCE for
+// both -- twice the workgroups per launch and half the launches, instead of two streams whose kernels have to find room
+// beside each other (a 32-clip batch is ~760 + ~600 workgroups per QKV launch on a chip with 768 resident slots).
+int encoder_layer_pair(avsep_ctx* c, const EncLayerW& A, const EncLayerW& V, const Workspace& w, int B, int La, int Lv,
+                       hipStream_t s) {
+  const int d = c->d, Ma = B * La, Mv = B * Lv;
+  RCK(run_ln_linear_pair(c, LnLin{w.a_x, A.g1, A.be1, w.ln, A.wqkv, A.bqkv, w.qkv, Ma},
+                         LnLin{w.v_x, V.g1, V.be1, w.v_ln, V.wqkv, V.bqkv, w.v_qkv, Mv}, 3 * d, ACT_NONE, s));
+  if (attention_pair_merges(c->dh, La, Lv)) {
+    const AttnProblem pa{w.qkv, w.qkv + d, w.qkv + 2 * d, w.att, 3 * d, 3 * d, 3 * d, d, B, La, La};
+    const AttnProblem pv{w.v_qkv, w.v_qkv + d, w.v_qkv + 2 * d, w.v_att, 3 * d, 3 * d, 3 * d, d, B, Lv, Lv};
+    const double flops = 4.0 * B * c->h * c->dh * ((double)La * La + (double)Lv * Lv);
+    const double bytes = 4.0 * B * c->d * 4.0 * (La + Lv);
+    RCK(profiled(c, attention_instance_name(c->dh, La, La, B, c->h), flops, bytes, s,
+                 [&] { return launch_attention_pair(pa, pv, c->h, c->dh, s); }));
+  } else {   // different kernel instances (e.g. T = 251 audio frames, N = 50 lip frames): one launch each
+    RCK(run_attention(c, w.qkv, 3 * d, w.qkv + d, 3 * d, w.qkv + 2 * d, 3 * d, w.att, d, B, La, La, s));
+    RCK(run_attention(c, w.v_qkv, 3 * d, w.v_qkv + d, 3 * d, w.v_qkv + 2 * d, 3 * d, w.v_att, d, B, Lv, Lv, s));
+  }
+  GemmParams oa = linear_params(w.att, d, A.wo, d, A.bo, w.a_x, d, Ma, d, ACT_NONE);
+  oa.R = w.a_x; oa.ldr = d; oa.rperiod = 0;
+  GemmParams ov = linear_params(w.v_att, d, V.wo, d, V.bo, w.v_x, d, Mv, d, ACT_NONE);
+  ov.R = w.v_x; ov.ldr = d; ov.rperiod = 0;
+  RCK(run_gemm_pair(c, oa, ov, s));
+  RCK(run_ln_linear_pair(c, LnLin{w.a_x, A.g2, A.be2, w.ln, A.w1, A.b1, w.ffn, Ma},
+                         LnLin{w.v_x, V.g2, V.be2, w.v_ln, V.w1, V.b1, w.v_ffn, Mv}, 4 * d, ACT_RELU, s));
+  GemmParams fa = linear_params(w.ffn, 4 * d, A.w2, 4 * d, A.b2, w.a_x, d, Ma, d, ACT_NONE);
+  fa.R = w.a_x; fa.ldr = d; fa.rperiod = 0;
+  GemmParams fv = linear_params(w.v_ffn, 4 * d, V.w2, 4 * d, V.b2, w.v_x, d, Mv, d, ACT_NONE);
+  fv.R = w.v_x; fv.ldr = d; fv.rperiod = 0;
+  RCK(run_gemm_pair(c, fa, fv, s));
+  return AVSEP_OK;
+}
+
 int check_common(const avsep_ctx* c, int B, int T) {
   if (!c) return fail(AVSEP_EINVAL, "null context");
   if (!c->finalized) return fail(AVSEP_ESTATE, "avsep_finalize_weights() has not been called");
@@ -440,8 +517,8 @@ int check_common(const avsep_ctx* c, int B, int T) {
   return AVSEP_OK;
 }
 
-// AudioEncoder.forward (model.py:54-60); result left in w.a_x.  Also fills w.xt (mixed^T, padded).
-int audio_branch(avsep_ctx* c, const Workspace& w, const float* mixed, int B, int T, hipStream_t s) {
+// AudioEncoder.input_proj + pos_enc (model.py:56-58): (B,F,T) -> w.a_x (B*T, d).  Also fills w.xt (mixed^T, padded).
+int audio_front(avsep_ctx* c, const Workspace& w, const float* mixed, int B, int T, hipStream_t s) {
   if (!c->ok_audio) return fail(AVSEP_ENOWEIGHT, "audio_encoder weights are incomplete");
   if (T > c->pe_len_a)
     return fail(AVSEP_EINVAL, "sequence length exceeds PositionalEncoding max_len (model.py:286,300)");
@@ -459,6 +536,13 @@ int audio_branch(avsep_ctx* c, const Workspace& w, const float* mixed, int B, in
   p2.R = c->a_pe; p2.ldr = d; p2.rperiod = T;   // x + pe[:, :T]  (model.py:300), fused after the ReLU
   RCK(run_gemm(c, p2, s));
   RCK(record_tap(c, w, "a_pe", w.a_x, (size_t)M * d, s));
+  return AVSEP_OK;
+}
+
+// AudioEncoder.forward (model.py:54-60); result left in w.a_x.
+int audio_branch(avsep_ctx* c, const Workspace& w, const float* mixed, int B, int T, hipStream_t s) {
+  RCK(audio_front(c, w, mixed, B, T, s));
+  const int d = c->d, M = B * T;
   for (int i = 0; i < c->Le; ++i) {
     RCK(encoder_layer(c, c->a_layers[i], w.a_x, w.ln, w.qkv, w.att, w.ffn, B, T, s));
     RCK(record_tap(c, w, ("a_enc" + std::to_string(i)).c_str(), w.a_x, (size_t)M * d, s));
@@ -466,9 +550,8 @@ int audio_branch(avsep_ctx* c, const Workspace& w, const float* mixed, int B, in
   return AVSEP_OK;
 }
 
-// VisualEncoder.forward (model.py:103-117); result (B,T,d) left in w.v_up.
-int visual_branch(avsep_ctx* c, const Workspace& w, const float* lips, int B, int N, int H, int W, int T,
-                  hipStream_t s) {
+// VisualEncoder.conv + frame_proj + pos_enc (model.py:106-110): (B,N,H,W) -> w.v_x (B*N, d).
+int visual_front(avsep_ctx* c, const Workspace& w, const float* lips, int B, int N, int H, int W, hipStream_t s) {
   if (!c->ok_visual) return fail(AVSEP_ENOWEIGHT, "visual_encoder weights are incomplete");
   if (N <= 0 || H <= 0 || W <= 0) return fail(AVSEP_EINVAL, "N, H, W must be positive");
   if (N > c->pe_len_v) return fail(AVSEP_EINVAL, "frame count exceeds PositionalEncoding max_len");
@@ -511,14 +594,27 @@ int visual_branch(avsep_ctx* c, const Workspace& w, const float* lips, int B, in
   GemmParams pf = linear_params(w.pool, 128, c->fp_w, 128, c->fp_b, w.v_x, d, Mv, d, ACT_NONE);
   pf.R = c->v_pe; pf.ldr = d; pf.rperiod = N;   // PE indexed by frame position
   RCK(run_gemm(c, pf, s));
+  return AVSEP_OK;
+}
+
+// F.interpolate(mode="linear") of the frame sequence to the audio length (model.py:114-116): w.v_x -> w.v_up
+int visual_upsample(avsep_ctx* c, const Workspace& w, int B, int N, int T, hipStream_t s) {
+  const int d = c->d;
+  RCK(profiled(c, "interp_linear_kernel", 3.0 * B * T * d, 4.0 * B * d * (N + T), s,
+               [&] { return launch_interp_linear(w.v_x, w.v_up, B, N, T, d, s); }));
+  return record_tap(c, w, "v_interp", w.v_up, (size_t)B * T * d, s);
+}
+
+// VisualEncoder.forward (model.py:103-117); result (B,T,d) left in w.v_up.
+int visual_branch(avsep_ctx* c, const Workspace& w, const float* lips, int B, int N, int H, int W, int T,
+                  hipStream_t s) {
+  RCK(visual_front(c, w, lips, B, N, H, W, s));
+  const int d = c->d, Mv = B * N;
   for (int i = 0; i < c->Le; ++i) {
     RCK(encoder_layer(c, c->v_layers[i], w.v_x, w.v_ln, w.v_qkv, w.v_att, w.v_ffn, B, N, s));
     RCK(record_tap(c, w, ("v_enc" + std::to_string(i)).c_str(), w.v_x, (size_t)Mv * d, s));
   }
-  RCK(profiled(c, "interp_linear_kernel", 3.0 * B * T * d, 4.0 * B * d * (N + T), s,
-               [&] { return launch_interp_linear(w.v_x, w.v_up, B, N, T, d, s); }));
-  RCK(record_tap(c, w, "v_interp", w.v_up, (size_t)B * T * d, s));
-  return AVSEP_OK;
+  return visual_upsample(c, w, B, N, T, s);
 }
 
 // K/V projections of the (layer-invariant) visual stream for ALL fusion layers in one GEMM.
@@ -603,8 +699,47 @@ inline void stamp(avsep_ctx* c, int idx, hipStream_t s) {
   if (c->stamps) (void)launch_stamp(c->stamps, idx, s);
 }
 
+// Paired schedule (the default): only the two front-ends run side by side -- the LDS-resident conv stack + frame
+// projection on `sv`, the Conv1d pair on `sa` -- then ONE chain on `sa`: every encoder layer as five launches that serve
+// the audio and the visual sequence at once (encoder_layer_pair), the resize, the K/V projection, the fusion layers and the
+// decoder on the whole batch.  A replayed step is then one queue of ~30 kernels with a short second queue at its head,
+// instead of two queues of 28 whose kernels compete for the CUs' LDS and wave slots: no dependence on how the runtime maps
+// four in-flight branches (two steps x two streams) onto its hardware queues.
+int forward_paired(avsep_ctx* c, const Workspace& w, const float* mixed, const float* lips, float* masks, float* sep,
+                   int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv) {
+  stamp(c, 1, sv);
+  int rv = visual_front(c, w, lips, B, N, H, W, sv);
+  stamp(c, 2, sv);
+  hipError_t ej = hipEventRecord(c->ev_vdone, sv);          // always join, even on error: never leave a capture forked
+  stamp(c, 0, sa);
+  int ra = audio_front(c, w, mixed, B, T, sa);
+  stamp(c, 4, sa);
+  hipError_t ew = hipStreamWaitEvent(sa, c->ev_vdone, 0);
+  if (rv != AVSEP_OK) return rv;
+  if (ra != AVSEP_OK) return ra;
+  HCK(ej);
+  HCK(ew);
+  if (N > c->pe_len_v) return fail(AVSEP_EINVAL, "frame count exceeds PositionalEncoding max_len");
+  const int d = c->d;
+  for (int i = 0; i < c->Le; ++i) {
+    RCK(encoder_layer_pair(c, c->a_layers[i], c->v_layers[i], w, B, T, N, sa));
+    RCK(record_tap(c, w, ("a_enc" + std::to_string(i)).c_str(), w.a_x, (size_t)B * T * d, sa));
+    RCK(record_tap(c, w, ("v_enc" + std::to_string(i)).c_str(), w.v_x, (size_t)B * N * d, sa));
+  }
+  stamp(c, 5, sa);
+  RCK(visual_upsample(c, w, B, N, T, sa));
+  RCK(fusion_kv(c, w, w.v_up, B, T, sa));
+  stamp(c, 3, sa);
+  RCK(fusion_layers(c, w, w.a_x, B, T, sa, /*final_norm=*/c->keep_taps));
+  stamp(c, 7, sa);
+  RCK(decoder_stage(c, w, w.a_x, masks, sep, B, T, sa, /*fuse_norm=*/true));
+  stamp(c, 9, sa);
+  return AVSEP_OK;
+}
+
 int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const float* lips, float* masks, float* sep,
                  int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv) {
+  if (c->paired) return forward_paired(c, w, mixed, lips, masks, sep, B, T, N, H, W, sa, sv);
   stamp(c, 1, sv);
   int rv = visual_branch(c, w, lips, B, N, H, W, T, sv);
   stamp(c, 2, sv);
@@ -677,7 +812,7 @@ int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* mas
   // capture in progress is never left with an un-joined stream
   HCK(hipEventRecord(c->ev_fork, s));
   hipStream_t sv = c->side;
-  static const bool serial = getenv("AVSEP_SERIAL") != nullptr;   // developer A/B: everything on one stream
+  static const bool serial = dev_env("AVSEP_SERIAL") != nullptr;   // developer A/B: everything on one stream
   // the live profiler times every kernel alone on the chip: with two streams the 20x repeated launches of one
   // branch would overlap the other branch's and inflate both (conv_stack's LDS footprint stalls the audio GEMMs)
   if (serial || c->prof_on) sv = s;
@@ -737,9 +872,11 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
             hipEventCreateWithFlags(&c->ev_vdone, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_adone, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_tdone, hipEventDisableTiming) == hipSuccess;
-  if (const char* e = getenv("AVSEP_TAIL_SPLIT")) c->tail_split = atoi(e) != 0;
-  c->no_fused_conv = getenv("AVSEP_NO_FUSED_CONV") != nullptr;
-  if (getenv("AVSEP_STAMPS")) {
+  // developer A/B switches (libavsep_hip_dev.so only): AVSEP_SCHEDULE=fork restores the two-stream schedule of rounds 1-2
+  if (const char* e = dev_env("AVSEP_SCHEDULE")) c->paired = strcmp(e, "fork") != 0;
+  if (const char* e = dev_env("AVSEP_TAIL_SPLIT")) c->tail_split = atoi(e) != 0;
+  c->no_fused_conv = dev_env("AVSEP_NO_FUSED_CONV") != nullptr;
+  if (dev_env("AVSEP_STAMPS")) {
     if (hipMalloc(reinterpret_cast<void**>(&c->stamps), 16 * sizeof(unsigned long long)) != hipSuccess) c->stamps = nullptr;
     else (void)hipMemset(c->stamps, 0, 16 * sizeof(unsigned long long));
   }
@@ -1104,6 +1241,38 @@ int avsep_op_linear(const float* x, const float* w, const float* bias, const flo
   return AVSEP_OK;
 }
 
+int avsep_op_linear_pair(const float* x0, const float* w0, const float* b0, const float* r0, const float* gamma0,
+                         const float* beta0, float* y0, int M0, const float* x1, const float* w1, const float* b1,
+                         const float* r1, const float* gamma1, const float* beta1, float* y1, int M1, int N, int K,
+                         int act, float eps, void* stream) {
+  if (!x0 || !w0 || !y0 || !x1 || !w1 || !y1 || M0 <= 0 || M1 <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32) return fail(AVSEP_EINVAL, "K must be a multiple of 32");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  if ((b0 == nullptr) != (b1 == nullptr) || (r0 == nullptr) != (r1 == nullptr) || (gamma0 == nullptr) != (gamma1 == nullptr) ||
+      (gamma0 == nullptr) != (beta0 == nullptr) || (gamma1 == nullptr) != (beta1 == nullptr))
+    return fail(AVSEP_EINVAL, "bias / residual / LayerNorm vectors must be given for both problems or for neither");
+  if (gamma0 && !gemm_ln_supported(K)) return fail(AVSEP_EINVAL, "in-kernel LayerNorm form: K is not supported");
+  GemmParams p0 = linear_params(x0, K, w0, K, b0, y0, N, M0, N, act);
+  GemmParams p1 = linear_params(x1, K, w1, K, b1, y1, N, M1, N, act);
+  if (r0) { p0.R = r0; p0.ldr = N; p1.R = r1; p1.ldr = N; }
+  if (gamma0) {
+    p0.ln_gamma = gamma0; p0.ln_beta = beta0; p0.ln_eps = eps;
+    p1.ln_gamma = gamma1; p1.ln_beta = beta1; p1.ln_eps = eps;
+  }
+  HCK(launch_gemm_pair(p0, p1, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_pair(const float* q0, const float* k0, const float* v0, float* o0, int ldqkv0, int ldo0, int B0,
+                            int L0, const float* q1, const float* k1, const float* v1, float* o1, int ldqkv1, int ldo1,
+                            int B1, int L1, int nhead, int dh, void* stream) {
+  if (!q0 || !k0 || !v0 || !o0 || !q1 || !k1 || !v1 || !o1) return fail(AVSEP_EINVAL, "null pointer");
+  const AttnProblem a{q0, k0, v0, o0, ldqkv0, ldqkv0, ldqkv0, ldo0, B0, L0, L0};
+  const AttnProblem b{q1, k1, v1, o1, ldqkv1, ldqkv1, ldqkv1, ldo1, B1, L1, L1};
+  HCK(launch_attention_pair(a, b, nhead, dh, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
 int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps,
                        void* stream) {
   if (!x || !gamma || !beta || !y) return fail(AVSEP_EINVAL, "null pointer");
@@ -1126,6 +1295,10 @@ int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, co
     if (!gemm_ln_supported(K)) return fail(AVSEP_EINVAL, "in-kernel LayerNorm form: K is not supported");
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps;
   } else if (form == 2) {                // statistics launch, normalisation while the GEMM stages A
+#ifndef AVSEP_DEV
+    return fail(AVSEP_EINVAL, "form 2 (LayerNorm applied while the GEMM stages A) is a developer instance: measured "
+                              "slower than form 0, built only into libavsep_hip_dev.so");
+#endif
     if (!scratch) return fail(AVSEP_EINVAL, "form 2 needs 2*M floats of scratch");
     if (!gemm_ln_staged_supported(K)) return fail(AVSEP_EINVAL, "staged LayerNorm form: K is not supported");
     HCK(launch_layernorm_stats(x, scratch, M, K, eps, s));

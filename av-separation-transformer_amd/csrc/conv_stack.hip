@@ -334,18 +334,19 @@ inline int conv_out(int x) { return (x - 1) / 2 + 1; }
 template <int G, int RB2, int RB3, int NW>
 hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) {
   auto kern = conv_stack_kernel<G, RB2, RB3, NW>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes);
-  if (e != hipSuccess) return e;
+  // the instance's dynamic-LDS ceiling is raised once (to the hardware's 160 KiB), not on every launch
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return attr;
   const int ngroups = (p.Mv + G - 1) / G;
   // One workgroup per CU: the audio branch runs concurrently on the other stream and its GEMMs need LDS too
   // (measured: with the CUs' LDS full of conv images the two branches serialise, profiles/r01c_step_timeline.txt).
   int per_cu = 1;
-  if (const char* e = getenv("AVSEP_CONV_WGPC")) per_cu = atoi(e) > 0 ? atoi(e) : 1;   // developer A/B switch
+  if (const char* e = dev_env("AVSEP_CONV_WGPC")) per_cu = atoi(e) > 0 ? atoi(e) : 1;   // developer A/B switch
   int grid = 256 * per_cu;
-  if (const char* e = getenv("AVSEP_CONV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer A/B switch
+  if (const char* e = dev_env("AVSEP_CONV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer A/B switch
   if (grid > ngroups) grid = ngroups;
-  static const bool dbg = getenv("AVSEP_CONV_DBG") != nullptr;
+  static const bool dbg = dev_env("AVSEP_CONV_DBG") != nullptr;
   if (!dbg) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, s, p);
     return hipGetLastError();
@@ -371,7 +372,7 @@ hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t 
 
 template <int G, int RB2, int RB3>
 hipError_t launch_cs(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) {
-  static const bool four = getenv("AVSEP_CONV_NW4") != nullptr;   // developer A/B switch
+  static const bool four = dev_env("AVSEP_CONV_NW4") != nullptr;   // developer A/B switch
   if (four) return launch_cs_nw<G, RB2, RB3, 4>(p, lds_bytes, s);
   return launch_cs_nw<G, RB2, RB3, 8>(p, lds_bytes, s);
 }
@@ -395,10 +396,10 @@ hipError_t launch_conv_stack(const float* frames, const float* w1, const float* 
   const int P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
   // per frame: the two haloed images + the raw pixels staged for conv1
   const size_t frame_bytes = (size_t)(p.a1_frame + p.a2_frame + H * W) * sizeof(float);
-  static const bool four_waves = getenv("AVSEP_CONV_NW4") != nullptr;
+  static const bool four_waves = dev_env("AVSEP_CONV_NW4") != nullptr;
   const size_t raw_cap = (size_t)5 * (four_waves ? 256 : 512);            // RAWN * NT prefetch registers per pass
   const size_t LDS_MAX = 160 * 1024;
-  static const bool force_g1 = getenv("AVSEP_CONV_G1") != nullptr;   // developer A/B switch
+  static const bool force_g1 = dev_env("AVSEP_CONV_G1") != nullptr;   // developer A/B switch
   // Instantiations (G frames per pass, conv2 row blocks, conv3 row blocks); the smallest one that covers the
   // frame size is used -- surplus row blocks recompute row 0 and are discarded.  Two frames per pass halve the
   // weight traffic per frame.

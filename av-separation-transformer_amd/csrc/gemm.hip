@@ -54,6 +54,17 @@ __device__ __forceinline__ int xcd_tile(const GemmParams& p) {
   return tile;
 }
 
+// Pair launch (GemmParams::alt): virtual tiles past g_tiles0 belong to the second problem -- same N, K, leading dimensions
+// and epilogue, other operands and row count.  Block-uniform: a handful of scalar selects at kernel entry.
+__device__ __forceinline__ void select_pair(GemmParams& p, int& tile) {
+  if (p.g_tiles0 > 0 && tile >= p.g_tiles0) {
+    tile -= p.g_tiles0;
+    p.A = p.alt.A; p.W = p.alt.W; p.bias = p.alt.bias; p.R = p.alt.R; p.rperiod = p.alt.rperiod;
+    p.ln_gamma = p.alt.ln_gamma; p.ln_beta = p.alt.ln_beta;
+    p.C = p.alt.C; p.M = p.alt.M;
+  }
+}
+
 // Fused epilogue shared by the GEMM kernels.  The MFMAs are issued with the operands swapped (A operand = W rows,
 // B operand = activation rows, see mfma_chunk), so the 16x16 C/D layout -- col = lane&15, row = 4*(lane>>4)+reg --
 // holds, for output row m = lane&15, FOUR CONSECUTIVE COLUMNS n = 4*(lane>>4)+reg per accumulator: one float4 store
@@ -342,7 +353,8 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (p.N + BN - 1) / BN;
-  const int tile = xcd_tile(p);
+  int tile = xcd_tile(p);
+  select_pair(p, tile);
   const int bm = tile / nbn;
   const int bn = tile - bm * nbn;
   const int m0 = bm * BM, n0 = bn * BN;
@@ -728,7 +740,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // NK = K / BK exactly (compile time): a runtime "if (kc < nk)" around the register arrays makes hipcc copy them
 // through v_mov / v_accvgpr webs (measured 4.5 TFLOP/s on the 8-chunk variant).
 template <int BM, int BN, int BK, int NKMAX>
-__global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams pin) {
+  GemmParams p = pin;
   dbg_stamp(p, 0);
   constexpr int SLOTS = BK / 4;
   constexpr int RPP = 256 / SLOTS;
@@ -745,7 +758,8 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (p.N + BN - 1) / BN;
-  const int tile = xcd_tile(p);
+  int tile = xcd_tile(p);
+  select_pair(p, tile);
   const int bm = tile / nbn;
   const int bn = tile - bm * nbn;
   const int m0 = bm * BM, n0 = bn * BN;
@@ -871,6 +885,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams p) {
   }
 }
 
+#ifdef AVSEP_DEV   // developer instances: measured slower, kept bit-identical for tests and sweeps (make dev)
 // ---------------------------------------------------------------------------------------------------------
 // Large-tile instance on v_mfma_f32_32x32x2_f32 (BM x BN = 128 x 128 or 256 x 128, 4 wavefronts as 2 x 2, each wave a
 // (BM/2) x (BN/2) tile made of 32 x 32 MFMA blocks).  For the M ~ 16 k shapes of configs 3-5 and the training step.
@@ -1348,9 +1363,18 @@ bool try_launch_persist(const GemmParams& p, hipStream_t s, hipError_t* err) {
   return true;
 }
 
+#endif  // AVSEP_DEV
+
+// rows -> 16-row-block tiles of BOTH problems of a pair launch (alt.M > 0), else of the one problem
+inline long row_tiles(const GemmParams& p, int bm) {
+  return (long)(p.M + bm - 1) / bm + (p.alt.M > 0 ? (long)(p.alt.M + bm - 1) / bm : 0);
+}
+
 template <int BM, int BN, int BK, int AMODE, bool PF = false, int RING = 0>
-hipError_t launch_t(const GemmParams& p, hipStream_t s) {
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+hipError_t launch_t(GemmParams p, hipStream_t s) {
+  const int nbn = (p.N + BN - 1) / BN;
+  p.g_tiles0 = p.alt.M > 0 ? ((p.M + BM - 1) / BM) * nbn : 0;
+#ifdef AVSEP_DEV
   if (p.dbg) {   // diagnostics: what the runtime says about residency of this instance
     int nb = 0;
     hipFuncAttributes fa{};
@@ -1359,47 +1383,43 @@ hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     fprintf(stderr, "[gemm dbg] instance <%d,%d,%d,%d,%d>: occupancy API %d workgroups / CU, numRegs %d, static LDS %zu B, scratch %zu B\n",
             BM, BN, BK, AMODE, (int)PF, nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE, PF, RING>), dim3(nbm * nbn, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+#endif
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AMODE, PF, RING>), dim3((unsigned)(row_tiles(p, BM) * nbn), p.ksplit > 1 ? p.ksplit : 1),
+                     dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
-struct Tile { int bm, bn, bk; };   // bm >= 128 && bn >= 128: the 32x32x2 large-tile kernel (gemm32_kernel)
+struct Tile { int bm, bn, bk; };   // bm >= 128 && bn >= 128: the 32x32x2 large-tile developer kernel (gemm32_kernel)
 inline bool is_g32(const Tile& t) { return t.bm >= 128 && t.bn >= 128; }
 
 // Block tile and K-chunk for one launch.
-//  * (BM,BN): measured on MI355X (tools/gemm_sweep.py, profiles/r01a_gemm_tile_sweep.txt): what decides the
-//    time at M ~ 2k is how many workgroups are resident, so small problems take small tiles.
-//  * BK: 64 where it divides K (and the per-tap K of the conv modes) and the tile is small, else 32
-//    (profiles/r01b_gemm_tile_sweep.txt: BK changes little; 64 halves the barriers of the small tiles).
+//  * (BM,BN): measured on MI355X (profiles/r01a_gemm_tile_sweep.txt, r02_gemm_tile_sweep.txt): what decides the time at
+//    M ~ 2k is how many workgroups are resident, so small problems take small tiles; 128x64 from 1000 tiles (the mask
+//    head -- N % 4 != 0, two outputs, block-by-block epilogue -- from 2048), 64x64 (register ring of depth 2, four
+//    workgroups per CU) from 448, 64x32 from 512, else 32x32.
+//  * BK: 64 where it divides K (and the per-tap K of the conv modes) and the tile is small, else 32.
+// The developer build can override every threshold (AVSEP_GEMM_TILE=BMxBNxBK, AVSEP_CONV_TILE, AVSEP_T64, AVSEP_T6432,
+// AVSEP_T12864, AVSEP_T128, AVSEP_T256) for hardware sweeps and for the tile bit-identity tests.
 Tile pick_tile(const GemmParams& p) {
-  // developer override for hardware sweeps (tools/gemm_sweep.py): AVSEP_GEMM_TILE=BMxBNxBK
-  if (const char* e = getenv("AVSEP_GEMM_TILE")) {
+  if (const char* e = dev_env("AVSEP_GEMM_TILE")) {
     Tile t{0, 0, 32};
     if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
   }
   if (p.amode == AMODE_CONV2D) {
-    if (const char* e = getenv("AVSEP_CONV_TILE")) {   // developer override: AVSEP_CONV_TILE=BMxBNxBK
+    if (const char* e = dev_env("AVSEP_CONV_TILE")) {
       Tile t{0, 0, 32};
       if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
     }
   }
-  // largest of {64x64, 64x32} that still gives >= 2 workgroups per CU, else 32x32; 128x64 only when even it
-  // yields >= 8 per CU (cuts L2 traffic on the very large problems; never faster than 64x64 below that)
   const long slices = p.ksplit > 1 ? p.ksplit : 1;
-  auto blocks = [&](int bm, int bn) { return slices * ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  // developer sweeps.  t64 = 448: the M = 4016 (training batch) x 512 outputs give 504 tiles of 64x64, 4-6 % faster than
-  // 64x32 there (profiles/r02_gemm_tile_sweep.txt); no inference shape falls between 448 and 512
-  static const long t64 = getenv("AVSEP_T64") ? atol(getenv("AVSEP_T64")) : 448;
-  static const long t6432 = getenv("AVSEP_T6432") ? atol(getenv("AVSEP_T6432")) : 512;
-  // measured (profiles/r02_gemm_tile_sweep.txt): the 32x32x2 large-tile kernel is bit-identical but 3-8 % SLOWER than the
-  // 128x64 / 64x64 16x16x4 tiles on every cfg3-5 shape, so it is off unless a developer asks for it (AVSEP_T128)
-  // 128x64 from 1000 tiles (profiles/r02_gemm_tile_sweep.txt: since the residual-free epilogue it also wins the
-  // N = 512 shapes of M = 16 k, 1008 tiles); the mask head (N % 4 != 0, two outputs: block-by-block epilogue) keeps 2048
-  static const long t12864 = getenv("AVSEP_T12864") ? atol(getenv("AVSEP_T12864")) : 1000;
-  static const long t128 = getenv("AVSEP_T128") ? atol(getenv("AVSEP_T128")) : 1L << 40;
-  static const long t256 = getenv("AVSEP_T256") ? atol(getenv("AVSEP_T256")) : 1L << 40;
+  auto blocks = [&](int bm, int bn) { return slices * row_tiles(p, bm) * ((p.N + bn - 1) / bn); };
+  static const long t64 = dev_env("AVSEP_T64") ? atol(dev_env("AVSEP_T64")) : 448;
+  static const long t6432 = dev_env("AVSEP_T6432") ? atol(dev_env("AVSEP_T6432")) : 512;
+  static const long t12864 = dev_env("AVSEP_T12864") ? atol(dev_env("AVSEP_T12864")) : 1000;
+  static const long t128 = dev_env("AVSEP_T128") ? atol(dev_env("AVSEP_T128")) : 1L << 40;
+  static const long t256 = dev_env("AVSEP_T256") ? atol(dev_env("AVSEP_T256")) : 1L << 40;
   Tile pick{32, 32, 32};
-  const bool g32_ok = (p.amode == AMODE_PLAIN || p.amode == AMODE_TAPS3) && slices == 1 && p.mag_F == 0;
+  const bool g32_ok = (p.amode == AMODE_PLAIN || p.amode == AMODE_TAPS3) && slices == 1 && p.mag_F == 0 && p.alt.M <= 0;
   if (g32_ok && blocks(256, 128) >= t256) pick = Tile{256, 128, 32};
   else if (g32_ok && blocks(128, 128) >= t128) pick = Tile{128, 128, 32};
   else if (blocks(128, 64) >= t12864 && !(p.N & 3) && !p.C2) pick = Tile{128, 64, 32};
@@ -1424,24 +1444,23 @@ bool ln_fusable(const GemmParams& p) {
 
 Tile pick_ln_tile(const GemmParams& p) {
   const int bk = ln_bk(p.K);
-  if (const char* e = getenv("AVSEP_LN_TILE")) {   // developer override: AVSEP_LN_TILE=BMxBN
+  if (const char* e = dev_env("AVSEP_LN_TILE")) {   // developer override: AVSEP_LN_TILE=BMxBN
     Tile t{32, 32, bk};
     if (sscanf(e, "%dx%d", &t.bm, &t.bn) == 2) return t;
   }
   Tile pick{32, 32, bk};
   if (bk == 64 && p.K / bk <= 4) {
     static const Tile cands[] = {{64, 64, 64}, {64, 32, 64}};
-    auto blocks = [&](const Tile& t) { return (long)((p.M + t.bm - 1) / t.bm) * ((p.N + t.bn - 1) / t.bn); };
-    // measured in the full cfg2 step (two queues busy): 32x32 LN tiles beat 64x32/64x64 by 5 % even where the
-    // bigger tiles win in isolation -- more, shorter workgroups interleave better with the other queue's kernels
-    static const long tln = getenv("AVSEP_TLN") ? atol(getenv("AVSEP_TLN")) : 2048;     // developer sweeps
+    auto blocks = [&](const Tile& t) { return row_tiles(p, t.bm) * ((p.N + t.bn - 1) / t.bn); };
+    // measured in the full cfg2 step: 32-row LN tiles beat 64x32 / 64x64 even where the bigger tiles win in isolation
+    static const long tln = dev_env("AVSEP_TLN") ? atol(dev_env("AVSEP_TLN")) : 2048;
     bool found = false;
     for (const Tile& t : cands)
       if (!found && blocks(t) >= tln) { pick = t; found = true; }
     // 32 rows x 64 columns: every A row block is fetched and normalised for half as many column tiles (the LN-fused
     // prologue is an L2 burst of the workgroup's whole A and W slabs: 97 -> 73 MB per 2016x768x256 launch) while the row
-    // parallelism stays; only where that still leaves >= 2 workgroups per CU (+0.8 % on the 32-clip step, same-run A/B)
-    static const long tln64 = getenv("AVSEP_TLN64") ? atol(getenv("AVSEP_TLN64")) : 512;
+    // parallelism stays; only where that still leaves >= 2 workgroups per CU
+    static const long tln64 = dev_env("AVSEP_TLN64") ? atol(dev_env("AVSEP_TLN64")) : 512;
     const Tile wide{32, 64, 64};
     if (!found && blocks(wide) >= tln64) pick = wide;
   }
@@ -1449,9 +1468,10 @@ Tile pick_ln_tile(const GemmParams& p) {
 }
 
 template <int BM, int BN, int BK, int NK>
-hipError_t launch_ln_t(const GemmParams& p, hipStream_t s) {
-  const int nb = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, BK, NK>), dim3(nb), dim3(256), 0, s, p);
+hipError_t launch_ln_t(GemmParams p, hipStream_t s) {
+  const int nbn = (p.N + BN - 1) / BN;
+  p.g_tiles0 = p.alt.M > 0 ? ((p.M + BM - 1) / BM) * nbn : 0;
+  hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, BK, NK>), dim3((unsigned)(row_tiles(p, BM) * nbn)), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -1479,7 +1499,14 @@ hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-bool gemm_ln_staged_supported(int K) { return K > 0 && K % 32 == 0 && K <= LN_KMAX; }
+bool gemm_ln_staged_supported(int K) {
+#ifdef AVSEP_DEV
+  return K > 0 && K % 32 == 0 && K <= LN_KMAX;
+#else
+  (void)K;
+  return false;   // the staged form (LayerNorm applied while A is staged, AMODE_LN) is a developer instance
+#endif
+}
 
 bool gemm_ln_supported(int K) {
   static const float dummy = 0.f;
@@ -1490,19 +1517,22 @@ bool gemm_ln_supported(int K) {
   return ln_fusable(p);
 }
 
-// long contractions on the 64x64 tile: see mfma_chunk
+#ifdef AVSEP_DEV
+// long contractions on the 64x64 tile: see mfma_chunk.  Off by default since the ring-2 instance (4 workgroups per CU)
+// beats it at every K measured; AVSEP_PF_KMIN=1024 restores the round-1 choice
 bool fragment_prefetch(const Tile& t, const GemmParams& p) {
-  // off by default since the ring-2 instance (4 workgroups per CU) beats it at every K measured; AVSEP_PF_KMIN=1024
-  // restores the round-1 choice
-  static const int kmin = getenv("AVSEP_PF_KMIN") ? atoi(getenv("AVSEP_PF_KMIN")) : 1 << 30;   // developer sweep
+  static const int kmin = dev_env("AVSEP_PF_KMIN") ? atoi(dev_env("AVSEP_PF_KMIN")) : 1 << 30;
   return t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && p.K >= kmin;
 }
-
 bool g32_prefetch() {
-  static const bool pf = getenv("AVSEP_G32_PF") ? atoi(getenv("AVSEP_G32_PF")) != 0 : true;   // developer A/B switch
+  static const bool pf = dev_env("AVSEP_G32_PF") ? atoi(dev_env("AVSEP_G32_PF")) != 0 : true;
   return pf;
 }
+bool ring4_6464() { return dev_env("AVSEP_6464_RING4") != nullptr; }   // read per launch (bit-identity test)
+#endif
 
+// The name rocprofv3 prints for the instance launch_gemm() will pick (without the "void (anonymous namespace)::" prefix and
+// the argument list), so the live profiler's table joins profiles/*_kernel_stats.csv and pmc_hbm_traffic.json by equality.
 const char* gemm_instance_name(const GemmParams& p) {
   static thread_local char buf[64];
   if (p.ln_gamma && !p.ln_stats) {
@@ -1511,23 +1541,30 @@ const char* gemm_instance_name(const GemmParams& p) {
     return buf;
   }
   const Tile t = pick_tile(p);
+#ifdef AVSEP_DEV
   if (p.ln_stats) {
     snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false, 0>", t.bm, t.bn, t.bk, (int)AMODE_LN);
     return buf;
   }
-  if (is_g32(t)) snprintf(buf, sizeof buf, "gemm32_kernel<%d, %d, %d, %s>", t.bm, t.bn, p.amode, g32_prefetch() ? "true" : "false");
-  else if (fragment_prefetch(t, p) && persist_grid<64, 64, 32, true>(p)) snprintf(buf, sizeof buf, "gemm_persist_kernel<64, 64, 32, true>");
-  else if (!fragment_prefetch(t, p) && t.bm == 128 && t.bn == 64 && t.bk == 32 && persist_grid<128, 64, 32, false>(p)) snprintf(buf, sizeof buf, "gemm_persist_kernel<128, 64, 32, false>");
-  else if (!fragment_prefetch(t, p) && t.bm == 64 && t.bn == 64 && t.bk == 32 && persist_grid<64, 64, 32, false>(p)) snprintf(buf, sizeof buf, "gemm_persist_kernel<64, 64, 32, false>");
-  else if (fragment_prefetch(t, p)) snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true, 0>");
-  else if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !getenv("AVSEP_6464_RING4"))
+  if (is_g32(t)) { snprintf(buf, sizeof buf, "gemm32_kernel<%d, %d, %d, %s>", t.bm, t.bn, p.amode, g32_prefetch() ? "true" : "false"); return buf; }
+  if (fragment_prefetch(t, p) && persist_grid<64, 64, 32, true>(p)) { snprintf(buf, sizeof buf, "gemm_persist_kernel<64, 64, 32, true>"); return buf; }
+  if (!fragment_prefetch(t, p) && t.bm == 128 && t.bn == 64 && t.bk == 32 && persist_grid<128, 64, 32, false>(p)) { snprintf(buf, sizeof buf, "gemm_persist_kernel<128, 64, 32, false>"); return buf; }
+  if (!fragment_prefetch(t, p) && t.bm == 64 && t.bn == 64 && t.bk == 32 && persist_grid<64, 64, 32, false>(p)) { snprintf(buf, sizeof buf, "gemm_persist_kernel<64, 64, 32, false>"); return buf; }
+  if (fragment_prefetch(t, p)) { snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, true, 0>"); return buf; }
+  if (t.bm == 128 && t.bn == 64 && t.bk == 16) { snprintf(buf, sizeof buf, "gemm_kernel<128, 64, 16, 0, false, 2>"); return buf; }
+  const bool ring4 = ring4_6464();
+#else
+  const bool ring4 = false;
+#endif
+  if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !ring4)
     snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, false, 2>");
-  else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false, 0>", t.bm, t.bn, t.bk, p.amode);   // as rocprofv3 prints it
+  else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false, 0>", t.bm, t.bn, t.bk, p.amode);
   return buf;
 }
 
 hipError_t launch_gemm_impl(GemmParams p, hipStream_t s);
 
+#ifdef AVSEP_DEV
 // AVSEP_GEMM_DBG: run the launch with the stamp buffer, wait, print where a workgroup's life goes (10 ns ticks)
 hipError_t launch_gemm_dbg(const GemmParams& p_in, hipStream_t s) {
   static unsigned long long* buf = nullptr;
@@ -1590,19 +1627,37 @@ hipError_t launch_gemm_dbg(const GemmParams& p_in, hipStream_t s) {
   }
   return hipSuccess;
 }
+#endif  // AVSEP_DEV
 
 hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
-  static const bool epi_general = getenv("AVSEP_EPI_GENERAL") != nullptr;   // developer A/B: block-by-block epilogue
+#ifdef AVSEP_DEV
+  static const bool epi_general = getenv("AVSEP_EPI_GENERAL") != nullptr;   // A/B: block-by-block epilogue
   p.epi_general = epi_general ? 1 : 0;
   static const bool dbg = getenv("AVSEP_GEMM_DBG") != nullptr;
   if (dbg && !p.dbg) return launch_gemm_dbg(p, s);
+  static const bool no_remap = getenv("AVSEP_NO_XCD_REMAP") != nullptr;     // A/B: launch-order tiles
+  p.no_xcd_remap = no_remap ? 1 : 0;
+#endif
   return launch_gemm_impl(p, s);
 }
 
+// Two problems that differ only in their operands and row count, as ONE launch (GemmParams::alt).
+hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t s) {
+  const bool same = p0.N == p1.N && p0.K == p1.K && p0.lda == p1.lda && p0.ldw == p1.ldw && p0.ldc == p1.ldc &&
+                    p0.ldr == p1.ldr && p0.amode == AMODE_PLAIN && p1.amode == AMODE_PLAIN && p0.act == p1.act &&
+                    (p0.bias == nullptr) == (p1.bias == nullptr) && (p0.R == nullptr) == (p1.R == nullptr) &&
+                    (p0.ln_gamma == nullptr) == (p1.ln_gamma == nullptr) && p0.ln_eps == p1.ln_eps && !p0.C2 && !p1.C2 &&
+                    !p0.ln_stats && !p1.ln_stats && p0.ksplit <= 1 && p1.ksplit <= 1 && p0.mag_F == 0 && p1.mag_F == 0 &&
+                    p0.alt.M <= 0 && p1.alt.M <= 0;
+  if (!same || p1.M <= 0) return hipErrorInvalidValue;
+  GemmParams p = p0;
+  p.alt.A = p1.A; p.alt.W = p1.W; p.alt.bias = p1.bias; p.alt.R = p1.R; p.alt.rperiod = p1.rperiod;
+  p.alt.ln_gamma = p1.ln_gamma; p.alt.ln_beta = p1.ln_beta; p.alt.C = p1.C; p.alt.M = p1.M;
+  return launch_gemm(p, s);
+}
+
 hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
-  static const bool no_remap = getenv("AVSEP_NO_XCD_REMAP") != nullptr;   // developer A/B switch
-  p.no_xcd_remap = no_remap ? 1 : 0;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 31)) return hipErrorInvalidValue;
   if ((p.amode == AMODE_TAPS3 || p.amode == AMODE_CONV2D) && (p.Kt <= 0 || (p.Kt & 31))) return hipErrorInvalidValue;
   if (p.amode == AMODE_FRAMES && (p.T <= 0 || p.frame_hop <= 0 || (p.frame_hop & 3) || p.frame_len <= 0 || (p.frame_len & 3)))
@@ -1610,20 +1665,26 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   if (p.mag_F > 0 && ((p.N & 1) || p.N != 2 * p.mag_F || p.T <= 0 || p.bias || p.R || p.C2 || p.act != ACT_NONE))
     return hipErrorInvalidValue;
   if (p.ksplit > 1) {
-    if (p.amode != AMODE_PLAIN || p.bias || p.R || p.C2 || p.ln_gamma || p.act != ACT_NONE) return hipErrorInvalidValue;
+    if (p.amode != AMODE_PLAIN || p.bias || p.R || p.C2 || p.ln_gamma || p.act != ACT_NONE || p.alt.M > 0) return hipErrorInvalidValue;
     if (p.kchunk <= 0 || (p.kchunk & 63) || (long long)(p.ksplit - 1) * p.kchunk >= p.K) return hipErrorInvalidValue;
   }
+  if (p.alt.M <= 0) p.alt.M = 0;
   if (p.ln_gamma && p.ln_stats) {                      // LayerNorm applied while staging A, statistics given
-    if (!p.ln_beta || p.amode != AMODE_PLAIN || !gemm_ln_staged_supported(p.K) || p.ksplit > 1) return hipErrorInvalidValue;
+#ifdef AVSEP_DEV
+    if (!p.ln_beta || p.amode != AMODE_PLAIN || !gemm_ln_staged_supported(p.K) || p.ksplit > 1 || p.alt.M > 0) return hipErrorInvalidValue;
     p.amode = AMODE_LN;
+#else
+    return hipErrorNotSupported;                       // developer instance (make dev)
+#endif
   } else if (p.ln_gamma) {
     if (!ln_fusable(p)) return hipErrorInvalidValue;   // callers check gemm_ln_supported() first
     return launch_gemm_ln(p, s);
   }
   const Tile t = pick_tile(p);
   if (p.K % t.bk) return hipErrorInvalidValue;
+#ifdef AVSEP_DEV
   if (is_g32(t)) {
-    if ((p.amode != AMODE_PLAIN && p.amode != AMODE_TAPS3) || p.mag_F > 0 || p.ksplit > 1 || t.bk != 32 || t.bn != 128)
+    if ((p.amode != AMODE_PLAIN && p.amode != AMODE_TAPS3) || p.mag_F > 0 || p.ksplit > 1 || t.bk != 32 || t.bn != 128 || p.alt.M > 0)
       return hipErrorInvalidValue;
     const bool pf = g32_prefetch();
 #define AVSEP_G32(BM_, AM_)                                                              \
@@ -1633,7 +1694,7 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
 #undef AVSEP_G32
     return hipErrorInvalidValue;
   }
-  {
+  if (p.alt.M <= 0) {
     hipError_t pe = hipSuccess;
     if (fragment_prefetch(t, p)) {
       if (try_launch_persist<64, 64, 32, true>(p, s, &pe)) return pe;
@@ -1643,30 +1704,40 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
       if (try_launch_persist<64, 64, 32, false>(p, s, &pe)) return pe;
     }
   }
-  if (t.bm == 128 && t.bn == 64 && t.bk == 16 && p.amode == AMODE_PLAIN)   // developer instance: four workgroups per CU
+  if (t.bm == 128 && t.bn == 64 && t.bk == 16 && p.amode == AMODE_PLAIN)   // four workgroups per CU, measured equal
     return launch_t<128, 64, 16, AMODE_PLAIN, false, 2>(p, s);
   if (fragment_prefetch(t, p)) return launch_t<64, 64, 32, AMODE_PLAIN, true>(p, s);
+  const bool ring4 = ring4_6464();
+#else
+  const bool ring4 = false;
+#endif
   // 64x64x32, plain A: register ring of depth 2 instead of 4 -> 104 registers, 4 workgroups per CU instead of 3
-  // (profiles/r02_ab_ring2_64x64.txt: +1..3 % on the N = 512 shapes, and with it the fragment-prefetch instance no
-  // longer pays for its registers at K = 2048: 269.6 vs 275.4 us).  AVSEP_6464_RING4 = the old instance.
-  if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !getenv("AVSEP_6464_RING4"))
+  // (profiles/r02_ab_ring2_64x64.txt: +1..3 % on the N = 512 shapes)
+  if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !ring4)
     return launch_t<64, 64, 32, AMODE_PLAIN, false, 2>(p, s);
 #define AVSEP_CASE(BM_, BN_, BK_, AM_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
+#ifdef AVSEP_DEV
 #define AVSEP_MODES(BM_, BN_, BK_) \
   AVSEP_CASE(BM_, BN_, BK_, AMODE_PLAIN) AVSEP_CASE(BM_, BN_, BK_, AMODE_TAPS3) AVSEP_CASE(BM_, BN_, BK_, AMODE_CONV2D) \
   AVSEP_CASE(BM_, BN_, BK_, AMODE_LN)
+#else
+#define AVSEP_MODES(BM_, BN_, BK_) \
+  AVSEP_CASE(BM_, BN_, BK_, AMODE_PLAIN) AVSEP_CASE(BM_, BN_, BK_, AMODE_TAPS3) AVSEP_CASE(BM_, BN_, BK_, AMODE_CONV2D)
+#endif
   AVSEP_MODES(128, 64, 32)
   AVSEP_MODES(64, 64, 32)
-  AVSEP_MODES(64, 64, 64)
   AVSEP_MODES(64, 32, 32)
   AVSEP_MODES(64, 32, 64)
   AVSEP_MODES(32, 32, 32)
   AVSEP_MODES(32, 32, 64)
-  AVSEP_CASE(32, 32, 128, AMODE_PLAIN)
-  AVSEP_CASE(32, 32, 128, AMODE_TAPS3)
   AVSEP_CASE(32, 32, 64, AMODE_FRAMES) AVSEP_CASE(64, 32, 64, AMODE_FRAMES) AVSEP_CASE(64, 64, 32, AMODE_FRAMES)
   AVSEP_CASE(32, 32, 32, AMODE_FRAMES) AVSEP_CASE(64, 32, 32, AMODE_FRAMES) AVSEP_CASE(128, 64, 32, AMODE_FRAMES)
+#ifdef AVSEP_DEV   // reachable only through the tile overrides
+  AVSEP_MODES(64, 64, 64)
+  AVSEP_CASE(32, 32, 128, AMODE_PLAIN)
+  AVSEP_CASE(32, 32, 128, AMODE_TAPS3)
+#endif
 #undef AVSEP_MODES
 #undef AVSEP_CASE
   return hipErrorInvalidValue;
@@ -1679,7 +1750,7 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
 // workgroups exist; 64x64 tiles from 128 tiles up (or 64 with a long contraction), 32x32 below.
 // (AVSEP_WGRAD_TILE / AVSEP_WGRAD_SLICES: developer sweeps)
 static int wgrad_tile(int N, int K, int R) {
-  if (const char* e = getenv("AVSEP_WGRAD_TILE")) return atoi(e) == 64 ? 64 : 32;
+  if (const char* e = dev_env("AVSEP_WGRAD_TILE")) return atoi(e) == 64 ? 64 : 32;
   const long tiles64 = (long)((N + 63) / 64) * ((K + 63) / 64);
   return (tiles64 >= 128 || (tiles64 >= 64 && R >= 2048)) ? 64 : 32;
 }
@@ -1687,7 +1758,7 @@ int wgrad_slices(int N, int K, int R) {
   const int bt = wgrad_tile(N, K, R);
   const long tiles = (long)((N + bt - 1) / bt) * ((K + bt - 1) / bt);
   long want;
-  if (const char* e = getenv("AVSEP_WGRAD_SLICES")) {
+  if (const char* e = dev_env("AVSEP_WGRAD_SLICES")) {
     want = atol(e);
   } else {
     if (tiles >= 1024 || R < 1024) return 1;

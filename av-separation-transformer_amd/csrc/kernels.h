@@ -3,6 +3,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Developer switches (tile overrides, A/B toggles, diagnostics) exist only in the developer build of the library
+// (`make dev` -> libavsep_hip_dev.so, -DAVSEP_DEV): the product library reads no environment variable and carries none
+// of the kernel instances that were measured slower and are kept for bit-identity tests and hardware sweeps.
+#ifdef AVSEP_DEV
+inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,9 +74,22 @@ struct GemmParams {
   // slices with a column reduction (deterministic, no atomics).  PLAIN mode, no bias/act/residual.  0/1 = off.
   int ksplit, kchunk;
   long long cstride;
+  // Pair launch (launch_gemm_pair): a second problem with the SAME N, K, leading dimensions, A mode, activation and
+  // epilogue kind rides in the same launch -- the audio and the visual instance of an encoder-layer GEMM
+  // (nn.TransformerEncoderLayer of AudioEncoder / VisualEncoder, model.py:48-52 / 97-101: same shapes of weights, M = B*T
+  // and B*N rows).  Virtual tiles [0, g_tiles0) belong to the problem above, the others to `alt`; g_tiles0 is filled in by
+  // the launcher once the tile is chosen (alt.M > 0 marks a pair).
+  int g_tiles0;
+  struct Alt {
+    const float *A, *W, *bias, *R, *ln_gamma, *ln_beta;
+    float* C;
+    int M, rperiod;
+  } alt;
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+// p0 and p1 in ONE launch; they must agree in everything but A, W, bias, C, R (+ rperiod), the LayerNorm vectors and M
+hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t s);
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
 // with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)
@@ -83,6 +106,13 @@ hipError_t launch_layernorm_stats(const float* x, float* stats, int M, int d, fl
 bool gemm_ln_staged_supported(int K);                   // can launch_gemm() take ln_stats for a LayerNorm over K columns?
 hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                             float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s);
+// two attention problems (same head count / head size) in one launch when both take the same kernel instance, else two
+// launches on `s`
+struct AttnProblem { const float *q, *k, *v; float* o; int ldq, ldk, ldv, ldo, B, Lq, Lk; };
+hipError_t launch_attention_pair(const AttnProblem& a, const AttnProblem& b, int nhead, int dh, hipStream_t s);
+bool attention_pair_merges(int dh, int Lk_a, int Lk_b);                          // does the pair become ONE launch?
+// the kernel instance launch_attention() picks for an inference call, spelled as rocprofv3 prints it
+const char* attention_instance_name(int dh, int Lq, int Lk, int B, int nhead);
 hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                                float* o, int ldo, int B, int nhead, int dh, int Lq, int Lk, float qscale, float* lse,
                                float drop_p, unsigned long long drop_seed, hipStream_t s);

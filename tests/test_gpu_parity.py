@@ -37,6 +37,15 @@ def lib():
     return _native.load()
 
 
+@pytest.fixture(scope="module")
+def devlib():
+    """libavsep_hip_dev.so: the same sources with -DAVSEP_DEV -- tile overrides, A/B switches and the kernel instances that
+    were measured slower.  The product library reads no environment variable; bit-identity across instances is shown here
+    through the developer build and tied to the product by comparing ITS output with the developer build's."""
+    from av_separation import _native
+    return _native.load_dev()
+
+
 def build_model(g, dev):
     import av_separation as av
     c = g["config"]
@@ -288,7 +297,7 @@ def test_op_linear(lib, dev, M, N, K, act, res):
     assert maxabs(y.cpu().numpy(), ref) < 2e-6 * max(1.0, float(np.abs(ref).max())) * math.sqrt(K / 32)
 
 
-def test_op_linear_tiles_bit_identical(lib, dev):
+def test_op_linear_tiles_bit_identical(lib, devlib, dev):
     """Every GEMM instance -- 16x16x4 MFMA tiles of any shape and the 32x32x2 large-tile kernel -- feeds the products
     into each accumulator in the same k order, so the outputs are bit-identical whatever tile the dispatcher picks
     (this is what makes results independent of the batch size)."""
@@ -305,9 +314,13 @@ def test_op_linear_tiles_bit_identical(lib, dev):
             if tile.endswith("/ring4"):       # the deeper register ring the 64x64 tile used before (3 workgroups per CU)
                 os.environ["AVSEP_6464_RING4"] = "1"
             y = torch.full((M, N), float("nan"), device=dev)
-            check(lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2,
-                                      _stream()))
+            check(devlib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2,
+                                         _stream()))
             outs[tile] = y
+        # the product library (no switches: its own tile choice) computes the same bits, with the override still set
+        y = torch.full((M, N), float("nan"), device=dev)
+        check(lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2, _stream()))
+        outs["product"] = y
     finally:
         os.environ.pop("AVSEP_GEMM_TILE", None)
         os.environ.pop("AVSEP_6464_RING4", None)
@@ -320,7 +333,7 @@ def test_op_linear_tiles_bit_identical(lib, dev):
 @pytest.mark.parametrize("tile,M,N,K,rounds", [("128x64x32", 8200, 1596, 128, "2"), ("128x64x32", 8200, 1596, 192, "2"),
                                                ("64x64x32", 4100, 1596, 256, "2"), ("128x64x32", 5000, 1280, 64, "1"),
                                                ("64x64x32", 3001, 644, 128, "1.2")])
-def test_op_linear_persistent_form_is_bit_identical(lib, dev, tile, M, N, K, rounds):
+def test_op_linear_persistent_form_is_bit_identical(devlib, dev, tile, M, N, K, rounds):
     """The persistent developer form of the plain GEMM (AVSEP_PERSIST: a resident workgroup walks its tiles and
     prefetches the next tile's first chunks under the current tile's last ones; measured slower, so off by default)
     has the same staging and MFMA order as the one-tile kernel: the two forms agree bit for bit -- ragged last row/column tiles, workgroups with one tile and with several, K
@@ -338,8 +351,8 @@ def test_op_linear_persistent_form_is_bit_identical(lib, dev, tile, M, N, K, rou
             if off:
                 os.environ.pop("AVSEP_PERSIST")
             y = torch.full((M, N), float("nan"), device=dev)
-            check(lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2,
-                                      _stream()))
+            check(devlib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2,
+                                         _stream()))
             outs.append(y)
     finally:
         for k in ("AVSEP_GEMM_TILE", "AVSEP_PERSIST_ROUNDS", "AVSEP_PERSIST"):
@@ -352,10 +365,11 @@ def test_op_linear_persistent_form_is_bit_identical(lib, dev, tile, M, N, K, rou
 
 @pytest.mark.parametrize("M,N,K,act", [(700, 384, 512, 1), (1001, 260, 256, 2), (333, 96, 64, 0), (2100, 1536, 512, 0),
                                        (129, 64, 480, 3)])
-def test_op_ln_linear_forms_agree(lib, dev, M, N, K, act):
-    """LayerNorm -> Linear in its three forms: form 2 (statistics launch + normalisation while the GEMM stages A: what
-    large batches run) is BIT-identical to form 0 (LayerNorm launch + GEMM) on every tile; form 1 (statistics inside
-    the GEMM, one-pass sums) agrees to rounding; all agree with float64."""
+def test_op_ln_linear_forms_agree(lib, devlib, dev, M, N, K, act):
+    """LayerNorm -> Linear in its three forms: form 2 (statistics launch + normalisation while the GEMM stages A; a
+    developer instance, measured slower) is BIT-identical to form 0 (LayerNorm launch + GEMM) on every tile; form 1
+    (statistics inside the GEMM, one-pass sums) agrees to rounding; all agree with float64.  The product library computes
+    form 0 / form 1 with the same bits as the developer build and refuses form 2."""
     import os
     from av_separation._native import check
     x = seeded.tensor(13, "x", (M, K), -3, 5)
@@ -364,11 +378,13 @@ def test_op_ln_linear_forms_agree(lib, dev, M, N, K, act):
     xd, wd, gd, bed, bd = (t(a, dev) for a in (x, w, g_, be_, b_))
     scratch = torch.empty(M * K, device=dev)
 
-    def run(form):
+    def run(form, which=None):
         y = torch.full((M, N), float("nan"), device=dev)
-        check(lib.avsep_op_ln_linear(xd.data_ptr(), gd.data_ptr(), bed.data_ptr(), wd.data_ptr(), bd.data_ptr(),
-                                     y.data_ptr(), scratch.data_ptr(), M, N, K, act, 1e-5, form, _stream()))
-        return y
+        rc = (which or devlib).avsep_op_ln_linear(xd.data_ptr(), gd.data_ptr(), bed.data_ptr(), wd.data_ptr(), bd.data_ptr(),
+                                                  y.data_ptr(), scratch.data_ptr(), M, N, K, act, 1e-5, form, _stream())
+        if which is None:
+            assert rc == 0, devlib.avsep_last_error()
+        return y if which is None else (rc, y)
 
     ln = onp.layer_norm(x.astype(np.float64), g_.astype(np.float64), be_.astype(np.float64))
     ref = torch.from_numpy(ln @ w.astype(np.float64).T + b_.astype(np.float64))
@@ -383,18 +399,109 @@ def test_op_ln_linear_forms_agree(lib, dev, M, N, K, act):
             assert (y0.double().cpu() - ref).abs().max().item() < 2e-5
     finally:
         os.environ.pop("AVSEP_GEMM_TILE", None)
+    rc, p0 = run(0, lib)
+    assert rc == 0 and torch.equal(p0, run(0))
+    assert run(2, lib)[0] == -1 and b"developer" in lib.avsep_last_error()
     if K <= 256:
         y1 = run(1)
         assert (y1.double().cpu() - ref).abs().max().item() < 2e-5
+        rc, p1 = run(1, lib)
+        assert rc == 0 and torch.equal(p1, y1)
 
 
-def test_op_ln_linear_rejects_bad_forms(lib, dev):
+def test_op_ln_linear_rejects_bad_forms(lib, devlib, dev):
     y = torch.empty(64 * 1024, device=dev)
     p_ = y.data_ptr()
-    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 1024, 0, 1e-5, 2, _stream()) == -1   # K > 512
+    assert devlib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 1024, 0, 1e-5, 2, _stream()) == -1   # K > 512
+    assert devlib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, None, 4, 4, 64, 0, 1e-5, 2, _stream()) == -1    # no scratch
+    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 1024, 0, 1e-5, 2, _stream()) == -1
     assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 512, 0, 1e-5, 1, _stream()) == -1    # K > 256
     assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, None, 4, 4, 64, 0, 1e-5, 2, _stream()) == -1    # no scratch
     assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 64, 0, 1e-5, 7, _stream()) == -1
+
+
+@pytest.mark.parametrize("M0,M1,N,K,act,res,ln", [(2016, 1600, 768, 256, 0, False, True), (2016, 1600, 256, 256, 0, True, False),
+                                                  (2016, 1600, 1024, 256, 1, False, True), (2016, 1600, 256, 1024, 0, True, False),
+                                                  (63, 50, 96, 64, 2, False, True), (1, 37, 36, 32, 3, True, False),
+                                                  (16064, 3200, 512, 512, 0, True, False), (700, 1, 384, 128, 1, False, True)])
+def test_op_linear_pair_equals_two_launches(lib, dev, M0, M1, N, K, act, res, ln):
+    """The audio and the visual instance of an encoder-layer GEMM ride in ONE launch (GemmParams::alt).  Whatever tile the
+    pair gets, each problem's outputs are bit-identical to its own single launch (with and without the fused LayerNorm,
+    residual, ragged last tiles, a one-row problem), and nothing is written past either output."""
+    from av_separation._native import check
+    rng = {}
+    for j, M in enumerate((M0, M1)):
+        rng[j] = dict(x=t(seeded.tensor(21 + j, "x", (M, K), -3, 4), dev), w=t(seeded.tensor(21 + j, "w", (N, K), -0.2, 0.2), dev),
+                      b=t(seeded.tensor(21 + j, "b", (N,), -1, 1), dev), r=t(seeded.tensor(21 + j, "r", (M, N), -1, 1), dev),
+                      g=t(seeded.tensor(21 + j, "g", (K,), 0.5, 1.5), dev), be=t(seeded.tensor(21 + j, "be", (K,), -1, 1), dev))
+    single = []
+    for j, M in enumerate((M0, M1)):
+        a = rng[j]
+        y = torch.full((M, N), float("nan"), device=dev)
+        if ln:
+            check(lib.avsep_op_ln_linear(a["x"].data_ptr(), a["g"].data_ptr(), a["be"].data_ptr(), a["w"].data_ptr(),
+                                         a["b"].data_ptr(), y.data_ptr(), None, M, N, K, act, 1e-5, 1, _stream()))
+        else:
+            check(lib.avsep_op_linear(a["x"].data_ptr(), a["w"].data_ptr(), a["b"].data_ptr(), a["r"].data_ptr() if res else None,
+                                      y.data_ptr(), M, N, K, act, _stream()))
+        single.append(y)
+    guard = 64
+    ys = [torch.full((M * N + guard,), float("nan"), device=dev) for M in (M0, M1)]
+    a0, a1 = rng[0], rng[1]
+    check(lib.avsep_op_linear_pair(a0["x"].data_ptr(), a0["w"].data_ptr(), a0["b"].data_ptr(), a0["r"].data_ptr() if res else None,
+                                   a0["g"].data_ptr() if ln else None, a0["be"].data_ptr() if ln else None, ys[0].data_ptr(), M0,
+                                   a1["x"].data_ptr(), a1["w"].data_ptr(), a1["b"].data_ptr(), a1["r"].data_ptr() if res else None,
+                                   a1["g"].data_ptr() if ln else None, a1["be"].data_ptr() if ln else None, ys[1].data_ptr(), M1,
+                                   N, K, act, 1e-5, _stream()))
+    for j, M in enumerate((M0, M1)):
+        assert torch.isfinite(single[j]).all()
+        assert torch.equal(ys[j][:M * N].view(M, N), single[j]), j
+        assert torch.isnan(ys[j][M * N:]).all(), j
+    # and against float64
+    a = rng[0]
+    x64 = a["x"].double().cpu()
+    if ln:
+        mu, var = x64.mean(1, keepdim=True), x64.var(1, unbiased=False, keepdim=True)
+        x64 = (x64 - mu) / torch.sqrt(var + 1e-5) * a["g"].double().cpu() + a["be"].double().cpu()
+    ref = x64 @ a["w"].double().cpu().T + a["b"].double().cpu()
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.nn.functional.gelu(ref), 3: torch.sigmoid(ref)}[act]
+    if res and not ln:
+        ref = ref + a["r"].double().cpu()
+    assert (single[0].double().cpu() - ref).abs().max().item() < 3e-5 * math.sqrt(K / 32)
+
+
+def test_op_linear_pair_rejects_mismatched_problems(lib, dev):
+    y = torch.empty(64 * 64, device=dev)
+    p_ = y.data_ptr()
+    assert lib.avsep_op_linear_pair(p_, p_, p_, None, None, None, p_, 4, p_, p_, None, None, None, None, p_, 4, 4, 32, 0, 1e-5, _stream()) == -1
+    assert lib.avsep_op_linear_pair(p_, p_, p_, None, p_, p_, p_, 4, p_, p_, p_, None, None, None, p_, 4, 4, 32, 0, 1e-5, _stream()) == -1
+    assert lib.avsep_op_linear_pair(p_, p_, p_, None, p_, p_, p_, 4, p_, p_, p_, None, p_, p_, p_, 4, 4, 512, 0, 1e-5, _stream()) == -1
+    assert lib.avsep_op_linear_pair(p_, p_, p_, None, None, None, p_, 4, p_, p_, p_, None, None, None, p_, 0, 4, 32, 0, 1e-5, _stream()) == -1
+
+
+@pytest.mark.parametrize("B,h,dh,L0,L1", [(32, 4, 64, 63, 50), (3, 2, 64, 49, 64), (2, 4, 64, 63, 20), (2, 8, 64, 251, 50),
+                                          (2, 4, 16, 32, 10)])
+def test_op_attention_pair_equals_two_launches(lib, dev, B, h, dh, L0, L1):
+    """Audio and visual self-attention of one encoder layer as one launch (both sequences in the short-sequence kernel's
+    range) or as two (any other lengths): bit-identical to the single launches either way."""
+    from av_separation._native import check
+    d = h * dh
+    outs, qkvs = [], []
+    for j, L in enumerate((L0, L1)):
+        qkv = t(seeded.tensor(31 + j, "qkv", (B * L, 3 * d), -1.5, 1.5), dev)
+        o = torch.full((B * L, d), float("nan"), device=dev)
+        check(lib.avsep_op_attention(qkv.data_ptr(), 3 * d, qkv.data_ptr() + 4 * d, 3 * d, qkv.data_ptr() + 8 * d, 3 * d,
+                                     o.data_ptr(), d, B, h, dh, L, L, _stream()))
+        outs.append(o)
+        qkvs.append(qkv)
+    po = [torch.full((B * L * d + 64,), float("nan"), device=dev) for L in (L0, L1)]
+    check(lib.avsep_op_attention_pair(qkvs[0].data_ptr(), qkvs[0].data_ptr() + 4 * d, qkvs[0].data_ptr() + 8 * d, po[0].data_ptr(),
+                                      3 * d, d, B, L0, qkvs[1].data_ptr(), qkvs[1].data_ptr() + 4 * d, qkvs[1].data_ptr() + 8 * d,
+                                      po[1].data_ptr(), 3 * d, d, B, L1, h, dh, _stream()))
+    for j, L in enumerate((L0, L1)):
+        assert torch.isfinite(outs[j]).all()
+        assert torch.equal(po[j][:B * L * d].view(B * L, d), outs[j]), j
+        assert torch.isnan(po[j][B * L * d:]).all()
 
 
 def test_op_linear_rejects_bad_k(lib, dev):
@@ -440,7 +547,7 @@ def test_op_attention(lib, dev, B, h, dh, Lq, Lk):
 
 
 @pytest.mark.parametrize("B,h,Lq,Lk", [(2, 8, 251, 251), (1, 4, 501, 501), (3, 2, 130, 129), (1, 2, 40, 300)])
-def test_op_attention_lds_variant_is_bit_identical(lib, dev, B, h, Lq, Lk):
+def test_op_attention_lds_variant_is_bit_identical(lib, devlib, dev, B, h, Lq, Lk):
     """Long sequences (dh = 64, Lk >= 128) take K / V through LDS; same arithmetic in the same order as the
     register-streaming kernel, so the two must agree bit for bit (AVSEP_ATTN_NO_LDS selects the latter)."""
     import os
@@ -459,9 +566,13 @@ def test_op_attention_lds_variant_is_bit_identical(lib, dev, B, h, Lq, Lk):
                 os.environ.pop(k_, None)
             os.environ.update(env)
             o = torch.full((B, Lq, d), float("nan"), device=dev)
-            check(lib.avsep_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d, B, h, dh,
-                                         Lq, Lk, _stream()))
+            check(devlib.avsep_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d, B, h, dh,
+                                            Lq, Lk, _stream()))
             outs.append(o)
+        o = torch.full((B, Lq, d), float("nan"), device=dev)          # the product library's own choice: the same bits
+        check(lib.avsep_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d, B, h, dh,
+                                     Lq, Lk, _stream()))
+        outs.append(o)
     finally:
         for k_ in ("AVSEP_ATTN_NO_LDS_NOW", "AVSEP_ATTN_QT"):
             os.environ.pop(k_, None)

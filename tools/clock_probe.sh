@@ -3,6 +3,7 @@
 # GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch duration on >= 9 ms dispatches of a 65536 x 4096 x 2048
 # problem (MI355X_MICROARCH.md "DVFS give-back": within 3 % of the in-kernel clock on dispatches of 10 ms or more),
 # after ~1 s of back-to-back launches.  Also prints matrix-pipe busy %.  Usage: tools/clock_probe.sh [TILE ...]
+export AVSEP_LIB=dev   # developer switches exist only in libavsep_hip_dev.so (make dev)
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/clock_probe; rm -rf $OUT; mkdir -p $OUT
 TILES=${@:-"auto 128x128x32"}

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: time avsep_op_linear on the large GEMM shapes under the tile chosen by AVSEP_GEMM_TILE (or auto)."""
+import os
+os.environ.setdefault("AVSEP_LIB", "dev")   # developer switches live in libavsep_hip_dev.so only
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))

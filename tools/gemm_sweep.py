@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): time avsep_op_linear for every instantiated tile on the GEMM shapes of a
 workload.  Tiles are forced through the AVSEP_GEMM_TILE developer override, one subprocess per tile."""
+import os
+os.environ.setdefault("AVSEP_LIB", "dev")   # developer switches live in libavsep_hip_dev.so only
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))

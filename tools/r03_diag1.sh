@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 diagnostics of the cfg2 step on the current build (one device, one run)
+export AVSEP_LIB=dev   # developer switches exist only in libavsep_hip_dev.so (make dev)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03a; mkdir -p $O; cd $R
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_cmd.json 2>$O/driver_cmd.err
 echo "driver cmd done"

@@ -2,6 +2,8 @@
 """Developer tool (GPU box): what would launching the audio and the visual instance of an encoder-layer GEMM as ONE kernel
 buy?  Times the plain / LayerNorm-fused GEMM and the attention kernel at M = 2016 (audio), 1600 (visual) and 3616 (both)
 rows for each tile override; one subprocess per override (the switches are read once per process)."""
+import os
+os.environ.setdefault("AVSEP_LIB", "dev")   # developer switches live in libavsep_hip_dev.so only
 import ctypes as C, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))

@@ -2,6 +2,8 @@
 """Developer tool (GPU box): profiler-free timeline of one cfg2 step under graph replay, from device wall-clock
 stamps at the stage boundaries (AVSEP_STAMPS, avsep_read_stamps).  Prints medians over many steps relative to the
 step's first stamp, plus the period between consecutive steps."""
+import os
+os.environ.setdefault("AVSEP_LIB", "dev")   # developer switches live in libavsep_hip_dev.so only
 import ctypes as C
 import os
 import sys
@@ -33,8 +35,12 @@ _, F, T = mixed.shape
 S = wl["model"]["num_speakers"]
 mk, sp = torch.empty(B, T, S, F, device=dev), torch.empty(B, T, S, F, device=dev)
 lib = _native.load()
-names = ["audio start", "visual start", "visual enc done", "kv proj done", "audio done", "tail start (main)",
-         "tail start (side)", "tail end (main)", "tail end (side)", "step end"]
+if os.environ.get("AVSEP_SCHEDULE") == "fork":      # the two-stream schedule of rounds 1-2
+    names = ["audio start", "visual start", "visual enc done", "kv proj done", "audio done", "tail start (main)",
+             "tail start (side)", "tail end (main)", "tail end (side)", "step end"]
+else:                                               # paired schedule (forward_paired): slots 6 and 8 are not stamped
+    names = ["audio front start", "visual front start", "visual front done (conv stack + frame proj)", "resize + K/V projection done",
+             "audio front done", "encoder layers done (paired launches)", None, "fusion layers done", None, "step end (decoder done)"]
 st = torch.cuda.Stream(device=dev)
 rows = []
 with torch.cuda.stream(st), torch.no_grad():
@@ -50,7 +56,9 @@ with torch.cuda.stream(st), torch.no_grad():
         _native.check(lib.avsep_read_stamps(m._engine.ctx, buf, 10), "read_stamps")
         rows.append([int(x) for x in buf])
 a = np.array(rows, dtype=np.float64) / 100.0           # us
+used = [i for i, n in enumerate(names) if n is not None]
+a = a[:, used]
 t0 = a.min(axis=1, keepdims=True)
 rel = np.median(a - t0, axis=0)
 for i in np.argsort(rel):
-    print(f"{rel[i]:8.1f} us  {names[i]}")
+    print(f"{rel[i]:8.1f} us  {names[used[i]]}")

@@ -2,6 +2,8 @@
 """Developer tool (GPU box): time avsep_op_wgrad_bias_direct (weight + bias gradient of a Linear) on the training
 shapes for several (tile, slice count) choices forced through AVSEP_WGRAD_TILE / AVSEP_WGRAD_SLICES, one subprocess
 per choice; 'auto' = the library's own choice.  Prints us per call (launch + slice sum) and TFLOP/s."""
+import os
+os.environ.setdefault("AVSEP_LIB", "dev")   # developer switches live in libavsep_hip_dev.so only
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))
