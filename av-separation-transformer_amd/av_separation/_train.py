@@ -192,7 +192,10 @@ class _WtTable:
                 or not self._usable(w)):
             return None
         if self.stale:
-            self._refresh()
+            self._refresh()                                 # may compact the table: look the weight up again
+            i = self.index.get(id(w))
+            if i is None:
+                return None
         return self.bufs[i]                                 # None if the refresh had to drop the entry
 
     def _compact(self):

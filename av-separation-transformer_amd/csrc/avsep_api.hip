@@ -107,7 +107,7 @@ struct avsep_ctx {
   hipStream_t side = nullptr;                      // eager forwards: the visual branch's stream
   hipEvent_t ev_fork = nullptr, ev_vdone = nullptr, ev_adone = nullptr, ev_tdone = nullptr;
   bool no_fused_conv = false;                      // developer A/B switch (AVSEP_NO_FUSED_CONV)
-  bool paired = true;                              // encoder layers of both branches in shared launches (forward_paired)
+  bool paired = false;                             // developer experiment: encoder layers of both branches in shared launches
   bool tail_split = true;                          // two-stream schedule: fusion+decoder, half the batch per stream after the join
   std::vector<GraphEntry> graphs;
   // live per-kernel profiler (HIP events around every launch, on the launch's own stream)
@@ -411,6 +411,7 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
 GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
                          int M, int N, int act);
 
+#ifdef AVSEP_DEV   // paired launches: a measured-slower schedule kept as a developer experiment (see forward_paired)
 // The second problem of a pair launch (kernels.h GemmParams::alt): p1 differs from p0 in operands and row count only.
 GemmParams pair_params(const GemmParams& p0, const GemmParams& p1) {
   GemmParams p = p0;
@@ -447,6 +448,7 @@ int run_ln_linear_pair(avsep_ctx* c, const LnLin& a, const LnLin& v, int N, int 
   pv.A = v.ln_buf;
   return run_gemm_pair(c, pa, pv, s);
 }
+#endif  // AVSEP_DEV
 
 GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
                          int M, int N, int act) {
@@ -475,6 +477,7 @@ int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* 
   return AVSEP_OK;
 }
 
+#ifdef AVSEP_DEV
 // Layer i of the audio encoder (rows B*La) and of the visual encoder (rows B*Lv) side by side: the two are independent
 // and have the same weight shapes (model.py:48-52 / 97-101), so each of the five kernels of a layer is launched ONCE for
 // both -- twice the workgroups per launch and half the launches, instead of two streams whose kernels have to find room
@@ -509,6 +512,7 @@ int encoder_layer_pair(avsep_ctx* c, const EncLayerW& A, const EncLayerW& V, con
   RCK(run_gemm_pair(c, fa, fv, s));
   return AVSEP_OK;
 }
+#endif  // AVSEP_DEV
 
 int check_common(const avsep_ctx* c, int B, int T) {
   if (!c) return fail(AVSEP_EINVAL, "null context");
@@ -699,12 +703,16 @@ inline void stamp(avsep_ctx* c, int idx, hipStream_t s) {
   if (c->stamps) (void)launch_stamp(c->stamps, idx, s);
 }
 
-// Paired schedule (the default): only the two front-ends run side by side -- the LDS-resident conv stack + frame
-// projection on `sv`, the Conv1d pair on `sa` -- then ONE chain on `sa`: every encoder layer as five launches that serve
-// the audio and the visual sequence at once (encoder_layer_pair), the resize, the K/V projection, the fusion layers and the
-// decoder on the whole batch.  A replayed step is then one queue of ~30 kernels with a short second queue at its head,
-// instead of two queues of 28 whose kernels compete for the CUs' LDS and wave slots: no dependence on how the runtime maps
-// four in-flight branches (two steps x two streams) onto its hardware queues.
+#ifdef AVSEP_DEV
+// Paired schedule (developer experiment, AVSEP_SCHEDULE=paired): only the two front-ends run side by side -- the
+// LDS-resident conv stack + frame projection on `sv`, the Conv1d pair on `sa` -- then ONE chain on `sa`: every encoder
+// layer as five launches that serve the audio and the visual sequence at once (encoder_layer_pair), the resize, the K/V
+// projection, the fusion layers and the decoder on the whole batch: ~30 launches per step instead of 56.
+// MEASURED SLOWER than the two-stream schedule (profiles/r03_ab_paired_schedule.txt, same-run A/B on one MI355X, cfg2):
+// 0.490 vs 0.439 ms one step at a time, 0.365 vs 0.353 with two steps in flight; cfg3 / cfg5 equal.  A pair launch takes
+// ~85 % of the time of its two halves launched one after the other (24.4 us for the 3616-row QKV against 14.3 + 13.9), but
+// two streams overlap the ramp, prologue and drain of DIFFERENT kernels, which is worth more (the two chains' 364 us of
+// kernel time finish in 290), and the full-batch tail on one stream (149 us) loses to two half-batch tails (139).
 int forward_paired(avsep_ctx* c, const Workspace& w, const float* mixed, const float* lips, float* masks, float* sep,
                    int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv) {
   stamp(c, 1, sv);
@@ -737,9 +745,13 @@ int forward_paired(avsep_ctx* c, const Workspace& w, const float* mixed, const f
   return AVSEP_OK;
 }
 
+#endif  // AVSEP_DEV
+
 int forward_part(avsep_ctx* c, const Workspace& w, const float* mixed, const float* lips, float* masks, float* sep,
                  int B, int T, int N, int H, int W, hipStream_t sa, hipStream_t sv) {
+#ifdef AVSEP_DEV
   if (c->paired) return forward_paired(c, w, mixed, lips, masks, sep, B, T, N, H, W, sa, sv);
+#endif
   stamp(c, 1, sv);
   int rv = visual_branch(c, w, lips, B, N, H, W, T, sv);
   stamp(c, 2, sv);
@@ -872,8 +884,8 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
             hipEventCreateWithFlags(&c->ev_vdone, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_adone, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_tdone, hipEventDisableTiming) == hipSuccess;
-  // developer A/B switches (libavsep_hip_dev.so only): AVSEP_SCHEDULE=fork restores the two-stream schedule of rounds 1-2
-  if (const char* e = dev_env("AVSEP_SCHEDULE")) c->paired = strcmp(e, "fork") != 0;
+  // developer A/B switches (libavsep_hip_dev.so only)
+  if (const char* e = dev_env("AVSEP_SCHEDULE")) c->paired = strcmp(e, "paired") == 0;
   if (const char* e = dev_env("AVSEP_TAIL_SPLIT")) c->tail_split = atoi(e) != 0;
   c->no_fused_conv = dev_env("AVSEP_NO_FUSED_CONV") != nullptr;
   if (dev_env("AVSEP_STAMPS")) {
@@ -1241,6 +1253,7 @@ int avsep_op_linear(const float* x, const float* w, const float* bias, const flo
   return AVSEP_OK;
 }
 
+#ifdef AVSEP_DEV
 int avsep_op_linear_pair(const float* x0, const float* w0, const float* b0, const float* r0, const float* gamma0,
                          const float* beta0, float* y0, int M0, const float* x1, const float* w1, const float* b1,
                          const float* r1, const float* gamma1, const float* beta1, float* y1, int M1, int N, int K,
@@ -1272,6 +1285,7 @@ int avsep_op_attention_pair(const float* q0, const float* k0, const float* v0, f
   HCK(launch_attention_pair(a, b, nhead, dh, reinterpret_cast<hipStream_t>(stream)));
   return AVSEP_OK;
 }
+#endif  // AVSEP_DEV
 
 int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps,
                        void* stream) {

@@ -145,6 +145,9 @@ int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, co
 int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                        int ldo, int B, int nhead, int dh, int Lq, int Lk, void* stream);
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream);
+#ifdef AVSEP_DEV
+/* Developer build only (libavsep_hip_dev.so): the paired-launch experiment of round 3, measured slower than the two-stream
+ * schedule and therefore not part of the product ABI. */
 /* The two instances of one encoder-layer kernel -- AudioEncoder's and VisualEncoder's layer i, /root/reference/src/
  * av_separation/model.py:48-52 and 97-101: same weight shapes, M0 = B*T and M1 = B*N rows -- as ONE launch (what the
  * forward path does for every encoder layer).  Problem j: y_j = act(LN?(x_j) w_j^T + b_j) (+ r_j); gamma_j / beta_j
@@ -159,6 +162,7 @@ int avsep_op_linear_pair(const float* x0, const float* w0, const float* b0, cons
 int avsep_op_attention_pair(const float* q0, const float* k0, const float* v0, float* o0, int ldqkv0, int ldo0, int B0,
                             int L0, const float* q1, const float* k1, const float* v1, float* o1, int ldqkv1, int ldo1,
                             int B1, int L1, int nhead, int dh, void* stream);
+#endif  /* AVSEP_DEV */
 
 /* ------------------------------------------------------------------------------------------------------------
  * STFT magnitude front-end: replaces SyntheticAVDataset._stft

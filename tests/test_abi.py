@@ -10,9 +10,15 @@ from conftest import ROOT
 from av_separation import _native
 
 
-def header_functions():
+def header_functions(dev_only=False):
+    """Functions include/avsep.h declares for the product (default) or only inside its `#ifdef AVSEP_DEV` sections."""
     text = open(os.path.join(ROOT, "include", "avsep.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    dev = "".join(re.findall(r"#ifdef AVSEP_DEV(.*?)#endif", text, flags=re.S))
+    if dev_only:
+        text = dev
+    else:
+        text = re.sub(r"#ifdef AVSEP_DEV.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(avsep_[a-z_0-9]+)\s*\(", text)))
 
 
@@ -25,6 +31,27 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in header_functions():
         assert hasattr(lib, name), name
+
+
+def test_developer_library_is_a_superset_and_the_product_has_no_developer_entry_points():
+    assert os.path.exists(_native.DEV_LIB_PATH), "run __graft_entry__.build() first"
+    dev, prod = ctypes.CDLL(_native.DEV_LIB_PATH), ctypes.CDLL(_native.LIB_PATH)
+    extra = header_functions(dev_only=True)
+    assert extra, "the header lists the developer build's extra entry points"
+    for name in header_functions() + extra:
+        assert hasattr(dev, name), name
+    for name in extra:
+        assert not hasattr(prod, name), name
+    assert dev.avsep_abi_version() == prod.avsep_abi_version()
+
+
+def test_product_library_reads_no_environment_variable():
+    """`nm -D --undefined-only`: the product library does not even import getenv / secure_getenv."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
+    out = subprocess.run(["nm", "-D", "--undefined-only", _native.DEV_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" in out
 
 
 def test_version_and_error_string_without_gpu():

@@ -424,8 +424,9 @@ def test_op_ln_linear_rejects_bad_forms(lib, devlib, dev):
                                                   (2016, 1600, 1024, 256, 1, False, True), (2016, 1600, 256, 1024, 0, True, False),
                                                   (63, 50, 96, 64, 2, False, True), (1, 37, 36, 32, 3, True, False),
                                                   (16064, 3200, 512, 512, 0, True, False), (700, 1, 384, 128, 1, False, True)])
-def test_op_linear_pair_equals_two_launches(lib, dev, M0, M1, N, K, act, res, ln):
-    """The audio and the visual instance of an encoder-layer GEMM ride in ONE launch (GemmParams::alt).  Whatever tile the
+def test_op_linear_pair_equals_two_launches(lib, devlib, dev, M0, M1, N, K, act, res, ln):
+    """(Developer experiment, libavsep_hip_dev.so.)  The audio and the visual instance of an encoder-layer GEMM ride in ONE
+    launch (GemmParams::alt).  Whatever tile the
     pair gets, each problem's outputs are bit-identical to its own single launch (with and without the fused LayerNorm,
     residual, ragged last tiles, a one-row problem), and nothing is written past either output."""
     from av_separation._native import check
@@ -448,7 +449,7 @@ def test_op_linear_pair_equals_two_launches(lib, dev, M0, M1, N, K, act, res, ln
     guard = 64
     ys = [torch.full((M * N + guard,), float("nan"), device=dev) for M in (M0, M1)]
     a0, a1 = rng[0], rng[1]
-    check(lib.avsep_op_linear_pair(a0["x"].data_ptr(), a0["w"].data_ptr(), a0["b"].data_ptr(), a0["r"].data_ptr() if res else None,
+    check(devlib.avsep_op_linear_pair(a0["x"].data_ptr(), a0["w"].data_ptr(), a0["b"].data_ptr(), a0["r"].data_ptr() if res else None,
                                    a0["g"].data_ptr() if ln else None, a0["be"].data_ptr() if ln else None, ys[0].data_ptr(), M0,
                                    a1["x"].data_ptr(), a1["w"].data_ptr(), a1["b"].data_ptr(), a1["r"].data_ptr() if res else None,
                                    a1["g"].data_ptr() if ln else None, a1["be"].data_ptr() if ln else None, ys[1].data_ptr(), M1,
@@ -470,7 +471,8 @@ def test_op_linear_pair_equals_two_launches(lib, dev, M0, M1, N, K, act, res, ln
     assert (single[0].double().cpu() - ref).abs().max().item() < 3e-5 * math.sqrt(K / 32)
 
 
-def test_op_linear_pair_rejects_mismatched_problems(lib, dev):
+def test_op_linear_pair_rejects_mismatched_problems(devlib, dev):
+    lib = devlib
     y = torch.empty(64 * 64, device=dev)
     p_ = y.data_ptr()
     assert lib.avsep_op_linear_pair(p_, p_, p_, None, None, None, p_, 4, p_, p_, None, None, None, None, p_, 4, 4, 32, 0, 1e-5, _stream()) == -1
@@ -481,7 +483,7 @@ def test_op_linear_pair_rejects_mismatched_problems(lib, dev):
 
 @pytest.mark.parametrize("B,h,dh,L0,L1", [(32, 4, 64, 63, 50), (3, 2, 64, 49, 64), (2, 4, 64, 63, 20), (2, 8, 64, 251, 50),
                                           (2, 4, 16, 32, 10)])
-def test_op_attention_pair_equals_two_launches(lib, dev, B, h, dh, L0, L1):
+def test_op_attention_pair_equals_two_launches(lib, devlib, dev, B, h, dh, L0, L1):
     """Audio and visual self-attention of one encoder layer as one launch (both sequences in the short-sequence kernel's
     range) or as two (any other lengths): bit-identical to the single launches either way."""
     from av_separation._native import check
@@ -495,7 +497,7 @@ def test_op_attention_pair_equals_two_launches(lib, dev, B, h, dh, L0, L1):
         outs.append(o)
         qkvs.append(qkv)
     po = [torch.full((B * L * d + 64,), float("nan"), device=dev) for L in (L0, L1)]
-    check(lib.avsep_op_attention_pair(qkvs[0].data_ptr(), qkvs[0].data_ptr() + 4 * d, qkvs[0].data_ptr() + 8 * d, po[0].data_ptr(),
+    check(devlib.avsep_op_attention_pair(qkvs[0].data_ptr(), qkvs[0].data_ptr() + 4 * d, qkvs[0].data_ptr() + 8 * d, po[0].data_ptr(),
                                       3 * d, d, B, L0, qkvs[1].data_ptr(), qkvs[1].data_ptr() + 4 * d, qkvs[1].data_ptr() + 8 * d,
                                       po[1].data_ptr(), 3 * d, d, B, L1, h, dh, _stream()))
     for j, L in enumerate((L0, L1)):

@@ -68,3 +68,25 @@ def test_dead_models_leave_no_slots():
     gc.collect()
     assert _live(t) == [keep]
     assert len(t.weights) == len(t.bufs) == len(t.ptrs) == len(t.index) == 1 and t.index[id(keep)] == 0
+
+
+def test_get_survives_the_compaction_its_own_refresh_triggers(monkeypatch):
+    """get() refreshes a stale table, the refresh drops dead slots and renumbers the live ones: the position looked up
+    before the refresh must not be used after it."""
+    t = _table()
+    dead = [torch.nn.Parameter(torch.randn(8, 32)) for _ in range(3)]
+    for w in dead:
+        t.register(w)
+    keep = torch.nn.Parameter(torch.randn(8, 32))
+    t.register(keep)                                # position 3
+    del dead, w
+    gc.collect()
+    monkeypatch.setattr(tr, "_ck", lambda rc, what="": rc)            # no library on the CPU box: the launch is a no-op
+
+    class _Lib:
+        def avsep_op_transpose_many(self, *a):
+            return 0
+    monkeypatch.setattr(tr, "_lib", lambda: _Lib())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: type("S", (), {"cuda_stream": 0})())
+    buf = t.get(keep)
+    assert buf is not None and tuple(buf.shape) == (32, 32) and t.index[id(keep)] == 0 and not t.stale
