@@ -1,10 +1,13 @@
 """Training path on the GPU against the reference's own train-mode forward/backward
 (tests/golden/train_*.npz, made by make_golden.py::make_train with dropout 0): forward outputs with BatchNorm
 batch statistics, the PIT loss, EVERY parameter gradient and the updated BatchNorm buffers."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
+from conftest import ROOT
 from helpers import maxabs
 from oracle import seeded
 
@@ -28,8 +31,41 @@ GRAD_TOL = 5e-5     # relative to the largest entry of each gradient tensor; obs
 MASK_TOL = 4e-6     # observed 4e-7
 
 
-@pytest.mark.parametrize("name", ["train_tiny", "train_odd", "train_cfg4"])
+QUIET = 1e-5        # a tensor whose reference fp32 gradient is this close to the reference's fp64 gradient is "quiet"
+RATIO = 1.5         # noisy tensors: dist(HIP, fp64) may be at most this multiple of dist(reference fp32, fp64) ...
+ALLOW_CAP = 5e-3    # ... and never more than this (relative to the tensor's largest entry), except for:
+KINK = "visual_encoder.conv.0.weight"   # a ReLU-kink / BatchNorm-cancellation tensor: its gradient is ~0 in exact arithmetic
+                                        # (BatchNorm removes what a conv-weight scale does), so its relative noise is O(1e-2)
+NORM_TOL = 5e-3
+
+
+def _grad_report(name, rows):
+    """Per-tensor record of what the gate measured (also written under gpurun_out/ on the GPU box -> profiles/)."""
+    lines = [f"# {name}: per parameter tensor, relative to its largest |gradient| entry:",
+             "#   ref_noise = dist(reference fp32, reference fp64), hip_fp32 = dist(HIP, reference fp32), hip_fp64 = dist(HIP, reference fp64)",
+             "#   ratio = hip_fp64 / ref_noise (noisy tensors only; gate <= %.1f); quiet tensors: hip_fp32 gate %.0e" % (RATIO, GRAD_TOL),
+             f"# {'tensor':70s} ref_noise   hip_fp32   hip_fp64   ratio  norm_rel_err"]
+    for r in sorted(rows, key=lambda r: -(r["ratio"] or 0.0)):
+        ratio = "" if r["ratio"] is None else f"{r['ratio']:6.2f}"
+        lines.append(f"{r['k']:72s} {r['noise']:9.2e}  {r['e32']:9.2e}  {r['e64']:9.2e}  {ratio:>6s}  {r['nrm']:9.2e}")
+    text = "\n".join(lines)
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        open(os.path.join(out, f"grad_gate_{name}.txt"), "w").write(text + "\n")
+    except OSError:
+        pass
+    return text
+
+
+@pytest.mark.parametrize("name", ["train_tiny", "train_odd", "train_d512s", "train_cfg4"])
 def test_train_forward_backward_matches_reference(golden, name):
+    """Every parameter gradient of a train-mode forward + SeparationLoss + backward against the REFERENCE's own backward.
+    tiny / odd: whole tensors, straight gate.  d512s (d = 512, 2+2 layers, T = 251, 3 speakers): the reference's fp32
+    gradient is within 1e-5 of its fp64 gradient for 92 of 96 tensors -- all of the transformer / LayerNorm / attention /
+    weight-gradient paths -- and those keep the straight gate; the four conv / BatchNorm tensors of the visual front-end
+    (and the deep cfg4 model's tensors, 6+4 layers) are gated on their distance to the reference's fp64 gradient relative
+    to the reference's own fp32-vs-fp64 distance."""
     from av_separation.losses import SeparationLoss
     g = golden(name)
     c = g["config"]
@@ -48,40 +84,56 @@ def test_train_forward_backward_matches_reference(golden, name):
         assert maxabs(sp.reshape(-1)[::7], g["separated.slice"]) < MASK_TOL * scale
         assert abs(mk.astype(np.float64).sum() - float(g["masks.sum"])) < 1e-6 * mk.size
     loss = SeparationLoss(l1_weight=0.5)(sep, torch.from_numpy(g["targets"]).to(dev))
-    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5
     loss.backward()
-    worst, bad = 0.0, []
+    rows, bad = [], []
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         got = p.grad.detach().cpu().numpy()
         if "g." + k in g:
             ref = g["g." + k]
             scale = max(1e-3, float(np.abs(ref).max()))
-            err = maxabs(got, ref) / scale
-        else:
-            ref = g["g." + k + ".slice"]
-            scale = max(1e-3, float(np.abs(ref).max()))
-            step = int(g["g." + k + ".step"]) if "g." + k + ".step" in g else 5
-            err = maxabs(got.reshape(-1)[::step], ref) / scale
-            if "g64." + k + ".slice" in g:
-                # deep model: the reference's fp32 gradient is itself up to 1e-3 (a ReLU-kink tensor: 2.5e-2) away from
-                # its fp64 gradient, so gate on the distance to fp64, allowing 3x the reference's own fp32 distance
-                ref64 = g["g64." + k + ".slice"]
-                noise = maxabs(ref, ref64) / scale
-                err = max(0.0, maxabs(got.reshape(-1)[::step], ref64) / scale - 3.0 * noise)
-            nrm = g["g." + k + ".norm"]
-            assert abs(np.linalg.norm(got.astype(np.float64)) - nrm) < (1e-4 if "g64." + k + ".slice" not in g else 2e-2) * max(1e-3, nrm)
-        worst = max(worst, err)
-        if err >= GRAD_TOL:
-            bad.append((k, round(err, 4)))
-    assert not bad, bad                      # errors are relative to the largest gradient entry of each tensor
+            e32 = maxabs(got, ref) / scale
+            rows.append(dict(k=k, noise=0.0, e32=e32, e64=float("nan"), ratio=None, nrm=0.0))
+            if e32 >= GRAD_TOL:
+                bad.append((k, "fp32", round(e32, 6)))
+            continue
+        ref = g["g." + k + ".slice"]
+        scale = max(1e-3, float(np.abs(ref).max()))
+        step = int(g["g." + k + ".step"]) if "g." + k + ".step" in g else 5
+        mine = got.reshape(-1)[::step]
+        e32 = maxabs(mine, ref) / scale
+        nrm = g["g." + k + ".norm"]
+        nrm_err = abs(np.linalg.norm(got.astype(np.float64)) - nrm) / max(1e-3, nrm)
+        if "g64." + k + ".slice" not in g:                       # train_odd: sliced, shallow, no fp64 copy stored
+            rows.append(dict(k=k, noise=0.0, e32=e32, e64=float("nan"), ratio=None, nrm=nrm_err))
+            if e32 >= GRAD_TOL or nrm_err >= 1e-4:
+                bad.append((k, "fp32", round(e32, 6), round(nrm_err, 6)))
+            continue
+        ref64 = g["g64." + k + ".slice"]
+        noise = maxabs(ref, ref64) / scale
+        e64 = maxabs(mine, ref64) / scale
+        if noise < QUIET:                                        # the reference itself is exact here: straight gate
+            rows.append(dict(k=k, noise=noise, e32=e32, e64=e64, ratio=None, nrm=nrm_err))
+            if e32 >= GRAD_TOL or nrm_err >= 1e-4:
+                bad.append((k, "quiet", round(e32, 6), round(nrm_err, 6)))
+            continue
+        ratio = e64 / noise
+        rows.append(dict(k=k, noise=noise, e32=e32, e64=e64, ratio=ratio, nrm=nrm_err))
+        allow = RATIO * noise if k == KINK else min(RATIO * noise, ALLOW_CAP)
+        if e64 > max(allow, GRAD_TOL) or nrm_err >= (NORM_TOL if k != KINK else 2e-2):
+            bad.append((k, "noisy", round(e64, 6), round(noise, 6), round(ratio, 2), round(nrm_err, 6)))
+    report = _grad_report(name, rows)
+    assert not bad, f"{bad}\n{report}"        # errors are relative to the largest gradient entry of each tensor
     # BatchNorm buffers after one training forward (momentum 0.1, unbiased variance)
     sd = m.state_dict()
     for k in g:
         if k.startswith("buf."):
             got = sd[k[4:]].cpu().numpy()
             assert maxabs(got, g[k]) < 1e-5, k
-    print(f"{name}: worst relative gradient error {worst:.2e}")
+    noisy = [r for r in rows if r["ratio"] is not None]
+    print(f"{name}: worst fp32 distance over quiet tensors {max([r['e32'] for r in rows if r['ratio'] is None] or [0]):.2e}; "
+          f"{len(noisy)} noisy tensors, worst ratio {max([r['ratio'] for r in noisy] or [0]):.2f}")
 
 
 def test_training_step_reduces_loss_and_eval_sees_new_weights():

@@ -210,3 +210,47 @@ def test_interp_fn_backward_is_the_adjoint_of_f_interpolate(dev, B, N, T, d):
     yr.reshape(B * T, d).backward(dy)
     assert _rel(y.detach().cpu(), yr.detach().reshape(B * T, d)) < 2e-6
     assert _rel(xd.grad.cpu(), xr.grad) < 3e-6
+
+
+@pytest.mark.parametrize("R,N,K", [(4016, 512, 512), (4016, 1536, 512), (4016, 2048, 512), (4016, 512, 2048),
+                                   (4016, 512, 128), (1200, 64, 288), (37, 772, 1024)])
+def test_wgrad_bias_direct_against_float64(dev, R, N, K):
+    """dW = dY^T X and db = column sums of dY from ONE launch (avsep_op_wgrad_bias_direct: the bias gradient rides the
+    weight-gradient kernel) at the config-4 training shapes, against float64 -- the library's own tile / slice choice, and
+    through the developer build every combination of the 32- and 64-wide tile with an unsliced and a sliced row range
+    (the slices are summed in a fixed order: all variants of one tile width agree bit for bit with each other's sums only
+    up to the slice boundaries, so each is held to the float64 result)."""
+    import ctypes as C
+    import os
+    from av_separation import _native
+    g = torch.Generator(device="cpu").manual_seed(R + N + K)
+    dy = torch.randn(R, N, generator=g).to(dev)
+    x = torch.randn(R, K, generator=g).to(dev)
+    ref_w = (dy.double().T @ x.double())
+    ref_b = dy.double().sum(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(lib):
+        out = torch.full((N * K + N,), float("nan"), device=dev)
+        ns = lib.avsep_op_wgrad_bias_direct_scratch_floats(N, K, R)
+        scratch = torch.empty(max(ns, 1), device=dev)
+        rc = lib.avsep_op_wgrad_bias_direct(dy.data_ptr(), N, x.data_ptr(), K, out.data_ptr(), scratch.data_ptr() if ns else None,
+                                            N, K, R, st)
+        assert rc == 0, lib.avsep_last_error()
+        return out[:N * K].view(N, K), out[N * K:]
+
+    variants = {"product": run(_native.load())}
+    dev_lib = _native.load_dev()
+    try:
+        for tile in ("32", "64"):
+            for slices in ("1", "4"):
+                os.environ["AVSEP_WGRAD_TILE"], os.environ["AVSEP_WGRAD_SLICES"] = tile, slices
+                variants[f"tile{tile}/slices{slices}"] = run(dev_lib)
+    finally:
+        os.environ.pop("AVSEP_WGRAD_TILE", None)
+        os.environ.pop("AVSEP_WGRAD_SLICES", None)
+    tol = 3e-7 * math.sqrt(R)                              # fp32 accumulation over R rows, relative to the largest entry
+    for name, (gw, gb) in variants.items():
+        assert torch.isfinite(gw).all() and torch.isfinite(gb).all(), name
+        assert _rel(gw.double(), ref_w) < tol, (name, _rel(gw.double(), ref_w))
+        assert _rel(gb.double(), ref_b) < tol, (name, _rel(gb.double(), ref_b))
