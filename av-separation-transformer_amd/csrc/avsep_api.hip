@@ -75,8 +75,8 @@ struct GraphEntry {
   const void *mixed, *lips, *masks, *sep, *ws;
   size_t ws_bytes;
   int B, T, N, H, W;
-  hipGraphExec_t exec[2];    // two executables of the same captured graph, replayed alternately (see avsep_forward_graph)
-  int nexec, turn;
+  hipGraphExec_t exec;       // ONE executable, re-launched every step: alternating two executables of the same graph was
+                             // measured 25 % SLOWER with two steps in flight (profiles/r03_graph_exec_alternation.txt)
   hipStream_t last_stream;   // where the graph was launched last (drained before the exec is destroyed)
   // Every graph is captured on its OWN pair of streams.  Two graphs captured one after the other on the same pair do
   // not overlap when replayed on different caller streams (measured: 2 steps in flight 0.467 ms/step with shared
@@ -909,7 +909,7 @@ void avsep_destroy(avsep_ctx* c) {
   for (auto& g : c->graphs) (void)hipStreamSynchronize(g.last_stream);
   (void)hipDeviceSynchronize();   // eager forwards ran on caller streams this context keeps no record of
   for (auto& g : c->graphs) {
-    for (int i = 0; i < g.nexec; ++i) (void)hipGraphExecDestroy(g.exec[i]);
+    (void)hipGraphExecDestroy(g.exec);
     (void)hipStreamDestroy(g.cap);
     (void)hipStreamDestroy(g.side);
   }
@@ -1117,7 +1117,7 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
   if (!hit) {
     // capture on streams of this graph's own (the caller's may be the legacy stream, which cannot capture; and see
     // GraphEntry for why not the context's)
-    GraphEntry g{mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, {nullptr, nullptr}, 0, 0, s, nullptr, nullptr};
+    GraphEntry g{mixed, lips, masks, sep, ws, ws_bytes, B, T, N, H, W, nullptr, s, nullptr, nullptr};
     HCK(hipStreamCreateWithFlags(&g.cap, hipStreamNonBlocking));
     hipError_t e = hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipStreamDestroy(g.cap); return fail_hip(e, "hipStreamCreate(capture side stream)"); }
@@ -1132,25 +1132,15 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
     e = hipStreamEndCapture(g.cap, &graph);
     if (r != AVSEP_OK) { if (graph) (void)hipGraphDestroy(graph); drop_streams(); return r; }
     if (e != hipSuccess) { drop_streams(); return fail_hip(e, "hipStreamEndCapture"); }
-    // Two executables per graph, replayed in turn: a back-to-back replay of ONE executable on one stream leaves the device
-    // idle between the steps (profiles/r03_graph_exec_alternation.txt), two alternating ones queue ahead of each other.
-    const int want = dev_env("AVSEP_GRAPH_EXECS") ? (atoi(dev_env("AVSEP_GRAPH_EXECS")) >= 2 ? 2 : 1) : 2;
-    for (g.nexec = 0; g.nexec < want; ++g.nexec) {
-      e = hipGraphInstantiate(&g.exec[g.nexec], graph, nullptr, nullptr, 0);
-      if (e != hipSuccess) break;
-    }
+    e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) {
-      for (int i = 0; i < g.nexec; ++i) (void)hipGraphExecDestroy(g.exec[i]);
-      drop_streams();
-      return fail_hip(e, "hipGraphInstantiate");
-    }
+    if (e != hipSuccess) { drop_streams(); return fail_hip(e, "hipGraphInstantiate"); }
     if (c->graphs.size() >= 8) {
       // the evicted graph may still be replaying on the stream it was last launched on (not necessarily this
       // caller's): let it drain there before its nodes are freed
       GraphEntry& old = c->graphs.front();
       (void)hipStreamSynchronize(old.last_stream);
-      for (int i = 0; i < old.nexec; ++i) (void)hipGraphExecDestroy(old.exec[i]);
+      (void)hipGraphExecDestroy(old.exec);
       (void)hipStreamDestroy(old.cap);
       (void)hipStreamDestroy(old.side);
       c->graphs.erase(c->graphs.begin());
@@ -1160,8 +1150,7 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
   }
   // Replay on the caller's own stream: no event fences between consecutive steps (the fenced hand-off to the
   // capture stream left a ~40-60 us bubble per step).  Only capture needs a non-legacy stream, launch does not.
-  HCK(hipGraphLaunch(hit->exec[hit->turn], s));
-  hit->turn = (hit->turn + 1) % hit->nexec;
+  HCK(hipGraphLaunch(hit->exec, s));
   hit->last_stream = s;
   return AVSEP_OK;
 } catch (...) {

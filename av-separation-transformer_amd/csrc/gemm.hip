@@ -558,6 +558,108 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LDS-DMA form of the plain GEMM (global_load_lds_dwordx4: memory -> LDS with no register in between).
+// gemm_kernel stages A / W through a register ring (128x64x32: 48 of its 148 VGPRs) and pays one ds_write_b128 per
+// float4; here every wave issues (BM + BN) / (4 * RPI) DMA instructions per chunk, each of which moves RPI = 64 / SLOTS
+// whole tile rows (1 KB) straight into the other LDS buffer while the MFMAs of the current chunk run.
+//   * the DMA writes lane l at (wave-uniform base) + 16 l bytes, i.e. LINEARLY: row = l / SLOTS, physical 16-byte slot
+//     = l % SLOTS.  The LDS image keeps gemm_kernel's XOR swizzle (fragment reads unchanged, conflict-free) by swizzling
+//     the SOURCE instead: the lane that fills physical slot p of row r fetches logical slot p ^ swz(r) of that row.
+//   * one chunk ahead, two LDS buffers: issue chunk k+1 -> MFMAs of chunk k -> s_waitcnt vmcnt(0) -> barrier.  The barrier
+//     that ended iteration k-1 is what makes buffer (k+1)&1 free to overwrite.
+//   * same fragment order, same MFMA order, same epilogue as gemm_kernel: bit-identical results.
+// PLAIN A operand only (the conv modes zero out-of-range taps on the way to LDS, which a DMA cannot).
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256, (BM + BN) * BK * 8 <= 40 * 1024 ? 4 : 3) void gemm_dma_kernel(const GemmParams pin) {
+  GemmParams p = pin;
+  constexpr int SLOTS = BK / 4;
+  constexpr int RPI = 64 / SLOTS;                  // tile rows per DMA instruction (one wave, 64 lanes x 16 B)
+  constexpr int GA = BM / RPI, GB = BN / RPI;      // DMA instructions per chunk for A / for W
+  constexpr int JA = GA / 4, JB = GB / 4;          // ... per wave
+  constexpr int WBM = BM / 32, WBN = BN / 32;
+  static_assert(GA % 4 == 0 && GB % 4 == 0, "row groups must divide over the four waves");
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + BN - 1) / BN;
+  int tile = xcd_tile(p);
+  select_pair(p, tile);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const int r8 = lane / SLOTS, pslot = lane % SLOTS;
+  const float* a_src[JA];
+  const float* b_src[JB];
+#pragma unroll
+  for (int j = 0; j < JA; ++j) {
+    const int row = RPI * (wave + 4 * j) + r8;
+    const int m = min(m0 + row, p.M - 1);
+    a_src[j] = p.A + (size_t)m * p.lda + 4 * (pslot ^ swz<SLOTS>(row));
+  }
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const int row = RPI * (wave + 4 * j) + r8;
+    const int n = min(n0 + row, p.N - 1);
+    b_src[j] = p.W + (size_t)n * p.ldw + 4 * (pslot ^ swz<SLOTS>(row));
+  }
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue = [&](int kc, int buf) {
+#pragma unroll
+    for (int j = 0; j < JA; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + (size_t)kc * BK),
+                                       (lptr_t)(As + buf * BM * BK + RPI * (wave + 4 * j) * BK), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[j] + (size_t)kc * BK),
+                                       (lptr_t)(Bs + buf * BN * BK + RPI * (wave + 4 * j) * BK), 16, 0, 0);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    const int r = wm * (BM / 2) + 16 * i + fr;
+    a_off[i] = r * BK;
+    a_swz[i] = swz<SLOTS>(r);
+  }
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int r = wn * (BN / 2) + 16 * j + fr;
+    b_off[j] = r * BK;
+    b_swz[j] = swz<SLOTS>(r);
+  }
+  f32x4 acc[WBM][WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);            // block-uniform
+    mfma_chunk<BK, WBM, WBN>(As + (kc & 1) * BM * BK, Bs + (kc & 1) * BN * BK, a_off, a_swz, b_off, b_swz, fq, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+}
+
+template <int BM, int BN, int BK>
+hipError_t launch_dma_t(GemmParams p, hipStream_t s) {
+  const int nbn = (p.N + BN - 1) / BN;
+  p.g_tiles0 = p.alt.M > 0 ? ((p.M + BM - 1) / BM) * nbn : 0;
+  const long rt = (long)(p.M + BM - 1) / BM + (p.alt.M > 0 ? (long)(p.alt.M + BM - 1) / BM : 0);
+  hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, BK>), dim3((unsigned)(rt * nbn)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient without transposes:  dW[n][k] = sum_r dY[r][n] * X[r][k]  (nn.Linear / conv-as-GEMM backward).
 // Both operands are "k-major" for this contraction (the contracted index r is the slow one), so a tile's chunk of
 // 32 r-rows is fetched as float4s ALONG m / n (coalesced rows of dY and X as they sit in memory) and scattered into
@@ -1703,6 +1805,11 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
     } else if (t.bm == 64 && t.bn == 64 && t.bk == 32) {
       if (try_launch_persist<64, 64, 32, false>(p, s, &pe)) return pe;
     }
+  }
+  if (dev_env("AVSEP_GEMM_DMA") && p.amode == AMODE_PLAIN && p.ksplit <= 1) {       // LDS-DMA staging (A/B measurement)
+    if (t.bm == 128 && t.bn == 64 && t.bk == 32) return launch_dma_t<128, 64, 32>(p, s);
+    if (t.bm == 128 && t.bn == 64 && t.bk == 16) return launch_dma_t<128, 64, 16>(p, s);
+    if (t.bm == 64 && t.bn == 64 && t.bk == 32) return launch_dma_t<64, 64, 32>(p, s);
   }
   if (t.bm == 128 && t.bn == 64 && t.bk == 16 && p.amode == AMODE_PLAIN)   // four workgroups per CU, measured equal
     return launch_t<128, 64, 16, AMODE_PLAIN, false, 2>(p, s);

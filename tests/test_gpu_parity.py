@@ -308,11 +308,15 @@ def test_op_linear_tiles_bit_identical(lib, devlib, dev):
     b, r = t(seeded.tensor(7, "b", (N,), -1, 1), dev), t(seeded.tensor(7, "r", (M, N), -1, 1), dev)
     outs = {}
     try:
-        for tile in ("32x32x32", "32x32x64", "64x32x64", "64x64x32", "64x64x32/ring4", "128x64x32", "128x64x16", "128x128x32", "256x128x32"):
+        for tile in ("32x32x32", "32x32x64", "64x32x64", "64x64x32", "64x64x32/ring4", "128x64x32", "128x64x16", "128x128x32", "256x128x32",
+                     "128x64x32/dma", "128x64x16/dma", "64x64x32/dma"):
             os.environ["AVSEP_GEMM_TILE"] = tile.split("/")[0]
             os.environ.pop("AVSEP_6464_RING4", None)
+            os.environ.pop("AVSEP_GEMM_DMA", None)
             if tile.endswith("/ring4"):       # the deeper register ring the 64x64 tile used before (3 workgroups per CU)
                 os.environ["AVSEP_6464_RING4"] = "1"
+            if tile.endswith("/dma"):         # LDS-DMA staging (global_load_lds) instead of the register ring
+                os.environ["AVSEP_GEMM_DMA"] = "1"
             y = torch.full((M, N), float("nan"), device=dev)
             check(devlib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), M, N, K, 2,
                                          _stream()))
@@ -324,6 +328,7 @@ def test_op_linear_tiles_bit_identical(lib, devlib, dev):
     finally:
         os.environ.pop("AVSEP_GEMM_TILE", None)
         os.environ.pop("AVSEP_6464_RING4", None)
+        os.environ.pop("AVSEP_GEMM_DMA", None)
     ref = outs.pop("32x32x32")
     assert torch.isfinite(ref).all()
     for tile, y in outs.items():
