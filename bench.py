@@ -455,7 +455,7 @@ def main():
     roofline["library_build_id"] = build_id
     try:
         pmc_file = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
-        hit = pmc_file["kernels"].get(dom["name"])
+        hit = (pmc_file.get("workloads", {}).get(a.workload) or (pmc_file["kernels"] if a.workload == "cfg2" else {})).get(dom["name"])
         if pmc_file.get("build_id") != build_id:
             roofline["traffic_note"] = (f"profiles/pmc_hbm_traffic.json was measured on build {pmc_file.get('build_id')}, "
                                         f"the loaded library is {build_id}: traffic withheld (re-run tools/pmc_bench.sh)")

@@ -1,10 +1,12 @@
 #!/bin/bash
 # Developer tool (GPU box): HBM-side traffic per kernel of the bench forward (separate PMC passes, no tracing).
+#   tools/pmc_bench.sh [workload [steps warmup]]     default cfg2 20 5; other workloads are merged into the same JSON
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
+WL=${1:-cfg2}; STEPS=${2:-20}; WARM=${3:-5}; export WL STEPS WARM
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT; rm -rf $OUT/fetch $OUT/write $OUT/l2
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --workload $WL --steps $STEPS --warmup $WARM --rounds 1 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --workload $WL --steps $STEPS --warmup $WARM --rounds 1 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 $R/bench.py --workload $WL --steps $STEPS --warmup $WARM --rounds 1 --no-cpu --no-profile --no-graph --inflight 1 > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, collections, os
 R=os.environ["GRAFT_REPO_ROOT"]; OUT=R+"/gpurun_out/pmc_bench"
@@ -17,7 +19,7 @@ for tag in ("fetch","write","l2"):
         n=n.replace("void (anonymous namespace)::","").replace("(anonymous namespace)::","").split("(")[0]
         tot[n][r["Counter_Name"]]+=float(r["Counter_Value"])
         if tag=="fetch": calls[n]+=1
-fw=25.0
+fw=float(os.environ["STEPS"])+float(os.environ["WARM"])   # forwards traced: warm-up + ONE round of steps
 print(f"{'kernel':34s} {'calls/fwd':>9s} {'fetch MB/fwd (x2 corr)':>22s} {'write MB/fwd':>12s} {'L2 hit%':>8s}")
 TF=TW=0
 for n,c in sorted(tot.items(), key=lambda kv: -kv[1].get("FETCH_SIZE",0)):
@@ -33,5 +35,13 @@ js={n:{"calls_per_forward":calls[n]/fw,
        "l2_hit_rate":c.get("TCC_HIT_sum",0)/max(1,c.get("TCC_HIT_sum",0)+c.get("TCC_MISS_sum",0))} for n,c in tot.items()}
 import subprocess, sys
 bid=subprocess.run([sys.executable,"-c","import sys;sys.path.insert(0,'%s/av-separation-transformer_amd');from av_separation import _native;print(_native.load().avsep_build_id().decode())"%R],capture_output=True,text=True).stdout.strip()
-json.dump({"build_id":bid,"note":"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes over `bench.py --no-graph`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream)","kernels":js}, open(OUT+"/pmc_hbm_traffic.json","w"), indent=1)
+path=OUT+"/pmc_hbm_traffic.json"
+doc={"build_id":bid,"note":"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes over `bench.py --no-graph`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream); per-launch figures are averages over all launches of the instance in one forward of the workload","kernels":{},"workloads":{}}
+if os.path.exists(path):
+    old=json.load(open(path))
+    if old.get("build_id")==bid: doc["kernels"]=old.get("kernels",{}); doc["workloads"]=old.get("workloads",{})
+wl=os.environ["WL"]
+doc["workloads"][wl]=js
+if wl=="cfg2": doc["kernels"]=js          # the headline workload stays where round 1/2 readers look for it
+json.dump(doc, open(path,"w"), indent=1)
 PY
