@@ -360,7 +360,7 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
   return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm(p, s); });
 }
 int run_layernorm(avsep_ctx* c, const float* x, const float* g, const float* b, float* y, int M, int d, hipStream_t s) {
-  return profiled(c, "layernorm_kernel", 8.0 * M * d, 2.0 * M * d * 4, s,
+  return profiled(c, layernorm_instance_name(d, false), 8.0 * M * d, 2.0 * M * d * 4, s,
                   [&] { return launch_layernorm(x, g, b, y, M, d, 1e-5f, s); });
 }
 int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
@@ -398,7 +398,7 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
   // stays available (avsep_op_ln_linear form 2, bit-identical) behind this developer switch.
   static const bool staged = dev_env("AVSEP_LN_STAGED") != nullptr;
   if (staged && gemm_ln_staged_supported(d)) {
-    RCK(profiled(c, "layernorm_kernel", 6.0 * M * d, 1.0 * M * d * 4 + 8.0 * M, s,
+    RCK(profiled(c, layernorm_instance_name(d, true), 6.0 * M * d, 1.0 * M * d * 4 + 8.0 * M, s,
                  [&] { return launch_layernorm_stats(x, ln_buf, M, d, 1e-5f, s); }));
     p.ln_gamma = g; p.ln_beta = be; p.ln_eps = 1e-5f; p.ln_stats = ln_buf;
     return run_gemm(c, p, s);
@@ -569,7 +569,7 @@ int visual_front(avsep_ctx* c, const Workspace& w, const float* lips, int B, int
   if (fused) {
     const double fl = 2.0 * Mv * ((double)H1 * W1 * 32 * 9 + (double)H2 * W2 * 64 * 288 + (double)H3 * W3 * 128 * 576);
     hipError_t e = hipSuccess;
-    int r = profiled(c, "conv_stack_kernel", fl, 4.0 * Mv * ((double)H * W + 128), s, [&] {
+    int r = profiled(c, conv_stack_instance_name(Mv, H, W), fl, 4.0 * Mv * ((double)H * W + 128), s, [&] {
       e = launch_conv_stack(lips, c->c1_w, c->c1_b, c->c2_w, c->c2_b, c->c3_w, c->c3_b, w.pool, Mv, H, W, s);
       return e == hipErrorNotSupported ? hipSuccess : e;
     });

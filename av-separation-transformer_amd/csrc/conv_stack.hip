@@ -379,6 +379,33 @@ hipError_t launch_cs(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) 
 
 }  // namespace
 
+// The instance launch_conv_stack() picks, spelled as rocprofv3 prints it ("conv_stack_kernel" when the frame does not fit).
+const char* conv_stack_instance_name(int Mv, int H, int W) {
+  static thread_local char buf[48];
+  const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2), W3 = conv_out(W2);
+  const int P2 = H2 * W2, P3 = H3 * W3;
+  const size_t frame_bytes = (size_t)((2 * H2 + 1) * (2 * W2 + 1) * C1P + (2 * H3 + 1) * (2 * W3 + 1) * C2P + H * W) * sizeof(float);
+  const bool four = dev_env("AVSEP_CONV_NW4") != nullptr;
+  const size_t raw_cap = (size_t)5 * (four ? 256 : 512), LDS_MAX = 160 * 1024;
+  const int r2g2 = (2 * P2 + 15) / 16, r3g2 = (2 * P3 + 15) / 16, r2 = (P2 + 15) / 16, r3 = (P3 + 15) / 16;
+  int g = 0, a = 0, b = 0;
+  if (!dev_env("AVSEP_CONV_G1") && 2 * frame_bytes <= LDS_MAX && Mv > 1 && (size_t)2 * H * W <= raw_cap) {
+    if (r2g2 <= 1 && r3g2 <= 1) { g = 2; a = 1; b = 1; }
+    else if (r2g2 <= 2 && r3g2 <= 1) { g = 2; a = 2; b = 1; }
+    else if (r2g2 <= 4 && r3g2 <= 1) { g = 2; a = 4; b = 1; }
+    else if (r2g2 <= 8 && r3g2 <= 2) { g = 2; a = 8; b = 2; }
+  }
+  if (!g && frame_bytes <= LDS_MAX && (size_t)H * W <= raw_cap) {
+    if (r2 <= 1 && r3 <= 1) { g = 1; a = 1; b = 1; }
+    else if (r2 <= 4 && r3 <= 1) { g = 1; a = 4; b = 1; }
+    else if (r2 <= 9 && r3 <= 3) { g = 1; a = 9; b = 3; }
+    else if (r2 <= 12 && r3 <= 4) { g = 1; a = 12; b = 4; }
+  }
+  if (!g) return "conv_stack_kernel";
+  snprintf(buf, sizeof buf, "conv_stack_kernel<%d, %d, %d, %d>", g, a, b, four ? 4 : 8);
+  return buf;
+}
+
 // Returns hipErrorNotSupported when the frame size does not fit the fused kernel's LDS / register tiling
 // (the caller then takes the unfused conv1 + implicit-GEMM path).
 hipError_t launch_conv_stack(const float* frames, const float* w1, const float* b1, const float* w2,

@@ -169,6 +169,11 @@ hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, i
 // w = np.hanning(n_fft) (symmetric); evaluated in double precision, rounded once
 hipError_t launch_stft_basis(float* basis, int n_fft, hipStream_t s);
 
+// instance names as rocprofv3 prints them (namespace prefix and argument list stripped): the live profiler's table joins
+// profiles/*_kernel_stats.csv and profiles/pmc_hbm_traffic.json by string equality
+const char* layernorm_instance_name(int d, bool stats_only);
+const char* conv_stack_instance_name(int Mv, int H, int W);
+
 hipError_t launch_delay(unsigned us, hipStream_t s);
 hipError_t launch_stamp(unsigned long long* buf, int idx, hipStream_t s);   // profiling aid, see rowops.hip
 

@@ -2,6 +2,7 @@
 // the one-off weight packers.  None of these has arithmetic intensity worth the matrix cores; they are
 // written for coalesced 16-byte accesses along the contiguous axis and 64-lane wavefront reductions.
 #include "kernels.h"
+#include <cstdio>
 
 namespace {
 
@@ -236,6 +237,13 @@ hipError_t launch_layernorm(const float* x, const float* g, const float* b, floa
   else if (vec <= 4) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, g, b, y, M, d, eps);
   else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, g, b, y, M, d, eps);
   return hipGetLastError();
+}
+
+const char* layernorm_instance_name(int d, bool stats_only) {
+  static thread_local char buf[48];
+  const int vec = (d + 255) / 256;
+  snprintf(buf, sizeof buf, "layernorm_kernel<%d, %s>", vec <= 1 ? 1 : vec <= 2 ? 2 : vec <= 4 ? 4 : 8, stats_only ? "true" : "false");
+  return buf;
 }
 
 hipError_t launch_layernorm_stats(const float* x, float* stats, int M, int d, float eps, hipStream_t s) {

@@ -466,6 +466,21 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # the same instances INSIDE the replayed graph (other kernels beside them on the chip): from the committed rocprofv3
+    # kernel statistics of the timed region (tools/graph_stats.py -> profiles/graph_kernel_stats.json), same build only
+    in_graph = {}
+    try:
+        gs = json.load(open(os.path.join(ROOT, "profiles", "graph_kernel_stats.json")))
+        if gs.get("build_id") == build_id:
+            in_graph = gs.get("workloads", {}).get(a.workload, {})
+    except (OSError, ValueError):
+        pass
+    if in_graph.get(dom["name"]):
+        # (no fraction is derived from it: inside the graph the tail runs as two half-batch launches per kernel, so an
+        # instance's launches there are not the launches the profile leg priced)
+        roofline["in_graph_avg_launch_us"] = round(in_graph[dom["name"]]["avg_us"], 3)
+        roofline["in_graph_launches_per_step"] = round(in_graph[dom["name"]]["calls_per_step"], 2)
+
     out = {
         "metric": "separated clips/sec (2-spk, 1s@8kHz, d=256) forward, fp32" +
                   (f", throughput with {R} steps in flight" if R > 1 else ""),
@@ -487,8 +502,13 @@ def main():
                    "ms_per_step_max": round(max(worst) / a.steps * 1e3, 4),
                    "ms_per_step_rounds": [round(w / a.steps * 1e3, 4) for w in worst]},
         "roofline": roofline,
+        # avg_us / tflops / gbs: each instance ALONE on the chip (HIP events, one stream); in_graph_*: the same instance inside
+        # the replayed step (rocprofv3 of the timed region), where the two branches' kernels share the CUs
         "kernels": [{"name": k["name"], "calls_per_step": k["calls"] / prof_iters, "avg_us": round(k["avg_us"], 2),
-                     "tflops": round(k["tflops"], 2), "gbs": round(k["gbs"], 1)} for k in kernels],
+                     "tflops": round(k["tflops"], 2), "gbs": round(k["gbs"], 1),
+                     "in_graph_avg_us": round(in_graph[k["name"]]["avg_us"], 2) if k["name"] in in_graph else None,
+                     "in_graph_calls_per_step": round(in_graph[k["name"]]["calls_per_step"], 2) if k["name"] in in_graph else None}
+                    for k in kernels],
     }
 
     if dist is not None:
