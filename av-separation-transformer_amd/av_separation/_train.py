@@ -65,11 +65,16 @@ def _scratch(M, Cc, like):
     return torch.empty(max(n, 1), device=like.device, dtype=torch.float32)
 
 
-def _gemm(x, w, bias, res, rperiod, act):
-    """act(x [M,K] @ w[N,K]^T + bias) (+ res rows); K % 32 == 0."""
+def _gemm(x, w, bias, res, rperiod, act, drop_p=0.0, drop_seed=0):
+    """res rows + dropout(act(x [M,K] @ w[N,K]^T + bias)); K % 32 == 0; the dropout (train mode) runs in the GEMM epilogue."""
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    if drop_p > 0:
+        _ck(_lib().avsep_op_linear_drop(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                        res.data_ptr() if res is not None else None, N, rperiod, y.data_ptr(), M, N, K,
+                                        act, drop_p, drop_seed, _st(x)), "avsep_op_linear_drop")
+        return y
     _ck(_lib().avsep_op_linear_ex(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                                   res.data_ptr() if res is not None else None, N, rperiod, y.data_ptr(), N, M, N, K,
                                   act, _st(x)), "avsep_op_linear_ex")
@@ -300,14 +305,17 @@ def _wgrad_bias_direct(dy, x):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = act(x w^T + b) + res;  act in {none, relu}; res: same-shape residual (grad flows) or constant rows with
-    period `rperiod` (positional encoding, no grad)."""
+    """y = dropout(act(x w^T + b)) + res;  act in {none, relu}; res: same-shape residual (grad flows) or constant rows
+    with period `rperiod` (positional encoding, no grad); dropout (drop_p > 0, train mode) sits between the activation
+    and the residual add, which is where dropout1 / dropout2 / the FFN's inner dropout of a transformer block are, and
+    runs in the GEMM's epilogue with the stateless mask the separate dropout kernels use (same values bit for bit)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, res, rperiod):
+    def forward(ctx, x, w, b, act, res, rperiod, drop_p=0.0, drop_seed=0):
         assert not (act == ACT_RELU and res is not None), "the ReLU mask needs the pre-residual output"
         x, w = _c(x), _c(w)
-        y = _gemm(x, w, b, res, rperiod, act)
+        y = _gemm(x, w, b, res, rperiod, act, drop_p, drop_seed)
+        ctx.drop = (float(drop_p), int(drop_seed))
         ctx.act, ctx.res_grad = act, (res is not None and rperiod <= 0)
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
         ctx.has_b = b is not None
@@ -323,9 +331,17 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = w.shape[0]
         lib = _lib()
-        if ctx.act == ACT_RELU:
+        drop_p, drop_seed = ctx.drop
+        if ctx.act == ACT_RELU and drop_p > 0:       # y = dropout(relu(z)): y > 0 <=> kept and z > 0 -- one launch for both
+            dpre = torch.empty_like(dy)
+            _ck(lib.avsep_op_relu_dropout_bwd(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dy.numel(), drop_p, _st(dy)),
+                "relu_dropout_bwd")
+        elif ctx.act == ACT_RELU:
             dpre = torch.empty_like(dy)
             _ck(lib.avsep_op_act_bwd(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dy.numel(), ACT_RELU, _st(dy)), "act_bwd")
+        elif drop_p > 0:                             # the same mask on the gradient (regenerated from the seed)
+            dpre = torch.empty_like(dy)
+            _ck(lib.avsep_op_dropout(dy.data_ptr(), dpre.data_ptr(), dy.numel(), drop_p, drop_seed, _st(dy)), "dropout(bwd)")
         else:
             dpre = dy
         dx = dw = db = None
@@ -368,7 +384,7 @@ class LinearFn(torch.autograd.Function):
                     tns.record_stream(main)
             _join_at_end_of_backward(st, main)
         dres = dy if (ctx.res_grad and ctx.needs_input_grad[4]) else None
-        return dx, dw, db, None, dres, None
+        return dx, dw, db, None, dres, None, None, None
 
 
 class ActFn(torch.autograd.Function):
@@ -413,6 +429,41 @@ class LayerNormFn(torch.autograd.Function):
         s = _scratch(M, d, x)
         _ck(_lib().avsep_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr(), dx.data_ptr(), dg.data_ptr(),
                                           db.data_ptr(), xh.data_ptr(), s.data_ptr(), M, d, ctx.eps, _st(x)), "layernorm_bwd")
+        return dx, dg, db, None
+
+
+class ResidualNormFn(torch.autograd.Function):
+    """(x, LayerNorm(x)) for a pre-norm block: x goes on along the residual path, the normalised rows into the branch.
+    With x handed through this ONE node, the two gradients that reach x -- along the residual path and through the
+    LayerNorm -- are summed inside the LayerNorm backward kernel instead of by a separate elementwise add launch that
+    autograd would insert for a tensor with two consumers (32 of them per step of the 6+4-layer model)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = _c(x)
+        M, d = x.shape
+        y = torch.empty_like(x)
+        _ck(_lib().avsep_op_layernorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), M, d, eps, _st(x)), "layernorm")
+        ctx.eps = eps
+        ctx.save_for_backward(x, g)
+        ctx.set_materialize_grads(False)          # an unused output must not cost a zero fill
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, g = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dy = _c(dy)
+        dres = _c(dres) if dres is not None else None
+        M, d = x.shape
+        dx, xh = torch.empty_like(x), torch.empty_like(x)
+        dg, db = torch.empty_like(g), torch.empty_like(g)
+        s = _scratch(M, d, x)
+        _ck(_lib().avsep_op_layernorm_bwd_res(dy.data_ptr(), x.data_ptr(), g.data_ptr(),
+                                              dres.data_ptr() if dres is not None else None, dx.data_ptr(), dg.data_ptr(),
+                                              db.data_ptr(), xh.data_ptr(), s.data_ptr(), M, d, ctx.eps, _st(x)),
+            "layernorm_bwd_res")
         return dx, dg, db, None
 
 
@@ -795,11 +846,24 @@ def make_drop(module, probs, seed=None, group=None):
 
 
 FUSED_DROPOUT_ADD = os.environ.get("AVSEP_TRAIN_NO_DROPOUT_ADD") is None    # developer A/B switch (same values either way)
+# dropout inside the GEMM epilogue (round 3) and the residual gradient inside the LayerNorm backward: module switches so
+# that tests can compare with the launch-per-op forms (same values bit for bit either way)
+EPILOGUE_DROPOUT = True
+FUSED_RESIDUAL_NORM = True
+
+
+def _norm_branch(x, g, b):
+    """-> (x for the residual path, LayerNorm(x) for the branch)"""
+    if FUSED_RESIDUAL_NORM:
+        return ResidualNormFn.apply(x, g, b, 1e-5)
+    return x, LayerNormFn.apply(x, g, b, 1e-5)
 
 
 def _residual_linear(x_res, inp, w, b, p, drop):
-    """x_res + dropout(inp w^T + b): the residual rides the GEMM epilogue unless dropout sits in between."""
+    """x_res + dropout(inp w^T + b): residual AND dropout ride the GEMM epilogue."""
     if drop.p(p) > 0:
+        if EPILOGUE_DROPOUT:
+            return LinearFn.apply(inp, w, b, ACT_NONE, x_res, 0, drop.p(p), drop.seed())
         if FUSED_DROPOUT_ADD:
             return DropoutAddFn.apply(LinearFn.apply(inp, w, b, ACT_NONE, None, 0), x_res, drop.p(p), drop.seed())
         return AddFn.apply(x_res, drop(LinearFn.apply(inp, w, b, ACT_NONE, None, 0), p))
@@ -812,12 +876,15 @@ def _encoder_layer(x, P, pre, B, L, h, p, drop):
     d = x.shape[1]
     dh = d // h
     pa = drop.p(p)
-    n = LayerNormFn.apply(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], 1e-5)
+    x, n = _norm_branch(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"])
     qkv = LinearFn.apply(n, P[pre + "self_attn.in_proj_weight"], P[pre + "self_attn.in_proj_bias"], ACT_NONE, None, 0)
     o = AttentionFn.apply(qkv, qkv, 0, d, 2 * d, B, h, dh, L, L, 1.0 / math.sqrt(dh), pa, drop.seed() if pa > 0 else 0)
     x = _residual_linear(x, o, P[pre + "self_attn.out_proj.weight"], P[pre + "self_attn.out_proj.bias"], p, drop)
-    n = LayerNormFn.apply(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], 1e-5)
-    f = drop(LinearFn.apply(n, P[pre + "linear1.weight"], P[pre + "linear1.bias"], ACT_RELU, None, 0), p)
+    x, n = _norm_branch(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"])
+    if EPILOGUE_DROPOUT and drop.p(p) > 0:        # relu and the FFN's inner dropout in linear1's epilogue
+        f = LinearFn.apply(n, P[pre + "linear1.weight"], P[pre + "linear1.bias"], ACT_RELU, None, 0, drop.p(p), drop.seed())
+    else:
+        f = drop(LinearFn.apply(n, P[pre + "linear1.weight"], P[pre + "linear1.bias"], ACT_RELU, None, 0), p)
     return _residual_linear(x, f, P[pre + "linear2.weight"], P[pre + "linear2.bias"], p, drop)
 
 
@@ -896,12 +963,12 @@ def fusion_stage(P, pre, a, v, B, T, d, h, p, drop):
     while f"{pre}layers.{i}.norm1.weight" in P:
         q_ = f"{pre}layers.{i}."
         win, bin_ = P[q_ + "cross_attn.in_proj_weight"], P[q_ + "cross_attn.in_proj_bias"]
-        n = LayerNormFn.apply(a, P[q_ + "norm1.weight"], P[q_ + "norm1.bias"], 1e-5)
+        a, n = _norm_branch(a, P[q_ + "norm1.weight"], P[q_ + "norm1.bias"])
         q = LinearFn.apply(n, win[:d], bin_[:d], ACT_NONE, None, 0)
         kv = LinearFn.apply(v, win[d:], bin_[d:], ACT_NONE, None, 0)
         o = AttentionFn.apply(q, kv, 0, 0, d, B, h, dh, T, T, 1.0 / math.sqrt(dh), pa, drop.seed() if pa > 0 else 0)
         a = _residual_linear(a, o, P[q_ + "cross_attn.out_proj.weight"], P[q_ + "cross_attn.out_proj.bias"], p, drop)
-        n = LayerNormFn.apply(a, P[q_ + "norm2.weight"], P[q_ + "norm2.bias"], 1e-5)
+        a, n = _norm_branch(a, P[q_ + "norm2.weight"], P[q_ + "norm2.bias"])
         f = drop(ActFn.apply(LinearFn.apply(n, P[q_ + "ff.0.weight"], P[q_ + "ff.0.bias"], ACT_NONE, None, 0), ACT_GELU), p)
         a = _residual_linear(a, f, P[q_ + "ff.3.weight"], P[q_ + "ff.3.bias"], p, drop)
         i += 1

@@ -91,6 +91,14 @@ __device__ __attribute__((noinline)) f32x4 act4_outofline(f32x4 v) {
   return v;
 }
 
+// Training-only epilogue step (GemmParams::drop_p), out of line for the same reason: the 64-bit hash of the mask must not
+// cost the inference instances registers.
+__device__ __attribute__((noinline)) f32x4 drop4_outofline(f32x4 v, unsigned long long seed, unsigned long long e0, float p) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = dropout_keep(seed, e0 + e, p) ? v[e] / (1.0f - p) : 0.0f;
+  return v;
+}
+
 // Straight-line epilogue for N % 4 == 0 (see the note on gemm_epilogue): every load of the tile is UNCONDITIONAL
 // (out-of-range rows / columns are clamped to the tile's last valid row / float4, a missing bias or residual reads the
 // same addresses of whatever pointer is valid and is discarded by a select), then the arithmetic, then the stores.
@@ -147,6 +155,8 @@ __device__ __forceinline__ void epilogue_finish(const GemmParams& p, const f32x4
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = act_t<ACT>(x[e]);
       }
+      if (p.drop_p > 0.0f)                          // block-uniform; training only (see GemmParams::drop_p)
+        x = drop4_outofline(x, p.drop_seed, (unsigned long long)(mbase + 16 * i + fr) * p.N + (nbase + 16 * j + 4 * fq), p.drop_p);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o.rv[i][j][e] = HAS_R ? x[e] + o.rv[i][j][e] : x[e];
     }
@@ -231,6 +241,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
         const bool in = n + e < p.N;
         float x = (p.bias && in) ? v[e] + p.bias[n + e] : v[e];
         x = apply_act(x, p.act);
+        if (p.drop_p > 0.0f)
+          x = dropout_keep(p.drop_seed, (unsigned long long)m * p.N + (n + e), p.drop_p) ? x / (1.0f - p.drop_p) : 0.0f;
         if (p.R && in) x += p.R[(size_t)rr * p.ldr + n + e];
         v[e] = x;
         w[e] = (p.C2 && in) ? x * p.X[(size_t)m * p.ldx + (n + e) % p.F] : 0.0f;
@@ -1771,6 +1783,8 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
     if (p.kchunk <= 0 || (p.kchunk & 63) || (long long)(p.ksplit - 1) * p.kchunk >= p.K) return hipErrorInvalidValue;
   }
   if (p.alt.M <= 0) p.alt.M = 0;
+  if (p.drop_p < 0.0f || p.drop_p >= 1.0f || (p.drop_p > 0.0f && (p.ldc != p.N || p.C2 || p.mag_F > 0 || p.ksplit > 1)))
+    return hipErrorInvalidValue;
   if (p.ln_gamma && p.ln_stats) {                      // LayerNorm applied while staging A, statistics given
 #ifdef AVSEP_DEV
     if (!p.ln_beta || p.amode != AMODE_PLAIN || !gemm_ln_staged_supported(p.K) || p.ksplit > 1 || p.alt.M > 0) return hipErrorInvalidValue;

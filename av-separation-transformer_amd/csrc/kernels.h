@@ -79,6 +79,11 @@ struct GemmParams {
   // (nn.TransformerEncoderLayer of AudioEncoder / VisualEncoder, model.py:48-52 / 97-101: same shapes of weights, M = B*T
   // and B*N rows).  Virtual tiles [0, g_tiles0) belong to the problem above, the others to `alt`; g_tiles0 is filled in by
   // the launcher once the tile is chosen (alt.M > 0 marks a pair).
+  // Training: inverted dropout in the epilogue, y = residual + (keep ? act(acc + bias) / (1 - p) : 0) with the stateless
+  // mask of dropout_keep() on the element index m*N + n -- the same values, bit for bit, as a dropout / dropout_add launch
+  // behind the GEMM (the backward regenerates the mask from the seed).  drop_p = 0: off.  Needs ldc == N.
+  float drop_p;
+  unsigned long long drop_seed;
   int g_tiles0;
   struct Alt {
     const float *A, *W, *bias, *R, *ln_gamma, *ln_beta;
@@ -146,12 +151,15 @@ hipError_t launch_bn_running(float* rmean, float* rvar, const float* mean, const
                              int M, hipStream_t s);
 hipError_t launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t s);
 hipError_t launch_act_bwd(const float* dy, const float* aux, float* dx, size_t n, int act, hipStream_t s);
+// backward of y = dropout(relu(z)) from y alone: dx = y > 0 ? dy / (1 - p) : 0  (y > 0 <=> kept and z > 0)
+hipError_t launch_relu_dropout_bwd(const float* dy, const float* y, float* dx, size_t n, float p, hipStream_t s);
 hipError_t launch_mul_mixed(const float* a, const float* xt, float* out, size_t M, int S, int F, int ldx, hipStream_t s);
 hipError_t launch_add_rows(const float* x, const float* r, float* y, size_t M, int C, int period, hipStream_t s);
 hipError_t launch_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_bwd(const float* dy, float* dx, int B, int N, int T, int d, hipStream_t s);
-hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* xhat, int M,
-                                int d, float eps, hipStream_t s);
+// dres (may be null): added to dx -- the gradient that reaches x along the residual path of a pre-norm block
+hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
+                                float* xhat, int M, int d, float eps, hipStream_t s);
 // (B,F,T) -> (B,T,Fp) zero padded
 hipError_t launch_transpose_pad(const float* x, float* y, int B, int F, int T, int Fp, hipStream_t s);
 // first visual conv (Cin=1) + folded BN + ReLU: frames (M,H,W) -> act (M,Ho,Wo,32) channels-last

@@ -45,6 +45,25 @@ int avsep_op_linear_ex(const float* x, int lda, const float* w, int ldw, const f
   return AVSEP_OK;
 }
 
+int avsep_op_linear_drop(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
+                         int ldr, int rperiod, float* y, int M, int N, int K, int act, float drop_p, uint64_t drop_seed,
+                         void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || (lda & 3) || (ldw & 3)) return fail(AVSEP_EINVAL, "K must be a multiple of 32 and rows 16-byte aligned");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  if (drop_p < 0.0f || drop_p >= 1.0f) return fail(AVSEP_EINVAL, "dropout probability must be in [0, 1)");
+  GemmParams p{};
+  p.A = x; p.W = w; p.bias = bias; p.C = y;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldw = ldw; p.ldc = N;
+  p.amode = AMODE_PLAIN;
+  p.act = act;
+  p.R = residual; p.ldr = ldr; p.rperiod = rperiod;
+  p.drop_p = drop_p; p.drop_seed = drop_seed;
+  TCK(launch_gemm(p, S(stream)));
+  return AVSEP_OK;
+}
+
 // ---- weight gradient dW[N][K] = dYt[N][R] . Xt[K][R]^T with the (long) row index R as the contraction.  Few output
 // tiles and R in the thousands to hundreds of thousands (conv layers: N*K = 32x32, R = 307200) would leave the chip
 // idle, so the contraction is cut into slices (gridDim.y) whose partial products are summed in a fixed order.
@@ -289,6 +308,11 @@ int avsep_op_act_bwd(const float* dy, const float* aux, float* dx, int64_t n, in
   TCK(launch_act_bwd(dy, aux, dx, (size_t)n, act, S(stream)));
   return AVSEP_OK;
 }
+int avsep_op_relu_dropout_bwd(const float* dy, const float* y, float* dx, int64_t n, float p, void* stream) {
+  if (!dy || !y || !dx || n <= 0 || p < 0.0f || p >= 1.0f) return fail(AVSEP_EINVAL, "bad argument");
+  TCK(launch_relu_dropout_bwd(dy, y, dx, (size_t)n, p, S(stream)));
+  return AVSEP_OK;
+}
 int avsep_op_mul_mixed(const float* a, const float* xt, float* out, int64_t M, int S_, int F, int ldx, void* stream) {
   if (!a || !xt || !out || M <= 0 || S_ <= 0 || F <= 0 || ldx < F) return fail(AVSEP_EINVAL, "bad argument");
   TCK(launch_mul_mixed(a, xt, out, (size_t)M, S_, F, ldx, S(stream)));
@@ -318,7 +342,17 @@ int avsep_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, 
                            float* xhat_scratch, float* scratch, int M, int d, float eps, void* stream) {
   if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !xhat_scratch || !scratch) return fail(AVSEP_EINVAL, "null pointer");
   hipStream_t s = S(stream);
-  TCK(launch_layernorm_bwd(dy, x, gamma, dx, xhat_scratch, M, d, eps, s));
+  TCK(launch_layernorm_bwd(dy, x, gamma, nullptr, dx, xhat_scratch, M, d, eps, s));
+  TCK(launch_colreduce(dy, xhat_scratch, scratch, dbeta, dgamma, M, d, 1.0f, s));
+  return AVSEP_OK;
+}
+
+int avsep_op_layernorm_bwd_res(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
+                               float* dgamma, float* dbeta, float* xhat_scratch, float* scratch, int M, int d, float eps,
+                               void* stream) {
+  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !xhat_scratch || !scratch) return fail(AVSEP_EINVAL, "null pointer");
+  hipStream_t s = S(stream);
+  TCK(launch_layernorm_bwd(dy, x, gamma, dres, dx, xhat_scratch, M, d, eps, s));
   TCK(launch_colreduce(dy, xhat_scratch, scratch, dbeta, dgamma, M, d, 1.0f, s));
   return AVSEP_OK;
 }

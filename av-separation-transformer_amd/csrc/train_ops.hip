@@ -343,6 +343,19 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   reinterpret_cast<T*>(dx)[idx] = g;
 }
 
+// backward of y = dropout(relu(z)) (the FFN's hidden activation, fused into the GEMM epilogue) from y alone
+template <int V>
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               float* __restrict__ dx, size_t nv, float p) {
+  typedef typename VecT<V>::type T;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nv) return;
+  T g = reinterpret_cast<const T*>(dy)[idx], a = reinterpret_cast<const T*>(y)[idx];
+#pragma unroll
+  for (int e = 0; e < V; ++e) lane_of<V>(g, e) = lane_of<V>(a, e) > 0.0f ? lane_of<V>(g, e) / (1.0f - p) : 0.0f;
+  reinterpret_cast<T*>(dx)[idx] = g;
+}
+
 // out[m][s*F + f] = a[m][s*F + f] * xt[m][f]   (SeparationDecoder.separate and its adjoint w.r.t. the masks)
 __global__ __launch_bounds__(256) void mul_mixed_kernel(const float* __restrict__ a, const float* __restrict__ xt,
                                                         float* __restrict__ out, size_t M, int S, int F, int ldx) {
@@ -453,8 +466,9 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
 // affine gradients (dgamma = sum dy*xhat, dbeta = sum dy) can use the generic column reduction.
 template <int VEC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ gam, float* __restrict__ dx,
-                                                            float* __restrict__ xhat, int M, int d, float eps) {
+                                                            const float* __restrict__ gam, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ xhat, int M, int d,
+                                                            float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -511,6 +525,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - mg - v[i][e] * mgx);
+      if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * d + col);   // the residual path's gradient
       *reinterpret_cast<f32x4*>(dx + (size_t)row * d + col) = o;
       *reinterpret_cast<f32x4*>(xhat + (size_t)row * d + col) = v[i];
     }
@@ -613,6 +628,12 @@ hipError_t launch_act_bwd(const float* dy, const float* aux, float* dx, size_t n
   else hipLaunchKernelGGL((act_bwd_kernel<1>), dim3(nblk(n)), dim3(256), 0, s, dy, aux, dx, n, act);
   return hipGetLastError();
 }
+hipError_t launch_relu_dropout_bwd(const float* dy, const float* y, float* dx, size_t n, float p, hipStream_t s) {
+  if (vec4_ok(n, dy, y, dx))
+    hipLaunchKernelGGL((relu_dropout_bwd_kernel<4>), dim3(nblk(n / 4)), dim3(256), 0, s, dy, y, dx, n / 4, p);
+  else hipLaunchKernelGGL((relu_dropout_bwd_kernel<1>), dim3(nblk(n)), dim3(256), 0, s, dy, y, dx, n, p);
+  return hipGetLastError();
+}
 hipError_t launch_mul_mixed(const float* a, const float* xt, float* out, size_t M, int S, int F, int ldx,
                             hipStream_t s) {
   hipLaunchKernelGGL(mul_mixed_kernel, dim3(nblk(M * S * F)), dim3(256), 0, s, a, xt, out, M, S, F, ldx);
@@ -645,14 +666,14 @@ hipError_t launch_interp_bwd(const float* dy, float* dx, int B, int N, int T, in
                      (float)N / (float)T);
   return hipGetLastError();
 }
-hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* xhat, int M,
-                                int d, float eps, hipStream_t s) {
+hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
+                                float* xhat, int M, int d, float eps, hipStream_t s) {
   if (M <= 0 || d <= 0 || (d & 3) || d > 2048) return hipErrorInvalidValue;
   const dim3 grid((M + 3) / 4), block(256);
   const int vec = (d + 255) / 256;
-  if (vec <= 1) hipLaunchKernelGGL((layernorm_bwd_kernel<1>), grid, block, 0, s, dy, x, gamma, dx, xhat, M, d, eps);
-  else if (vec <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<2>), grid, block, 0, s, dy, x, gamma, dx, xhat, M, d, eps);
-  else if (vec <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, s, dy, x, gamma, dx, xhat, M, d, eps);
-  else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, s, dy, x, gamma, dx, xhat, M, d, eps);
+  if (vec <= 1) hipLaunchKernelGGL((layernorm_bwd_kernel<1>), grid, block, 0, s, dy, x, gamma, dres, dx, xhat, M, d, eps);
+  else if (vec <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<2>), grid, block, 0, s, dy, x, gamma, dres, dx, xhat, M, d, eps);
+  else if (vec <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, s, dy, x, gamma, dres, dx, xhat, M, d, eps);
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, s, dy, x, gamma, dres, dx, xhat, M, d, eps);
   return hipGetLastError();
 }

@@ -274,6 +274,21 @@ int avsep_op_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, void* 
 int avsep_op_interp_linear_bwd(const float* dy, float* dx, int B, int N, int T, int d, void* stream);
 int avsep_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
                            float* xhat_scratch, float* scratch, int M, int d, float eps, void* stream);
+/* The same with the gradient that reaches x along the RESIDUAL path of a pre-norm block (nn.TransformerEncoderLayer
+ * norm_first=True, CrossAttentionLayer, model.py:48-52,168-172) added inside the kernel: dx = LayerNorm'(dy) + dres
+ * (dres may be null) -- instead of the elementwise add autograd inserts for a tensor with two consumers. */
+int avsep_op_layernorm_bwd_res(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
+                               float* dgamma, float* dbeta, float* xhat_scratch, float* scratch, int M, int d, float eps,
+                               void* stream);
+/* y = residual + dropout(act(x w^T + b)) with the dropout of a train-mode transformer block (dropout1 / dropout2 / the FFN's
+ * inner dropout, model.py:48-52,159,164) applied in the GEMM epilogue: inverted dropout, keep-mask = stateless hash of
+ * (seed, element index m*N + n) -- the values of avsep_op_linear_ex followed by avsep_op_dropout / _dropout_add, bit for
+ * bit, in one launch.  y is (M, N) contiguous. */
+int avsep_op_linear_drop(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
+                         int ldr, int rperiod, float* y, int M, int N, int K, int act, float drop_p, uint64_t drop_seed,
+                         void* stream);
+/* backward of y = dropout(relu(z)) from y alone: dx = y > 0 ? dy / (1 - p) : 0 */
+int avsep_op_relu_dropout_bwd(const float* dy, const float* y, float* dx, int64_t n, float p, void* stream);
 
 #ifdef __cplusplus
 }

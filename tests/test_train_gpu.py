@@ -294,6 +294,83 @@ def test_weight_table_survives_a_model_leaving_the_device():
     assert all(w.dtype == torch.float32 for w, _ in table._descriptors())
 
 
+def test_epilogue_dropout_and_fused_residual_norm_change_no_bit():
+    """Round 3 removed launches from the training step: dropout1 / dropout2 / the FFN's inner dropout run in the GEMM
+    epilogue, and the residual path's gradient is added inside the LayerNorm backward kernel.  With the same dropout seed
+    the outputs, the loss and EVERY parameter gradient equal the launch-per-op forms bit for bit."""
+    import av_separation as av
+    from av_separation import _train as tr
+    from av_separation.losses import SeparationLoss
+    dev = torch.device("cuda:0")
+    ds = av.SyntheticAVDataset(num_samples=3, sample_rate=8000, duration=1.0, n_fft=256, hop_length=128, num_frames=10,
+                               frame_h=16, frame_w=16)
+    items = [ds[i] for i in range(3)]
+    mixed = torch.stack([x["mixed_spec"] for x in items]).to(dev)
+    lips = torch.stack([x["lip_frames"] for x in items]).to(dev)
+    tg = torch.stack([x["clean_specs"] for x in items]).to(dev)
+    crit = SeparationLoss(0.5)
+    res = {}
+    old = (tr.EPILOGUE_DROPOUT, tr.FUSED_RESIDUAL_NORM)
+    try:
+        for fused in (False, True):
+            tr.EPILOGUE_DROPOUT = tr.FUSED_RESIDUAL_NORM = fused
+            torch.manual_seed(9)
+            m = av.AVSeparationTransformer(freq_bins=129, d_model=128, nhead=4, num_encoder_layers=2,
+                                           num_fusion_layers=2, num_speakers=2, dropout=0.2).to(dev).train()
+            torch.manual_seed(77)                      # the dropout base seed is drawn from torch's CPU generator
+            sep, masks = m(mixed, lips)
+            loss = crit(sep, tg)
+            loss.backward()
+            res[fused] = (sep.detach().clone(), masks.detach().clone(), loss.detach().clone(),
+                          {n: p.grad.clone() for n, p in m.named_parameters()})
+    finally:
+        tr.EPILOGUE_DROPOUT, tr.FUSED_RESIDUAL_NORM = old
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert 0.0 < float((b[1] == b[1]).float().mean())          # finite
+    for n in a[3]:
+        assert torch.equal(a[3][n], b[3][n]), n
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(504, 256, 256, 0, True), (2016, 1024, 256, 1, False), (37, 50, 64, 0, True),
+                                           (130, 771, 512, 1, False), (4016, 512, 2048, 0, True)])
+def test_op_linear_drop_equals_gemm_then_dropout(M, N, K, act, res):
+    """avsep_op_linear_drop = avsep_op_linear_ex followed by avsep_op_dropout (/ _dropout_add), bit for bit, on the fast
+    (N % 4 == 0) and the general epilogue; and its ReLU form's backward kernel against the two-launch backward."""
+    import ctypes as C
+    from av_separation import _native
+    lib = _native.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    r = torch.randn(M, N, generator=g).to(dev) if res else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p, seed = 0.3, 0x1234567890ABCDEF
+    y0 = torch.empty(M, N, device=dev)
+    _native.check(lib.avsep_op_linear_ex(x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), None, N, 0, y0.data_ptr(), N, M, N, K,
+                                         act, st))
+    want = torch.empty_like(y0)
+    if res:
+        _native.check(lib.avsep_op_dropout_add(y0.data_ptr(), r.data_ptr(), want.data_ptr(), y0.numel(), p, seed, st))
+    else:
+        _native.check(lib.avsep_op_dropout(y0.data_ptr(), want.data_ptr(), y0.numel(), p, seed, st))
+    got = torch.full((M, N), float("nan"), device=dev)
+    _native.check(lib.avsep_op_linear_drop(x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), r.data_ptr() if res else None, N, 0,
+                                           got.data_ptr(), M, N, K, act, p, seed, st))
+    assert torch.equal(got, want)
+    kept = float((got != (r if res else 0)).float().mean())
+    assert abs(kept - (0.7 if act == 0 else 0.35)) < 0.05            # keep rate (x relu's ~half)
+    if act == 1:
+        dy = torch.randn(M, N, generator=g).to(dev)
+        g1, g2, g3 = torch.empty_like(dy), torch.empty_like(dy), torch.empty_like(dy)
+        _native.check(lib.avsep_op_dropout(dy.data_ptr(), g1.data_ptr(), dy.numel(), p, seed, st))         # mask on the gradient
+        _native.check(lib.avsep_op_act_bwd(g1.data_ptr(), y0.data_ptr(), g2.data_ptr(), dy.numel(), 1, st))  # then relu'
+        _native.check(lib.avsep_op_relu_dropout_bwd(dy.data_ptr(), got.data_ptr(), g3.data_ptr(), dy.numel(), p, st))
+        assert torch.equal(g2, g3)
+
+
 def test_dropout_training_is_self_consistent():
     """dropout > 0 (the reference's default 0.1): masks cannot match torch's RNG stream, so check what must hold
     anyway: same seed -> same output, different seed -> different; keep rate and 1/(1-p) scaling of the mask;
