@@ -98,22 +98,27 @@ def gather_ranks(dist, obj):
 
 
 def device_identity(dev):
-    """What tells two GPUs of a node apart: name, PCI domain:bus:device, uuid (whatever this torch build exposes)."""
+    """What tells two GPUs of a node apart: name, PCI domain:bus:device (the reliable one on this stack), uuid when the
+    torch build exposes a non-degenerate one."""
     p = torch.cuda.get_device_properties(dev)
     pci = None
     if hasattr(p, "pci_bus_id"):
         pci = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}"
-    return {"index": dev.index, "name": p.name, "pci": pci, "uuid": str(getattr(p, "uuid", "")) or None,
-            "pid": os.getpid()}
+    uuid = str(getattr(p, "uuid", "") or "")
+    if not uuid.strip("0-") or uuid in ("None", ""):
+        uuid = None
+    return {"index": dev.index, "name": p.name, "pci": pci, "uuid": uuid, "pid": os.getpid(),
+            "visible_devices": torch.cuda.device_count()}
 
 
 def duplicate_devices(idents):
-    """Pairs of ranks that report the same physical device (same uuid, or same PCI address when no uuid is exposed):
-    a rank that landed on a neighbour's GPU would otherwise be invisible in the one aggregated number."""
+    """Pairs of ranks that report the same physical device: same PCI address (a rank that landed on a neighbour's GPU
+    would otherwise be invisible in the one aggregated number).  Only a real address counts -- a missing or all-zero one
+    proves nothing, and the uuid field is informational (runtimes have reported the same uuid for every device)."""
     seen, dup = {}, []
     for r, d in enumerate(idents):
-        key = d.get("uuid") or d.get("pci")
-        if key is None:
+        key = d.get("pci")
+        if not key or not key.replace(":", "").strip("0"):
             continue
         if key in seen:
             dup.append((seen[key], r, key))
@@ -182,7 +187,7 @@ def selftest_launch(rank, world, a):
     per_rank = gather_ranks(dist, 10.0 * (rank + 1))
     # pretend devices: distinct unless the test asks for two ranks on one GPU
     same = os.environ.get("AVSEP_SELFTEST_SAME_DEVICE") == "1"
-    idents = gather_ranks(dist, {"index": 0 if same else rank, "name": "selftest", "pci": f"0000:{0 if same else rank:02x}:00",
+    idents = gather_ranks(dist, {"index": 0 if same else rank, "name": "selftest", "pci": f"0000:{1 if same else rank + 1:02x}:00",
                                  "uuid": None, "pid": os.getpid()})
     dup = duplicate_devices(idents)
     dist.barrier()

@@ -71,7 +71,7 @@ def test_plain_bench_gpus2_spawns_its_own_ranks():
     assert abs(lines[0]["elapsed_max"] - 0.020) < 1e-12 and lines[0]["rank0_clips"] == [0, 1, 2, 3]
     # per-rank reporting of the N > 1 line: every rank's own time and device identity, gathered on rank 0
     assert lines[0]["per_rank_ms"] == [10.0, 20.0] and lines[0]["world_size"] == 2
-    assert [d["pci"] for d in lines[0]["devices"]] == ["0000:00:00", "0000:01:00"]
+    assert [d["pci"] for d in lines[0]["devices"]] == ["0000:01:00", "0000:02:00"]
     assert lines[0]["devices"][0]["pid"] != lines[0]["devices"][1]["pid"]
 
 
@@ -85,9 +85,12 @@ def test_duplicate_device_detection():
     a = {"uuid": "GPU-1", "pci": "0000:05:00"}
     b = {"uuid": "GPU-2", "pci": "0000:06:00"}
     assert bench.duplicate_devices([a, b]) == []
-    assert bench.duplicate_devices([a, b, dict(a)]) == [(0, 2, "GPU-1")]
+    assert bench.duplicate_devices([a, b, dict(a)]) == [(0, 2, "0000:05:00")]
     assert bench.duplicate_devices([{"uuid": None, "pci": "0000:05:00"}, {"uuid": None, "pci": "0000:05:00"}]) == [(0, 1, "0000:05:00")]
+    # nothing is concluded from a missing or all-zero address, nor from equal uuids alone
     assert bench.duplicate_devices([{"uuid": None, "pci": None}, {"uuid": None, "pci": None}]) == []
+    assert bench.duplicate_devices([{"uuid": "X", "pci": "0000:00:00"}, {"uuid": "X", "pci": "0000:00:00"}]) == []
+    assert bench.duplicate_devices([{"uuid": "X", "pci": "0000:05:00"}, {"uuid": "X", "pci": "0000:06:00"}]) == []
     assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5
 
 
