@@ -853,16 +853,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // lanes that own the row with in-wave shuffles; biased variance, eps inside the sqrt like nn.LayerNorm.
 // NK = K / BK exactly (compile time): a runtime "if (kc < nk)" around the register arrays makes hipcc copy them
 // through v_mov / v_accvgpr webs (measured 4.5 TFLOP/s on the 8-chunk variant).
-template <int BM, int BN, int BK, int NKMAX>
-__global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams pin) {
+// WM x WN wavefronts (default 2 x 2 = 256 threads).  The large-workgroup instances (8 or 16 wavefronts, ONE workgroup per CU)
+// exist because of what the resident-workgroup census of the 256-thread form shows on the model's shapes
+// (profiles/r03_ln_gemm_phases.txt): its three workgroups per CU each pull their own A and W slabs through the CU's one
+// texture-address unit (288 KB per CU and launch at 32x64) and then leave the CU one after the other, a staircase of three
+// ~3.4 us steps behind a ~5 us prologue.  One workgroup of 8-16 waves covering the same outputs fetches every A row and W row
+// of the CU once (160-192 KB) and keeps 2-4 waves per SIMD on the matrix pipes in one K loop.
+template <int BM, int BN, int BK, int NKMAX, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_ln_kernel(const GemmParams pin) {
   GemmParams p = pin;
   dbg_stamp(p, 0);
+  constexpr int NT = 64 * WM * WN;
   constexpr int SLOTS = BK / 4;
-  constexpr int RPP = 256 / SLOTS;
+  constexpr int RPP = NT / SLOTS;
   constexpr int APASS = BM / RPP;
   constexpr int BPASS = BN / RPP;
-  constexpr int WBM = BM / 32;
-  constexpr int WBN = BN / 32;
+  constexpr int WBM = BM / (16 * WM);
+  constexpr int WBN = BN / (16 * WN);
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "tile / workgroup shape mismatch");
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BK];
   float* As = lds;
   float* Bs = lds + 2 * BM * BK;
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams pin) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int nbn = (p.N + BN - 1) / BN;
   int tile = xcd_tile(p);
   select_pair(p, tile);
@@ -959,13 +967,13 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams pin) {
   int a_off[WBM], a_swz[WBM], b_off[WBN], b_swz[WBN];
 #pragma unroll
   for (int i = 0; i < WBM; ++i) {
-    const int r = wm * (BM / 2) + 16 * i + fr;
+    const int r = wm * (BM / WM) + 16 * i + fr;
     a_off[i] = r * BK;
     a_swz[i] = swz<SLOTS>(r);
   }
 #pragma unroll
   for (int j = 0; j < WBN; ++j) {
-    const int r = wn * (BN / 2) + 16 * j + fr;
+    const int r = wn * (BN / WN) + 16 * j + fr;
     b_off[j] = r * BK;
     b_swz[j] = swz<SLOTS>(r);
   }
@@ -990,7 +998,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const GemmParams pin) {
   }
 
   dbg_stamp(p, 2);
-  gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / WM), wn * (BN / WN), fr, fq);
   if (p.dbg) {                                                   // block-uniform, diagnostics only
     dbg_stamp(p, 3);
     __builtin_amdgcn_s_waitcnt(0);
@@ -1556,36 +1564,39 @@ bool ln_fusable(const GemmParams& p) {
   return nk == 1 || nk == 2 || nk == 4;
 }
 
-Tile pick_ln_tile(const GemmParams& p) {
+// LN-fused tiles: (bm, bn, bk) + wavefronts of the workgroup (4 = the 256-thread form)
+struct LnTile { int bm, bn, bk, waves; };
+
+LnTile pick_ln_tile(const GemmParams& p) {
   const int bk = ln_bk(p.K);
-  if (const char* e = dev_env("AVSEP_LN_TILE")) {   // developer override: AVSEP_LN_TILE=BMxBN
-    Tile t{32, 32, bk};
-    if (sscanf(e, "%dx%d", &t.bm, &t.bn) == 2) return t;
+  if (const char* e = dev_env("AVSEP_LN_TILE")) {   // developer override: AVSEP_LN_TILE=BMxBN[xWAVES]
+    LnTile t{32, 32, bk, 4};
+    if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.waves) >= 2) return t;
   }
-  Tile pick{32, 32, bk};
+  LnTile pick{32, 32, bk, 4};
   if (bk == 64 && p.K / bk <= 4) {
-    static const Tile cands[] = {{64, 64, 64}, {64, 32, 64}};
-    auto blocks = [&](const Tile& t) { return row_tiles(p, t.bm) * ((p.N + t.bn - 1) / t.bn); };
+    static const LnTile cands[] = {{64, 64, 64, 4}, {64, 32, 64, 4}};
+    auto blocks = [&](const LnTile& t) { return row_tiles(p, t.bm) * ((p.N + t.bn - 1) / t.bn); };
     // measured in the full cfg2 step: 32-row LN tiles beat 64x32 / 64x64 even where the bigger tiles win in isolation
     static const long tln = dev_env("AVSEP_TLN") ? atol(dev_env("AVSEP_TLN")) : 2048;
     bool found = false;
-    for (const Tile& t : cands)
+    for (const LnTile& t : cands)
       if (!found && blocks(t) >= tln) { pick = t; found = true; }
     // 32 rows x 64 columns: every A row block is fetched and normalised for half as many column tiles (the LN-fused
     // prologue is an L2 burst of the workgroup's whole A and W slabs: 97 -> 73 MB per 2016x768x256 launch) while the row
     // parallelism stays; only where that still leaves >= 2 workgroups per CU
     static const long tln64 = dev_env("AVSEP_TLN64") ? atol(dev_env("AVSEP_TLN64")) : 512;
-    const Tile wide{32, 64, 64};
+    const LnTile wide{32, 64, 64, 4};
     if (!found && blocks(wide) >= tln64) pick = wide;
   }
   return pick;
 }
 
-template <int BM, int BN, int BK, int NK>
+template <int BM, int BN, int BK, int NK, int WM = 2, int WN = 2>
 hipError_t launch_ln_t(GemmParams p, hipStream_t s) {
   const int nbn = (p.N + BN - 1) / BN;
   p.g_tiles0 = p.alt.M > 0 ? ((p.M + BM - 1) / BM) * nbn : 0;
-  hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, BK, NK>), dim3((unsigned)(row_tiles(p, BM) * nbn)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_ln_kernel<BM, BN, BK, NK, WM, WN>), dim3((unsigned)(row_tiles(p, BM) * nbn)), dim3(64 * WM * WN), 0, s, p);
   return hipGetLastError();
 }
 
@@ -1599,9 +1610,25 @@ hipError_t launch_ln_nk(const GemmParams& p, int nk, hipStream_t s) {
   }
 }
 
+template <int BM, int BN, int WM, int WN>
+hipError_t launch_ln_big(const GemmParams& p, int nk, hipStream_t s) {     // the 8- / 16-wave instances: K = 128 or 256
+  if (nk == 4) return launch_ln_t<BM, BN, 64, 4, WM, WN>(p, s);
+  if (nk == 2) return launch_ln_t<BM, BN, 64, 2, WM, WN>(p, s);
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
-  const Tile t = pick_ln_tile(p);
+  const LnTile t = pick_ln_tile(p);
   const int nk = p.K / t.bk;
+  if (t.bk == 64 && t.waves != 4) {
+    if (t.bm == 128 && t.bn == 64 && t.waves == 16) return launch_ln_big<128, 64, 8, 2>(p, nk, s);
+    if (t.bm == 64 && t.bn == 128 && t.waves == 16) return launch_ln_big<64, 128, 4, 4>(p, nk, s);
+    if (t.bm == 64 && t.bn == 96 && t.waves == 8) return launch_ln_big<64, 96, 4, 2>(p, nk, s);
+    if (t.bm == 64 && t.bn == 64 && t.waves == 8) return launch_ln_big<64, 64, 4, 2>(p, nk, s);
+    if (t.bm == 128 && t.bn == 32 && t.waves == 8) return launch_ln_big<128, 32, 8, 1>(p, nk, s);
+    if (t.bm == 32 && t.bn == 128 && t.waves == 8) return launch_ln_big<32, 128, 2, 4>(p, nk, s);
+    return hipErrorInvalidValue;
+  }
   if (t.bk == 64) {
     if (t.bm == 64 && t.bn == 64 && nk <= 4) return launch_ln_nk<64, 64, 64>(p, nk, s);
     if (t.bm == 64 && t.bn == 32 && nk <= 4) return launch_ln_nk<64, 32, 64>(p, nk, s);
@@ -1650,8 +1677,12 @@ bool ring4_6464() { return dev_env("AVSEP_6464_RING4") != nullptr; }   // read p
 const char* gemm_instance_name(const GemmParams& p) {
   static thread_local char buf[64];
   if (p.ln_gamma && !p.ln_stats) {
-    const Tile t = pick_ln_tile(p);
-    snprintf(buf, sizeof buf, "gemm_ln_kernel<%d, %d, %d, %d>", t.bm, t.bn, t.bk, p.K / t.bk);
+    const LnTile t = pick_ln_tile(p);
+    if (t.waves == 4) snprintf(buf, sizeof buf, "gemm_ln_kernel<%d, %d, %d, %d, 2, 2>", t.bm, t.bn, t.bk, p.K / t.bk);
+    else {
+      const int wn = (t.bm == 128 && t.bn == 32) ? 1 : (t.bn == 128) ? 4 : 2;
+      snprintf(buf, sizeof buf, "gemm_ln_kernel<%d, %d, %d, %d, %d, %d>", t.bm, t.bn, t.bk, p.K / t.bk, t.waves / wn, wn);
+    }
     return buf;
   }
   const Tile t = pick_tile(p);

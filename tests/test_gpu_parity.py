@@ -414,6 +414,37 @@ def test_op_ln_linear_forms_agree(lib, devlib, dev, M, N, K, act):
         assert rc == 0 and torch.equal(p1, y1)
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 384, 256), (2016, 768, 256), (333, 96, 128), (1600, 1024, 256)])
+def test_op_ln_linear_instances_bit_identical(lib, devlib, dev, M, N, K):
+    """Every instance of the LayerNorm-fused GEMM (form 1) -- the 256-thread tiles and the 8- / 16-wavefront workgroups that
+    cover a CU's outputs in ONE workgroup -- computes the row statistics from the same registers in the same order and feeds
+    the matrix cores in the same k order: all agree bit for bit, and so does the product library's own choice."""
+    import os
+    from av_separation._native import check
+    x = t(seeded.tensor(17, "x", (M, K), -3, 5), dev)
+    w = t(seeded.tensor(17, "w", (N, K), -0.2, 0.2), dev)
+    g_, be_, b_ = (t(seeded.tensor(17, n_, shp, lo, hi), dev) for n_, shp, lo, hi in
+                   (("g", (K,), 0.5, 1.5), ("be", (K,), -1, 1), ("b", (N,), -1, 1)))
+
+    def run(which):
+        y = torch.full((M, N), float("nan"), device=dev)
+        check(which.avsep_op_ln_linear(x.data_ptr(), g_.data_ptr(), be_.data_ptr(), w.data_ptr(), b_.data_ptr(), y.data_ptr(),
+                                       None, M, N, K, 2, 1e-5, 1, _stream()))
+        return y
+    outs = {}
+    try:
+        for tile in ("32x32", "32x64", "64x32", "64x64", "128x64x16", "64x128x16", "64x96x8", "64x64x8", "128x32x8", "32x128x8"):
+            os.environ["AVSEP_LN_TILE"] = tile
+            outs[tile] = run(devlib)
+        outs["product"] = run(lib)
+    finally:
+        os.environ.pop("AVSEP_LN_TILE", None)
+    ref = outs.pop("32x32")
+    assert torch.isfinite(ref).all()
+    for tile, y in outs.items():
+        assert torch.equal(y, ref), tile
+
+
 def test_op_ln_linear_rejects_bad_forms(lib, devlib, dev):
     y = torch.empty(64 * 1024, device=dev)
     p_ = y.data_ptr()
