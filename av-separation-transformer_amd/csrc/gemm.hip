@@ -1574,6 +1574,20 @@ LnTile pick_ln_tile(const GemmParams& p) {
     if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.waves) >= 2) return t;
   }
   LnTile pick{32, 32, bk, 4};
+  // One workgroup of 8 / 16 wavefronts per CU where its tile grid fills the chip in ONE round (161..256 workgroups): the CU
+  // fetches each of its A and W rows once instead of once per 256-thread workgroup, and the workgroup's prologue is one
+  // memory round trip instead of three staggered ones (census + sweep: profiles/r03_ln_gemm_phases.txt, r03_ln_gemm_sweep.txt:
+  // QKV 2016x768 14.4 -> 13.4 us, FFN-1 2016x1024 18.1 -> 16.0, 1008x1024 10.4 -> 9.6, 2016x512 10.5 -> 9.6; nothing to gain
+  // at N = 256 or below 160 tiles).  Bit-identical to every other instance (tests/test_gpu_parity.py).
+  if (bk == 64 && (p.K == 256 || p.K == 128) && p.alt.M <= 0 && !dev_env("AVSEP_NO_LN_BIG")) {
+    auto fits = [&](int bm, int bn) {
+      const long t = row_tiles(p, bm) * ((p.N + bn - 1) / bn);
+      return t > 160 && t <= 256;
+    };
+    if (p.N % 96 == 0 && fits(64, 96)) return LnTile{64, 96, bk, 8};
+    if (p.N % 128 == 0 && fits(64, 128)) return LnTile{64, 128, bk, 16};
+    if (p.N % 128 == 0 && fits(32, 128)) return LnTile{32, 128, bk, 8};
+  }
   if (bk == 64 && p.K / bk <= 4) {
     static const LnTile cands[] = {{64, 64, 64, 4}, {64, 32, 64, 4}};
     auto blocks = [&](const LnTile& t) { return row_tiles(p, t.bm) * ((p.N + t.bn - 1) / t.bn); };
