@@ -1574,12 +1574,14 @@ LnTile pick_ln_tile(const GemmParams& p) {
     if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.waves) >= 2) return t;
   }
   LnTile pick{32, 32, bk, 4};
-  // One workgroup of 8 / 16 wavefronts per CU where its tile grid fills the chip in ONE round (161..256 workgroups): the CU
-  // fetches each of its A and W rows once instead of once per 256-thread workgroup, and the workgroup's prologue is one
-  // memory round trip instead of three staggered ones (census + sweep: profiles/r03_ln_gemm_phases.txt, r03_ln_gemm_sweep.txt:
-  // QKV 2016x768 14.4 -> 13.4 us, FFN-1 2016x1024 18.1 -> 16.0, 1008x1024 10.4 -> 9.6, 2016x512 10.5 -> 9.6; nothing to gain
-  // at N = 256 or below 160 tiles).  Bit-identical to every other instance (tests/test_gpu_parity.py).
-  if (bk == 64 && (p.K == 256 || p.K == 128) && p.alt.M <= 0 && !dev_env("AVSEP_NO_LN_BIG")) {
+  // Developer experiment (AVSEP_LN_BIG=1): one workgroup of 8 / 16 wavefronts per CU where its tile grid fills the chip in
+  // ONE round (161..256 workgroups) -- the CU fetches each of its A and W rows once instead of once per 256-thread workgroup
+  // and the prologue is one memory round trip instead of three staggered ones.  ALONE on the chip these instances are 8-12 %
+  // faster (profiles/r03_ln_gemm_sweep.txt: QKV 2016x768 14.4 -> 13.4 us, FFN-1 2016x1024 18.1 -> 16.0, 1008x1024 10.4 -> 9.6)
+  // and bit-identical; INSIDE the two-stream step they are 3 % SLOWER with two steps in flight and 4.5 % slower one step at a
+  // time (profiles/r03_ab_ln_big_workgroups.txt): a workgroup that holds 80-96 KB of LDS and 8-16 wave slots of its CU keeps
+  // the other branch's kernels off that CU, and the step lives on exactly that overlap.  Not in the product library.
+  if (bk == 64 && (p.K == 256 || p.K == 128) && p.alt.M <= 0 && dev_env("AVSEP_LN_BIG")) {
     auto fits = [&](int bm, int bn) {
       const long t = row_tiles(p, bm) * ((p.N + bn - 1) / bn);
       return t > 160 && t <= 256;
@@ -1634,6 +1636,7 @@ hipError_t launch_ln_big(const GemmParams& p, int nk, hipStream_t s) {     // th
 hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
   const LnTile t = pick_ln_tile(p);
   const int nk = p.K / t.bk;
+#ifdef AVSEP_DEV
   if (t.bk == 64 && t.waves != 4) {
     if (t.bm == 128 && t.bn == 64 && t.waves == 16) return launch_ln_big<128, 64, 8, 2>(p, nk, s);
     if (t.bm == 64 && t.bn == 128 && t.waves == 16) return launch_ln_big<64, 128, 4, 4>(p, nk, s);
@@ -1643,6 +1646,7 @@ hipError_t launch_gemm_ln(const GemmParams& p, hipStream_t s) {
     if (t.bm == 32 && t.bn == 128 && t.waves == 8) return launch_ln_big<32, 128, 2, 4>(p, nk, s);
     return hipErrorInvalidValue;
   }
+#endif
   if (t.bk == 64) {
     if (t.bm == 64 && t.bn == 64 && nk <= 4) return launch_ln_nk<64, 64, 64>(p, nk, s);
     if (t.bm == 64 && t.bn == 32 && nk <= 4) return launch_ln_nk<64, 32, 64>(p, nk, s);

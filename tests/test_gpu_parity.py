@@ -416,8 +416,8 @@ def test_op_ln_linear_forms_agree(lib, devlib, dev, M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K", [(700, 384, 256), (2016, 768, 256), (333, 96, 128), (1600, 1024, 256)])
 def test_op_ln_linear_instances_bit_identical(lib, devlib, dev, M, N, K):
-    """Every instance of the LayerNorm-fused GEMM (form 1) -- the 256-thread tiles and the 8- / 16-wavefront workgroups that
-    cover a CU's outputs in ONE workgroup -- computes the row statistics from the same registers in the same order and feeds
+    """Every instance of the LayerNorm-fused GEMM (form 1) -- the 256-thread tiles and the developer build's 8- / 16-wavefront
+    workgroups that cover a CU's outputs in ONE workgroup (faster alone, slower inside the step) -- computes the row statistics from the same registers in the same order and feeds
     the matrix cores in the same k order: all agree bit for bit, and so does the product library's own choice."""
     import os
     from av_separation._native import check
