@@ -687,6 +687,11 @@ struct WgradParams {
   int bias;          // 1: also the bias gradient db[n] = sum_r dY[r][n], written behind each slice's N*K weight gradients
                      //    (slice stride N*K + N) by the workgroups of the first K tile -- the column sums of the dY
                      //    chunks they stage anyway, instead of two more launches per layer (colreduce)
+  // In-launch merge of the r-slices (gridDim.y > 1): `dw` then holds the slices' partial results, and the workgroup that
+  // arrives LAST at a tile's ticket counter sums the slices of that tile in slice order (the order of the former
+  // sum_slices launch: bit-identical) into `merged`.  cnt: one zero-initialised counter per tile, left at zero again.
+  float* merged;     // [N][K] (+ [N] bias gradients behind it), or null: no merge, the caller sums the slices
+  unsigned* cnt;
 };
 
 template <int BM, int BN>
@@ -838,6 +843,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   GemmParams q{};   // float4 rows (K % 4 == 0 is a precondition of this kernel)
   q.C = out; q.M = p.N; q.N = p.K; q.ldc = p.K; q.act = ACT_NONE;
   gemm_epilogue<WBM, WBN>(q, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  if (p.merged == nullptr) return;                     // block-uniform
+  // ---- in-launch slice merge: the split-K hand-off of cdna_hip_programming.md (section 5, "Projection GEMM at M = 256",
+  //      item 2), in its plain-store form.  Producer side, every workgroup: all its stores have left (each wave's
+  //      vmcnt(0), then the barrier), ONE lane publishes with an agent-scope release and draws the tile's ticket.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                     // also: the bias reduction above is done with `lds`
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep: the compiler may drop the fence's own wait
+    const unsigned t = __hip_atomic_fetch_add(p.cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == gridDim.y - 1;
+    if (last) {                                        // consumer side: ONE agent-scope acquire, then the barrier below
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p.cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    reinterpret_cast<volatile int*>(lds)[0] = last;
+  }
+  __syncthreads();
+  if (reinterpret_cast<volatile int*>(lds)[0] == 0) return;
+  const int S = gridDim.y;
+  const size_t stride = (size_t)p.N * p.K + (p.bias ? p.N : 0);
+  constexpr int C4 = BN / 4;
+  for (int idx = tid; idx < BM * C4; idx += 256) {
+    const int m = m0 + idx / C4, n = n0 + 4 * (idx % C4);
+    if (m >= p.N || n >= p.K) continue;
+    const size_t off = (size_t)m * p.K + n;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p.dw + off);
+    for (int z = 1; z < S; ++z) a += *reinterpret_cast<const f32x4*>(p.dw + (size_t)z * stride + off);
+    *reinterpret_cast<f32x4*>(p.merged + off) = a;
+  }
+  if (do_bias) {
+    for (int i = tid; i < BM; i += 256) {
+      const int m = m0 + i;
+      if (m >= p.N) continue;
+      const size_t off = (size_t)p.N * p.K + m;
+      float a = p.dw[off];
+      for (int z = 1; z < S; ++z) a += p.dw[(size_t)z * stride + off];
+      p.merged[off] = a;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1939,10 +1985,16 @@ int wgrad_slices(int N, int K, int R) {
   return (R + rchunk - 1) / rchunk;
 }
 
+int wgrad_tiles(int N, int K, int R) {
+  const int bt = wgrad_tile(N, K, R);
+  return ((N + bt - 1) / bt) * ((K + bt - 1) / bt);
+}
+
 hipError_t launch_wgrad(const float* dy, int ldy, const float* x, int ldx, float* out, int N, int K, int R, int slices,
-                        bool with_bias, hipStream_t s) {
+                        bool with_bias, hipStream_t s, float* merged, unsigned* counters) {
   if (N <= 0 || K <= 0 || R <= 0 || (N & 3) || (K & 3) || (ldy & 3) || (ldx & 3) || slices < 1) return hipErrorInvalidValue;
-  WgradParams p{dy, x, out, R, N, K, ldy, ldx, 0, with_bias ? 1 : 0};
+  if (merged && (slices < 2 || !counters)) return hipErrorInvalidValue;
+  WgradParams p{dy, x, out, R, N, K, ldy, ldx, 0, with_bias ? 1 : 0, merged, counters};
   p.rchunk = slices > 1 ? (((R + slices - 1) / slices + 31) / 32 * 32) : ((R + 31) / 32 * 32);
   const long tiles64 = (long)((N + 63) / 64) * ((K + 63) / 64);
   if (wgrad_tile(N, K, R) == 64) {

@@ -98,8 +98,11 @@ hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStrea
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
 // with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)
+// merged + counters (slices > 1): the slices are summed inside the launch by each tile's last-arriving workgroup into
+// `merged` ([N][K] (+ [N])); counters: wgrad_tiles() zero-initialised words, left at zero
 hipError_t launch_wgrad(const float* dy, int ldy, const float* x, int ldx, float* out, int N, int K, int R, int slices,
-                        bool with_bias, hipStream_t s);
+                        bool with_bias, hipStream_t s, float* merged = nullptr, unsigned* counters = nullptr);
+int wgrad_tiles(int N, int K, int R);
 const char* gemm_instance_name(const GemmParams& p);
 bool gemm_ln_supported(int K);                          // can launch_gemm() fuse a LayerNorm over K columns?   // template instance launch_gemm() will pick
 

@@ -153,6 +153,24 @@ int avsep_op_wgrad_bias_direct(const float* dy, int ldy, const float* x, int ldx
   return AVSEP_OK;
 }
 
+int64_t avsep_op_wgrad_tiles(int N, int K, int R) { return wgrad_tiles(N, K, R); }
+
+int avsep_op_wgrad_merged(const float* dy, int ldy, const float* x, int ldx, float* dwb, float* scratch, uint32_t* counters,
+                          int N, int K, int R, int with_bias, void* stream) {
+  if (!dy || !x || !dwb || N <= 0 || K <= 0 || R <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if ((N & 3) || (K & 3) || (ldy & 3) || (ldx & 3))
+    return fail(AVSEP_EINVAL, "wgrad_merged needs N, K and both row strides to be multiples of 4");
+  const int sl = wgrad_slices(N, K, R);
+  if (sl > 1) {
+    if (!scratch || !counters) return fail(AVSEP_EINVAL, "wgrad_merged needs the scratch floats of avsep_op_wgrad_bias_direct_scratch_floats() "
+                                                         "and avsep_op_wgrad_tiles() zero-initialised counters");
+    TCK(launch_wgrad(dy, ldy, x, ldx, scratch, N, K, R, sl, with_bias != 0, S(stream), dwb, counters));
+  } else {
+    TCK(launch_wgrad(dy, ldy, x, ldx, dwb, N, K, R, 1, with_bias != 0, S(stream)));
+  }
+  return AVSEP_OK;
+}
+
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                              int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,
                              uint64_t drop_seed, void* stream) {

@@ -249,6 +249,22 @@ def test_wgrad_bias_direct_against_float64(dev, R, N, K):
     finally:
         os.environ.pop("AVSEP_WGRAD_TILE", None)
         os.environ.pop("AVSEP_WGRAD_SLICES", None)
+    # the in-launch slice merge (the tile's last-arriving workgroup sums the slices): the SAME bits as the two-launch form,
+    # every time (a race between a slice's stores and the reducer's loads would show as a run-to-run difference)
+    lib = _native.load()
+    ns = lib.avsep_op_wgrad_bias_direct_scratch_floats(N, K, R)
+    cnt = torch.zeros(max(int(lib.avsep_op_wgrad_tiles(N, K, R)), 1), dtype=torch.int32, device=dev)
+    for with_bias in (1, 0):
+        for _ in range(6):
+            out = torch.full((N * K + N,), float("nan"), device=dev)
+            scratch = torch.full((max(ns, 1),), float("nan"), device=dev)
+            rc = lib.avsep_op_wgrad_merged(dy.data_ptr(), N, x.data_ptr(), K, out.data_ptr(), scratch.data_ptr() if ns else None,
+                                           cnt.data_ptr(), N, K, R, with_bias, st)
+            assert rc == 0, lib.avsep_last_error()
+            assert torch.equal(out[:N * K].view(N, K), variants["product"][0])
+            if with_bias:
+                assert torch.equal(out[N * K:], variants["product"][1])
+            assert int(cnt.abs().sum()) == 0                    # every counter is back at zero
     tol = 3e-7 * math.sqrt(R)                              # fp32 accumulation over R rows, relative to the largest entry
     for name, (gw, gb) in variants.items():
         assert torch.isfinite(gw).all() and torch.isfinite(gb).all(), name
