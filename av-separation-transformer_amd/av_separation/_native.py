@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "avsep_op_wgrad_direct", "avsep_op_wgrad_bias_direct_scratch_floats", "avsep_op_wgrad_bias_direct", "avsep_op_transpose_many",
     "avsep_op_bn_stats", "avsep_op_bn_apply", "avsep_op_bn_bwd_sums", "avsep_op_bn_bwd_dx", "avsep_op_avgpool_fwd", "avsep_op_avgpool_bwd",
     "avsep_op_interp_linear_bwd", "avsep_op_layernorm_bwd", "avsep_op_layernorm_bwd_res", "avsep_op_linear_drop",
-    "avsep_op_relu_dropout_bwd", "avsep_op_wgrad_tiles", "avsep_op_wgrad_merged",
+    "avsep_op_relu_dropout_bwd",
 )
 
 
@@ -123,9 +123,10 @@ def _open(path):
     lib.avsep_op_wgrad_bias_direct_scratch_floats.argtypes = [i, i, i]
     lib.avsep_op_wgrad_bias_direct_scratch_floats.restype = C.c_int64
     lib.avsep_op_wgrad_bias_direct.argtypes = [fp, i, fp, i, fp, fp, i, i, i, p]
-    lib.avsep_op_wgrad_tiles.argtypes = [i, i, i]
-    lib.avsep_op_wgrad_tiles.restype = C.c_int64
-    lib.avsep_op_wgrad_merged.argtypes = [fp, i, fp, i, fp, fp, fp, i, i, i, i, p]
+    if hasattr(lib, "avsep_op_wgrad_merged"):       # developer build only
+        lib.avsep_op_wgrad_tiles.argtypes = [i, i, i]
+        lib.avsep_op_wgrad_tiles.restype = C.c_int64
+        lib.avsep_op_wgrad_merged.argtypes = [fp, i, fp, i, fp, fp, fp, i, i, i, i, p]
     lib.avsep_op_transpose_many.argtypes = [p, i, i, i, p]
     lib.avsep_op_bn_stats.argtypes = [fp, fp, fp, fp, i, i, p]
     lib.avsep_op_bn_apply.argtypes = [fp, fp, fp, fp, fp, fp, fp, i, i, f, i, p]

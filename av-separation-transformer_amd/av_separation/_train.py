@@ -278,41 +278,8 @@ def _wgrad(dyt, xt):
     return dw
 
 
-# Ticket counters of the in-launch slice merge (avsep_op_wgrad_merged): zero when created, left at zero by every launch;
-# the weight-gradient launches of one device follow each other on one stream (the main one, or the side stream of
-# SIDE_STREAM_WGRAD), so one buffer per (device, stream) serves them all.
-MERGED_WGRAD = True
-_WG_CNT = {}
-
-
-def _wgrad_counters(t, need):
-    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
-    c = _WG_CNT.get(key)
-    if c is None or c.numel() < need:
-        c = _WG_CNT[key] = torch.zeros(max(int(need), 4096), dtype=torch.int32, device=t.device)
-    return c
-
-
-def _wgrad_merged(dy, x, with_bias):
-    """dW [N, K] (+ db [N]) with the split contraction's slices summed inside the launch (no sum_slices launch)."""
-    R, N = dy.shape
-    K = x.shape[1]
-    lib = _lib()
-    buf = torch.empty(N * K + (N if with_bias else 0), device=dy.device)
-    ns = lib.avsep_op_wgrad_bias_direct_scratch_floats(N, K, R)
-    scratch = torch.empty(ns, device=dy.device) if ns else None
-    cnt = _wgrad_counters(dy, lib.avsep_op_wgrad_tiles(N, K, R)) if ns else None
-    _ck(lib.avsep_op_wgrad_merged(dy.data_ptr(), N, x.data_ptr(), K, buf.data_ptr(), scratch.data_ptr() if ns else None,
-                                  cnt.data_ptr() if ns else None, N, K, R, 1 if with_bias else 0, _st(dy)), "wgrad_merged")
-    if with_bias:
-        return buf[:N * K].view(N, K), buf[N * K:]
-    return buf.view(N, K)
-
-
 def _wgrad_direct(dy, x):
     """dW [N, K] = dY^T X from the row-major tensors themselves (k-major wgrad kernel; N, K multiples of 4)."""
-    if MERGED_WGRAD and dy.is_cuda:
-        return _wgrad_merged(dy, x, False)
     R, N = dy.shape
     K = x.shape[1]
     lib = _lib()
@@ -326,8 +293,6 @@ def _wgrad_direct(dy, x):
 
 def _wgrad_bias_direct(dy, x):
     """(dW [N, K], db [N]) from one launch: views of one buffer (the bias gradient rides the weight-gradient kernel)."""
-    if MERGED_WGRAD and dy.is_cuda:
-        return _wgrad_merged(dy, x, True)
     R, N = dy.shape
     K = x.shape[1]
     lib = _lib()

@@ -210,7 +210,10 @@ int avsep_op_wgrad_direct(const float* dy, int ldy, const float* x, int ldx, flo
 int64_t avsep_op_wgrad_bias_direct_scratch_floats(int N, int K, int R);
 int avsep_op_wgrad_bias_direct(const float* dy, int ldy, const float* x, int ldx, float* dwb, float* scratch, int N,
                                int K, int R, void* stream);
-/* The same gradients (with_bias = 0: dwb holds only the N*K weight gradients) with the split contraction's slices summed
+#ifdef AVSEP_DEV
+/* Developer build only: measured 12 % slower on the training step than the two-launch form (every one of a launch's ~1000
+ * workgroups pays an agent-scope release of 16 KB of freshly written partials, 256 KB of slices per tile for the reducer).
+ * The same gradients (with_bias = 0: dwb holds only the N*K weight gradients) with the split contraction's slices summed
  * INSIDE the launch: the workgroup that arrives last at a tile's ticket counter adds the slices in slice order -- the values
  * of avsep_op_wgrad_(bias_)direct bit for bit, one launch instead of two.  scratch: the floats
  * avsep_op_wgrad_bias_direct_scratch_floats() asks for (0 = no split, counters unused); counters: avsep_op_wgrad_tiles()
@@ -218,6 +221,7 @@ int avsep_op_wgrad_bias_direct(const float* dy, int ldy, const float* x, int ldx
 int64_t avsep_op_wgrad_tiles(int N, int K, int R);
 int avsep_op_wgrad_merged(const float* dy, int ldy, const float* x, int ldx, float* dwb, float* scratch, uint32_t* counters,
                           int N, int K, int R, int with_bias, void* stream);
+#endif  /* AVSEP_DEV */
 
 int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                              int ldo, float* lse, int B, int nhead, int dh, int Lq, int Lk, float qscale, float drop_p,

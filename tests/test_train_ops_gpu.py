@@ -249,9 +249,10 @@ def test_wgrad_bias_direct_against_float64(dev, R, N, K):
     finally:
         os.environ.pop("AVSEP_WGRAD_TILE", None)
         os.environ.pop("AVSEP_WGRAD_SLICES", None)
-    # the in-launch slice merge (the tile's last-arriving workgroup sums the slices): the SAME bits as the two-launch form,
-    # every time (a race between a slice's stores and the reducer's loads would show as a run-to-run difference)
-    lib = _native.load()
+    # the in-launch slice merge of the developer build (the tile's last-arriving workgroup sums the slices; measured slower,
+    # not in the product): the SAME bits as the two-launch form, every time (a race between a slice's stores and the
+    # reducer's loads would show as a run-to-run difference)
+    lib = dev_lib
     ns = lib.avsep_op_wgrad_bias_direct_scratch_floats(N, K, R)
     cnt = torch.zeros(max(int(lib.avsep_op_wgrad_tiles(N, K, R)), 1), dtype=torch.int32, device=dev)
     for with_bias in (1, 0):
