@@ -3,7 +3,7 @@
 # (PMC passes only, no tracing; eager launches so every kernel is its own dispatch record).
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_mfma; rm -rf $OUT; mkdir -p $OUT
-ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --no-graph --inflight 1 ${BENCH_EXTRA}"
+ARGS="$R/bench.py --steps 20 --warmup 5 --no-cpu --no-profile --rounds 1 --no-graph --inflight 1 ${BENCH_EXTRA}"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/b -- python3 $ARGS > /dev/null 2>&1
 rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/c -- python3 $ARGS > /dev/null 2>&1
