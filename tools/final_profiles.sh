@@ -2,10 +2,13 @@
 # GPU box: produce the judged artefacts for profiles/ (round tag = $1) on ONE build of the PRODUCT library: HBM traffic PMC
 # passes per workload and in-graph kernel statistics (both stamped with the library's build id, both read back by bench.py),
 # then the bench lines, rocprofv3 kernel stats of the same command, matrix-pipe PMC, the other workloads, the training step.
-TAG=${1:-r03}
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
+# Two calls (a GPU call is limited to 20 minutes): `final_profiles.sh r03 a` = the PMC / in-graph passes; copy
+# gpurun_out/final/{pmc_hbm_traffic,graph_kernel_stats}.json into profiles/ and run `final_profiles.sh r03 b` = the bench lines.
+TAG=${1:-r03}; PART=${2:-ab}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
 unset AVSEP_LIB
+if [[ $PART == *a* ]]; then
 # ---- 1. HBM-side traffic (bench.py fills roofline.traffic from it only when the build id matches the loaded library)
 rm -rf $R/gpurun_out/pmc_bench
 bash tools/pmc_bench.sh cfg2 20 5 > $O/${TAG}_pmc_hbm_traffic_cfg2.txt 2>&1
@@ -26,6 +29,8 @@ cp $O/graph_kernel_stats.json $R/profiles/graph_kernel_stats.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu --no-profile --inflight 1 --steps 50 --rounds 1 > /dev/null 2>&1
 python3 $R/tools/trace_step.py $(find $O/kt -name "*kernel_trace.csv") > $O/${TAG}_step_timeline.txt 2>&1; rm -rf $O/kt
 echo "graph stats done"
+fi
+if [[ $PART == *b* ]]; then
 # ---- 3. the bench lines (traffic + in-graph columns now match this build)
 cd $R
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_cfg2_driver_command.json 2>$O/bench.err
@@ -46,4 +51,5 @@ echo "train done"
 cd $R
 AVSEP_SCHEDULE=fork AVSEP_LIB=dev python3 tools/stamps.py cfg2 2>/dev/null | grep " us " > $O/${TAG}_stage_stamps.txt
 timeout -k 10 600 python3 -m pytest tests -m gpu -q > $O/${TAG}_validation.txt 2>&1; tail -2 $O/${TAG}_validation.txt
+fi
 ls -la $O
