@@ -20,11 +20,11 @@ echo "pmc traffic done"
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu --no-profile --steps 100 --warmup 5 --rounds 1 > /dev/null 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv") $O/${TAG}_bench_cfg2_graph_only_kernel_stats.csv; rm -rf $O/kt
-# (two steps in flight: 105 replays + one eager forward of the slot check, counted as 106)
-python3 $R/tools/graph_stats.py $O/${TAG}_bench_cfg2_graph_only_kernel_stats.csv cfg2 106 $O/graph_kernel_stats.json
+# (replays: 105 of the two-in-flight leg + 105 of the one-step-at-a-time leg + one eager forward of the slot check = 211)
+python3 $R/tools/graph_stats.py $O/${TAG}_bench_cfg2_graph_only_kernel_stats.csv cfg2 211 $O/graph_kernel_stats.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload cfg3 --no-cpu --no-profile --steps 10 --warmup 2 --rounds 1 > /dev/null 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv") $O/${TAG}_bench_cfg3_graph_only_kernel_stats.csv; rm -rf $O/kt
-python3 $R/tools/graph_stats.py $O/${TAG}_bench_cfg3_graph_only_kernel_stats.csv cfg3 13 $O/graph_kernel_stats.json
+python3 $R/tools/graph_stats.py $O/${TAG}_bench_cfg3_graph_only_kernel_stats.csv cfg3 25 $O/graph_kernel_stats.json
 cp $O/graph_kernel_stats.json $R/profiles/graph_kernel_stats.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu --no-profile --inflight 1 --steps 50 --rounds 1 > /dev/null 2>&1
 python3 $R/tools/trace_step.py $(find $O/kt -name "*kernel_trace.csv") > $O/${TAG}_step_timeline.txt 2>&1; rm -rf $O/kt
