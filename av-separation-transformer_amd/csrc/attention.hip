@@ -439,6 +439,77 @@ __global__ __launch_bounds__(256, QT == 4 ? 2 : DROP ? 1 : (QT == 2 ? 3 : 4)) vo
   }
 }
 
+// One 16-query tile of one (clip, head) against all (<= 16*NKT) keys: everything the short-sequence kernels share.  On return
+// lane (c, g) holds the UNNORMALISED O[query c][4*(4g+r) + blk] in acc[blk][r] and its partial softmax denominator in lrun.
+template <int NB, int NKT>
+__device__ __forceinline__ void attn_short_tile(const float* __restrict__ qb, const float* __restrict__ kb,
+                                                const float* __restrict__ vb, int ldq, int ldk, int ldv, int Lq, int Lk,
+                                                int qt, int c, int g, f32x4 (&acc)[NB], float& lrun) {
+  const int qrow = min(qt * 16 + c, Lq - 1);
+  f32x4 qf[NB], kf[NKT][NB], vf[NKT][4];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) qf[s] = *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g);
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int krow = min(kt * 16 + c, Lk - 1);
+#pragma unroll
+    for (int s = 0; s < NB; ++s) kf[kt][s] = *reinterpret_cast<const f32x4*>(kb + (size_t)krow * ldk + 16 * s + 4 * g);
+  }
+  static_assert(NB == 4, "V fragment = one float4 per key row");
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int vrow = min(kt * 16 + 4 * g + r, Lk - 1);
+      vf[kt][r] = *reinterpret_cast<const f32x4*>(vb + (size_t)vrow * ldv + NB * c);
+    }
+  // Nothing may move across this point: hipcc otherwise sinks most of the 36 loads between the MFMAs that use them (55 VGPRs,
+  // a dozen dependent memory waits per wave -- the assembly of round 2's kernel), and the whole point of this kernel is ONE
+  // memory round trip with every load in flight.
+  __builtin_amdgcn_sched_barrier(0);
+
+  // All scores at once: NKT independent accumulators, MFMAs interleaved across tiles so the 40-cycle
+  // dependent-accumulator latency never stalls the pipe; then ONE exact softmax over the <= 64 keys held in
+  // registers (row max, exp, row sum -- the order nn.MultiheadAttention itself uses), then P V.
+  f32x4 st[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NB; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][s][j], qf[s][j], st[kt], 0, 0, 0);
+  float mrow = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      st[kt][r] = key < Lk ? st[kt][r] : -INFINITY;
+      mrow = fmaxf(mrow, st[kt][r]);
+    }
+  mrow = rows_max(mrow);
+  lrun = 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      st[kt][r] = exp_neg(st[kt][r] - mrow);
+      lrun += st[kt][r];
+    }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][blk], st[kt][r], acc[blk], 0, 0, 0);
+}
+
 // Short-sequence specialisation (49 <= Lk <= 64, dh = 64: the 1 s @ 8 kHz clips of BASELINE configs 1/2, T = 63
 // audio frames / N = 50 lip frames): all NKT = 4 key tiles of K and V are loaded before the first MFMA, so the
 // wave pays ONE memory round trip instead of one per tile (the generic kernel's 1-tile prefetch leaves a ~4 us
@@ -474,66 +545,9 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnProblem 
   const float* vb = v + (size_t)b * Lk * ldv + h * DH;
   float* ob = o + (size_t)b * Lq * ldo + h * DH;
 
-  const int qrow = min(qt * 16 + c, Lq - 1);
-  f32x4 qf[NB], kf[NKT][NB], vf[NKT][4];
-#pragma unroll
-  for (int s = 0; s < NB; ++s) qf[s] = *reinterpret_cast<const f32x4*>(qb + (size_t)qrow * ldq + 16 * s + 4 * g);
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    const int krow = min(kt * 16 + c, Lk - 1);
-#pragma unroll
-    for (int s = 0; s < NB; ++s) kf[kt][s] = *reinterpret_cast<const f32x4*>(kb + (size_t)krow * ldk + 16 * s + 4 * g);
-  }
-  static_assert(NB == 4, "V fragment = one float4 per key row");
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int vrow = min(kt * 16 + 4 * g + r, Lk - 1);
-      vf[kt][r] = *reinterpret_cast<const f32x4*>(vb + (size_t)vrow * ldv + NB * c);
-    }
-
-  // All scores at once: NKT independent accumulators, MFMAs interleaved across tiles so the 40-cycle
-  // dependent-accumulator latency never stalls the pipe; then ONE exact softmax over the <= 64 keys held in
-  // registers (row max, exp, row sum -- the order nn.MultiheadAttention itself uses), then P V.
-  f32x4 st[NKT];
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < NB; ++s)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][s][j], qf[s][j], st[kt], 0, 0, 0);
-  float mrow = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kt * 16 + 4 * g + r;
-      st[kt][r] = key < Lk ? st[kt][r] : -INFINITY;
-      mrow = fmaxf(mrow, st[kt][r]);
-    }
-  mrow = rows_max(mrow);
-  float lrun = 0.0f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      st[kt][r] = exp_neg(st[kt][r] - mrow);
-      lrun += st[kt][r];
-    }
   f32x4 acc[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int blk = 0; blk < NB; ++blk)
-        acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r][blk], st[kt][r], acc[blk], 0, 0, 0);
+  float lrun;
+  attn_short_tile<NB, NKT>(qb, kb, vb, ldq, ldk, ldv, Lq, Lk, qt, c, g, acc, lrun);
   lrun = rows_sum(lrun);
   const float inv = 1.0f / lrun;
   const int qo = qt * 16 + c;
@@ -542,6 +556,105 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnProblem 
     for (int r = 0; r < 4; ++r)
       *reinterpret_cast<f32x4*>(ob + (size_t)qo * ldo + NB * (4 * g + r)) =
           f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
+  }
+}
+
+// Short-sequence attention AND the output projection behind it in one launch (round 3):
+//     x[rows of the tile] += softmax(q k^T) v  W_o^T + b_o
+// i.e. the `self_attn` / `cross_attn` call of a pre-norm block with its out_proj and the residual add (model.py:48-52 via
+// nn.MultiheadAttention, 168-170).  One workgroup per (clip, 16-query tile); wavefront w computes head w exactly as
+// attention_short_kernel does (attn_short_tile), parks its 16 x 64 slice of O in a swizzled LDS tile [16][d], and after one
+// barrier the same wavefront computes the 64 output columns [64w, 64w+64) of the projection over K = d: A fragments from the
+// LDS tile, W_o fragments straight from L2 through a register ring (every wave needs different rows of W_o, so there is
+// nothing for an LDS stage to share), bias + residual in the epilogue, in place on x.
+// Saves, per layer and branch, the attention launch's 128 workgroups on half of the chip, the kernel boundary, the round trip
+// of O through memory and the 504-workgroup projection launch.  The MFMAs see the operands in the order of
+// attention_short_kernel followed by gemm_kernel (k = 16s + 4q' + j: s outer, j, then the lane quarter inside the MFMA), and
+// the epilogue adds bias then residual like gemm_kernel's: BIT-IDENTICAL to the two launches
+// (tests/test_gpu_parity.py::test_op_attention_proj_equals_two_launches).
+struct AttnProjParams {
+  const float *q, *k, *v;     // head h at column offset 64 h
+  int ldq, ldk, ldv;
+  const float* wo;            // [d][d] (nn.Linear layout: row n = output column, K contiguous)
+  const float* bo;            // [d] or null
+  float* x;                   // [B*Lq][d]: residual in, result out
+  int B, Lq, Lk;
+};
+
+template <int NH>
+__global__ __launch_bounds__(64 * NH) void attn_proj_kernel(const AttnProjParams p) {
+  constexpr int NB = 4, DH = 64, D = DH * NH, D16 = D / 16, P = D16 < 6 ? D16 : 6;
+  __shared__ __attribute__((aligned(16))) float Os[16 * D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;       // wave = head, later = 64-column group of the projection
+  const int c = lane & 15, g = lane >> 4;
+  const int nqt = (p.Lq + 15) >> 4;
+  const int b = blockIdx.x / nqt, qt = blockIdx.x - b * nqt;
+  {
+    const float* qb = p.q + (size_t)b * p.Lq * p.ldq + wave * DH;
+    const float* kb = p.k + (size_t)b * p.Lk * p.ldk + wave * DH;
+    const float* vb = p.v + (size_t)b * p.Lk * p.ldv + wave * DH;
+    f32x4 acc[NB];
+    float lrun;
+    attn_short_tile<NB, 4>(qb, kb, vb, p.ldq, p.ldk, p.ldv, p.Lq, p.Lk, qt, c, g, acc, lrun);
+    lrun = rows_sum(lrun);
+    const float inv = 1.0f / lrun;
+    // O[query c][64 wave + 4 (4g + r) + blk] = acc[blk][r] * inv: 16-byte slot 16 wave + 4g + r of row c, XOR-swizzled by the row
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(Os + c * D + (((16 * wave + 4 * g + r) ^ c) << 2)) =
+          f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
+  }
+  // ---- output projection: this wave's columns n0 .. n0 + 63, four 16-column MFMA blocks, K = D
+  const int fr = c, fq = g;                         // fragment row (query / W_o row inside a block), k quarter
+  const int n0 = DH * wave;
+  const float* wsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wsrc[j] = p.wo + (size_t)(n0 + 16 * j + fr) * D + 4 * fq;
+  f32x4 wr[P][4];
+#pragma unroll
+  for (int s = 0; s < P; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[s][j] = *reinterpret_cast<const f32x4*>(wsrc[j] + 16 * s);
+  f32x4 acc2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                  // every head's O slice is in the tile
+#pragma unroll
+  for (int s = 0; s < D16; ++s) {
+    const f32x4 fa = *reinterpret_cast<const f32x4*>(Os + fr * D + (((4 * s + fq) ^ fr) << 2));
+    f32x4 fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = wr[s % P][j];
+    if (s + P < D16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wr[s % P][j] = *reinterpret_cast<const f32x4*>(wsrc[j] + 16 * (s + P));
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][cc], fa[cc], acc2[j], 0, 0, 0);   // D^T like gemm_kernel
+  }
+  // ---- epilogue (gemm_kernel's fast path with a residual): all loads, then arithmetic, then stores
+  const int qo = qt * 16 + fr;
+  const int mrow = min(qo, p.Lq - 1);
+  float* xr = p.x + ((size_t)b * p.Lq + mrow) * D + n0 + 4 * fq;
+  f32x4 bv[4], rv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bv[j] = p.bo ? *reinterpret_cast<const f32x4*>(p.bo + n0 + 16 * j + 4 * fq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rv[j] = *reinterpret_cast<const f32x4*>(xr + 16 * j);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = p.bo ? acc2[j][e] + bv[j][e] : acc2[j][e];
+      rv[j][e] = t + rv[j][e];
+    }
+  if (qo < p.Lq) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(xr + 16 * j) = rv[j];
   }
 }
 
@@ -659,5 +772,29 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
   }
   AVSEP_ATT(1) AVSEP_ATT(2) AVSEP_ATT(3) AVSEP_ATT(4) AVSEP_ATT(5) AVSEP_ATT(6) AVSEP_ATT(7) AVSEP_ATT(8)
 #undef AVSEP_ATT
+  return hipGetLastError();
+}
+
+// ---- attention + output projection + residual in one launch (attn_proj_kernel): dh = 64, 49..64 keys, d = 64 nhead <= 512
+bool attn_proj_supported(int nhead, int dh, int Lk) {
+  return short_ok(dh, Lk) && nhead >= 1 && nhead <= 8 && !dev_env("AVSEP_NO_ATTN_PROJ");   // (developer A/B switch)
+}
+const char* attn_proj_instance_name(int nhead) {
+  static thread_local char buf[32];
+  snprintf(buf, sizeof buf, "attn_proj_kernel<%d>", nhead);
+  return buf;
+}
+hipError_t launch_attn_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
+                            const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s) {
+  if (!attn_proj_supported(nhead, dh, Lk)) return hipErrorNotSupported;
+  if (B <= 0 || Lq <= 0 || ((ldq | ldk | ldv) & 3)) return hipErrorInvalidValue;
+  const AttnProjParams p{q, k, v, ldq, ldk, ldv, wo, bo, x, B, Lq, Lk};
+  const dim3 grid((unsigned)(B * ((Lq + 15) / 16)));
+  switch (nhead) {
+#define AVSEP_AP(NH_) case NH_: hipLaunchKernelGGL((attn_proj_kernel<NH_>), grid, dim3(64 * NH_), 0, s, p); break;
+    AVSEP_AP(1) AVSEP_AP(2) AVSEP_AP(3) AVSEP_AP(4) AVSEP_AP(5) AVSEP_AP(6) AVSEP_AP(7) AVSEP_AP(8)
+#undef AVSEP_AP
+    default: return hipErrorNotSupported;
+  }
   return hipGetLastError();
 }

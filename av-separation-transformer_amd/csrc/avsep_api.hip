@@ -371,6 +371,26 @@ int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk
                   [&] { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, s); });
 }
 
+GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
+                         int M, int N, int act);
+
+// x += softmax(q k^T) v W_o^T + b_o: one launch for short sequences (attn_proj_kernel), else attention into `att` and the
+// projection GEMM with its residual epilogue
+int run_attention_proj(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* att,
+                       const float* wo, const float* bo, float* x, int B, int Lq, int Lk, hipStream_t s) {
+  const int d = c->d, M = B * Lq;
+  if (attn_proj_supported(c->h, c->dh, Lk)) {
+    const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh + 2.0 * M * (double)d * d;
+    const double bytes = 4.0 * B * d * (1.0 * Lq + 2.0 * Lk) + 4.0 * d * d + 8.0 * M * d;
+    return profiled(c, attn_proj_instance_name(c->h), flops, bytes, s,
+                    [&] { return launch_attn_proj(q, ldq, k, ldk, v, ldv, wo, bo, x, B, c->h, c->dh, Lq, Lk, s); });
+  }
+  RCK(run_attention(c, q, ldq, k, ldk, v, ldv, att, d, B, Lq, Lk, s));
+  GemmParams po = linear_params(att, d, wo, d, bo, x, d, M, d, ACT_NONE);
+  po.R = x; po.ldr = d; po.rperiod = 0;
+  return run_gemm(c, po, s);
+}
+
 // y = act( LayerNorm(x) W^T + b ).  At small M the LayerNorm is fused into the GEMM's A staging (one launch
 // less per LayerNorm, 13 per forward); once the problem is big enough for 64x64 tiles to fill the chip the
 // fused kernel's 32x32 tiles would sit at the L2 feed limit, so the stand-alone LayerNorm + big-tile GEMM wins.
@@ -467,10 +487,7 @@ int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* 
                   int Lseq, hipStream_t s) {
   const int d = c->d, M = B * Lseq;
   RCK(run_ln_linear(c, x, L.g1, L.be1, ln, L.wqkv, L.bqkv, qkv, M, 3 * d, ACT_NONE, s));   // norm1 -> in_proj
-  RCK(run_attention(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, d, B, Lseq, Lseq, s));
-  GemmParams po = linear_params(att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
-  po.R = x; po.ldr = d; po.rperiod = 0;
-  RCK(run_gemm(c, po, s));
+  RCK(run_attention_proj(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, L.wo, L.bo, x, B, Lseq, Lseq, s));
   RCK(run_ln_linear(c, x, L.g2, L.be2, ln, L.w1, L.b1, ffn, M, 4 * d, ACT_RELU, s));        // norm2 -> linear1
   GemmParams p2 = linear_params(ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
   p2.R = x; p2.ldr = d; p2.rperiod = 0;
@@ -637,10 +654,7 @@ int fusion_layer(avsep_ctx* c, const Workspace& w, float* x, int B, int T, int i
   const FusLayerW& L = c->f_layers[i];
   RCK(run_ln_linear(c, x, L.g1, L.be1, w.ln, L.wq, L.bq, w.f_q, M, d, ACT_NONE, s));       // norm1 -> q proj
   const float* kk = w.kv_all + (size_t)i * 2 * d;
-  RCK(run_attention(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, d, B, T, T, s));
-  GemmParams po = linear_params(w.att, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
-  po.R = x; po.ldr = d;
-  RCK(run_gemm(c, po, s));
+  RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s));
   RCK(run_ln_linear(c, x, L.g2, L.be2, w.ln, L.w1, L.b1, w.ffn, M, 4 * d, ACT_GELU, s));   // norm2 -> ff.0
   GemmParams p2 = linear_params(w.ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
   p2.R = x; p2.ldr = d;
@@ -1363,6 +1377,15 @@ int avsep_op_stft_mag(const float* audio, const float* basis, float* spec, int B
   p.amode = AMODE_FRAMES; p.T = T; p.frame_hop = hop; p.frame_len = L; p.mag_F = F;
   p.act = ACT_NONE;
   HCK(launch_gemm(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
+                            const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, void* stream) {
+  if (!q || !k || !v || !wo || !x) return fail(AVSEP_EINVAL, "null pointer");
+  if (!attn_proj_supported(nhead, dh, Lk))
+    return fail(AVSEP_EINVAL, "fused attention + projection needs dh = 64, 49..64 keys and at most 8 heads");
+  HCK(launch_attn_proj(q, ldq, k, ldk, v, ldv, wo, bo, x, B, nhead, dh, Lq, Lk, reinterpret_cast<hipStream_t>(stream)));
   return AVSEP_OK;
 }
 

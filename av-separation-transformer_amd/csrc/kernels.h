@@ -118,6 +118,12 @@ hipError_t launch_attention(const float* q, int ldq, const float* k, int ldk, co
 // launches on `s`
 struct AttnProblem { const float *q, *k, *v; float* o; int ldq, ldk, ldv, ldo, B, Lq, Lk; };
 hipError_t launch_attention_pair(const AttnProblem& a, const AttnProblem& b, int nhead, int dh, hipStream_t s);
+// x += softmax(q k^T) v W_o^T + b_o in ONE launch (short sequences: dh = 64, 49..64 keys, nhead <= 8, d = 64 nhead);
+// hipErrorNotSupported otherwise (callers then launch attention and the projection GEMM separately)
+bool attn_proj_supported(int nhead, int dh, int Lk);
+const char* attn_proj_instance_name(int nhead);
+hipError_t launch_attn_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
+                            const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s);
 bool attention_pair_merges(int dh, int Lk_a, int Lk_b);                          // does the pair become ONE launch?
 // the kernel instance launch_attention() picks for an inference call, spelled as rocprofv3 prints it
 const char* attention_instance_name(int dh, int Lq, int Lk, int B, int nhead);

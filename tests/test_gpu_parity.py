@@ -619,6 +619,51 @@ def test_op_attention_lds_variant_is_bit_identical(lib, devlib, dev, B, h, Lq, L
         assert torch.equal(outs[0], o)
 
 
+@pytest.mark.parametrize("B,h,Lq,Lk,bias", [(32, 4, 63, 63, True), (32, 4, 50, 50, True), (16, 4, 63, 63, True), (3, 2, 20, 64, False),
+                                            (2, 8, 49, 49, True), (1, 1, 17, 50, True), (5, 3, 64, 57, True)])
+def test_op_attention_proj_equals_two_launches(lib, dev, B, h, Lq, Lk, bias):
+    """attn_proj_kernel: attention + out_proj + residual of a pre-norm block in ONE launch (short sequences).  The matrix
+    cores see the operands in the order of attention_short_kernel followed by gemm_kernel and the epilogue adds bias then
+    residual like the GEMM's, so x equals avsep_op_attention followed by avsep_op_linear(residual = x) bit for bit -- for the
+    packed self-attention layout (q, k, v columns of one (M, 3d) tensor) and the cross-attention one (separate q, packed k|v),
+    ragged last query tiles, and nothing is written outside x."""
+    from av_separation._native import check
+    dh = 64
+    d = h * dh
+    Mq, Mk = B * Lq, B * Lk
+    self_attn = Lq == Lk
+    if self_attn:
+        qkv = t(seeded.tensor(41, "qkv", (Mq, 3 * d), -1.5, 1.5), dev)
+        qp, kp, vp, ldq, ldk = qkv.data_ptr(), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, 3 * d, 3 * d
+    else:
+        q = t(seeded.tensor(41, "q", (Mq, d), -1.5, 1.5), dev)
+        kv = t(seeded.tensor(41, "kv", (Mk, 2 * d), -1.5, 1.5), dev)
+        qp, kp, vp, ldq, ldk = q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 4 * d, d, 2 * d
+    wo = t(seeded.tensor(41, "wo", (d, d), -0.2, 0.2), dev)
+    bo = t(seeded.tensor(41, "bo", (d,), -1, 1), dev)
+    x0 = t(seeded.tensor(41, "x", (Mq, d), -2, 2), dev)
+    att = torch.full((Mq, d), float("nan"), device=dev)
+    check(lib.avsep_op_attention(qp, ldq, kp, ldk, vp, ldk, att.data_ptr(), d, B, h, dh, Lq, Lk, _stream()))
+    want = x0.clone()
+    check(lib.avsep_op_linear(att.data_ptr(), wo.data_ptr(), bo.data_ptr() if bias else None, want.data_ptr(), want.data_ptr(),
+                              Mq, d, d, 0, _stream()))
+    buf = torch.full((Mq * d + 256,), float("nan"), device=dev)
+    buf[:Mq * d] = x0.reshape(-1)
+    check(lib.avsep_op_attention_proj(qp, ldq, kp, ldk, vp, ldk, wo.data_ptr(), bo.data_ptr() if bias else None, buf.data_ptr(),
+                                      B, h, dh, Lq, Lk, _stream()))
+    assert torch.isfinite(want).all()
+    assert torch.equal(buf[:Mq * d].view(Mq, d), want)
+    assert torch.isnan(buf[Mq * d:]).all()
+
+
+def test_op_attention_proj_rejects_long_sequences(lib, dev):
+    y = torch.empty(64 * 1024, device=dev)
+    p_ = y.data_ptr()
+    assert lib.avsep_op_attention_proj(p_, 256, p_, 256, p_, 256, p_, None, p_, 1, 4, 64, 251, 251, _stream()) == -1
+    assert lib.avsep_op_attention_proj(p_, 256, p_, 256, p_, 256, p_, None, p_, 1, 4, 32, 63, 63, _stream()) == -1
+    assert b"49..64" in lib.avsep_last_error()
+
+
 @pytest.mark.parametrize("B,N,T,d", [(2, 10, 32, 64), (2, 50, 63, 256), (1, 12, 5, 32), (3, 1, 7, 64),
                                      (1, 50, 501, 512), (2, 75, 251, 512)])
 def test_op_interp_linear(lib, dev, B, N, T, d):
