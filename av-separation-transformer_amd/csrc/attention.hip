@@ -463,10 +463,9 @@ __device__ __forceinline__ void attn_short_tile(const float* __restrict__ qb, co
       const int vrow = min(kt * 16 + 4 * g + r, Lk - 1);
       vf[kt][r] = *reinterpret_cast<const f32x4*>(vb + (size_t)vrow * ldv + NB * c);
     }
-  // Nothing may move across this point: hipcc otherwise sinks most of the 36 loads between the MFMAs that use them (55 VGPRs,
-  // a dozen dependent memory waits per wave -- the assembly of round 2's kernel), and the whole point of this kernel is ONE
-  // memory round trip with every load in flight.
-  __builtin_amdgcn_sched_barrier(0);
+  // (hipcc sinks most of these 36 loads between the MFMAs that use them -- 55 VGPRs, a dozen counted waits.  Pinning them in
+  // front with a scheduling barrier, "one round trip with every load in flight", was measured: 7.3 us instead of 6.7 for the
+  // 32-clip launch (profiles/r03_ab_attention_proj.txt).  The compiler's order stays.)
 
   // All scores at once: NKT independent accumulators, MFMAs interleaved across tiles so the 40-cycle
   // dependent-accumulator latency never stalls the pipe; then ONE exact softmax over the <= 64 keys held in
@@ -559,7 +558,8 @@ __global__ __launch_bounds__(256) void attention_short_kernel(const AttnProblem 
   }
 }
 
-// Short-sequence attention AND the output projection behind it in one launch (round 3):
+#ifdef AVSEP_DEV
+// Short-sequence attention AND the output projection behind it in one launch (round 3, developer experiment):
 //     x[rows of the tile] += softmax(q k^T) v  W_o^T + b_o
 // i.e. the `self_attn` / `cross_attn` call of a pre-norm block with its out_proj and the residual add (model.py:48-52 via
 // nn.MultiheadAttention, 168-170).  One workgroup per (clip, 16-query tile); wavefront w computes head w exactly as
@@ -657,6 +657,7 @@ __global__ __launch_bounds__(64 * NH) void attn_proj_kernel(const AttnProjParams
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(xr + 16 * j) = rv[j];
   }
 }
+#endif  // AVSEP_DEV
 
 }  // namespace
 
@@ -776,8 +777,12 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
 }
 
 // ---- attention + output projection + residual in one launch (attn_proj_kernel): dh = 64, 49..64 keys, d = 64 nhead <= 512
+// Developer experiment (AVSEP_ATTN_PROJ=1): bit-identical to the two launches and SLOWER -- 15.4 us alone against 6.7 + 6.4, the
+// step 0.365 vs 0.355 ms with two in flight and 0.463 vs 0.437 one at a time (profiles/r03_ab_attention_proj.txt).  With 16
+// rows per workgroup the projection is 512 waves chasing fragment-shaped W_o loads (16 rows x 64 B per instruction) through
+// L2, where the GEMM launch puts 2016 waves behind full-row staged tiles.
 bool attn_proj_supported(int nhead, int dh, int Lk) {
-  return short_ok(dh, Lk) && nhead >= 1 && nhead <= 8 && !dev_env("AVSEP_NO_ATTN_PROJ");   // (developer A/B switch)
+  return short_ok(dh, Lk) && nhead >= 1 && nhead <= 8 && dev_env("AVSEP_ATTN_PROJ") != nullptr;
 }
 const char* attn_proj_instance_name(int nhead) {
   static thread_local char buf[32];
@@ -786,7 +791,10 @@ const char* attn_proj_instance_name(int nhead) {
 }
 hipError_t launch_attn_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
                             const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, hipStream_t s) {
-  if (!attn_proj_supported(nhead, dh, Lk)) return hipErrorNotSupported;
+#ifndef AVSEP_DEV
+  return hipErrorNotSupported;
+#else
+  if (!(short_ok(dh, Lk) && nhead >= 1 && nhead <= 8)) return hipErrorNotSupported;
   if (B <= 0 || Lq <= 0 || ((ldq | ldk | ldv) & 3)) return hipErrorInvalidValue;
   const AttnProjParams p{q, k, v, ldq, ldk, ldv, wo, bo, x, B, Lq, Lk};
   const dim3 grid((unsigned)(B * ((Lq + 15) / 16)));
@@ -797,4 +805,5 @@ hipError_t launch_attn_proj(const float* q, int ldq, const float* k, int ldk, co
     default: return hipErrorNotSupported;
   }
   return hipGetLastError();
+#endif
 }

@@ -1380,14 +1380,17 @@ int avsep_op_stft_mag(const float* audio, const float* basis, float* spec, int B
   return AVSEP_OK;
 }
 
+#ifdef AVSEP_DEV
 int avsep_op_attention_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
                             const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, void* stream) {
   if (!q || !k || !v || !wo || !x) return fail(AVSEP_EINVAL, "null pointer");
-  if (!attn_proj_supported(nhead, dh, Lk))
+  const hipError_t e = launch_attn_proj(q, ldq, k, ldk, v, ldv, wo, bo, x, B, nhead, dh, Lq, Lk, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorNotSupported)
     return fail(AVSEP_EINVAL, "fused attention + projection needs dh = 64, 49..64 keys and at most 8 heads");
-  HCK(launch_attn_proj(q, ldq, k, ldk, v, ldv, wo, bo, x, B, nhead, dh, Lq, Lk, reinterpret_cast<hipStream_t>(stream)));
+  HCK(e);
   return AVSEP_OK;
 }
+#endif  // AVSEP_DEV
 
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream) {
   if (!x || !y || B <= 0 || N <= 0 || T <= 0 || d <= 0) return fail(AVSEP_EINVAL, "bad argument");

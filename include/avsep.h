@@ -144,13 +144,16 @@ int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, co
  * column offset h*dh; out (B,Lq,ldo). */
 int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                        int ldo, int B, int nhead, int dh, int Lq, int Lk, void* stream);
-/* x += softmax(q k^T) v  W_o^T + b_o in ONE launch: the attention core of a pre-norm block with its out_proj and the
+#ifdef AVSEP_DEV
+/* Developer build only (measured slower than the two launches it replaces).
+ * x += softmax(q k^T) v  W_o^T + b_o in ONE launch: the attention core of a pre-norm block with its out_proj and the
  * residual add (nn.MultiheadAttention inside nn.TransformerEncoderLayer, model.py:48-52, and CrossAttentionLayer 168-170)
  * for short sequences -- dh = 64, 49 <= Lk <= 64, nhead <= 8, d = 64 nhead (the 1 s clips of BASELINE configs 1 / 2).
  * q (B*Lq, ldq), k / v (B*Lk, ldk / ldv) with head h at column 64 h, q pre-scaled; wo (d, d), bo (d) or null; x (B*Lq, d)
  * updated in place.  Bit-identical to avsep_op_attention followed by avsep_op_linear(residual = x). */
 int avsep_op_attention_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
                             const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, void* stream);
+#endif  /* AVSEP_DEV */
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream);
 #ifdef AVSEP_DEV
 /* Developer build only (libavsep_hip_dev.so): the paired-launch experiment of round 3, measured slower than the two-stream

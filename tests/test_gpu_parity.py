@@ -621,8 +621,8 @@ def test_op_attention_lds_variant_is_bit_identical(lib, devlib, dev, B, h, Lq, L
 
 @pytest.mark.parametrize("B,h,Lq,Lk,bias", [(32, 4, 63, 63, True), (32, 4, 50, 50, True), (16, 4, 63, 63, True), (3, 2, 20, 64, False),
                                             (2, 8, 49, 49, True), (1, 1, 17, 50, True), (5, 3, 64, 57, True)])
-def test_op_attention_proj_equals_two_launches(lib, dev, B, h, Lq, Lk, bias):
-    """attn_proj_kernel: attention + out_proj + residual of a pre-norm block in ONE launch (short sequences).  The matrix
+def test_op_attention_proj_equals_two_launches(lib, devlib, dev, B, h, Lq, Lk, bias):
+    """(Developer experiment, measured slower.)  attn_proj_kernel: attention + out_proj + residual of a pre-norm block in ONE launch (short sequences).  The matrix
     cores see the operands in the order of attention_short_kernel followed by gemm_kernel and the epilogue adds bias then
     residual like the GEMM's, so x equals avsep_op_attention followed by avsep_op_linear(residual = x) bit for bit -- for the
     packed self-attention layout (q, k, v columns of one (M, 3d) tensor) and the cross-attention one (separate q, packed k|v),
@@ -649,14 +649,15 @@ def test_op_attention_proj_equals_two_launches(lib, dev, B, h, Lq, Lk, bias):
                               Mq, d, d, 0, _stream()))
     buf = torch.full((Mq * d + 256,), float("nan"), device=dev)
     buf[:Mq * d] = x0.reshape(-1)
-    check(lib.avsep_op_attention_proj(qp, ldq, kp, ldk, vp, ldk, wo.data_ptr(), bo.data_ptr() if bias else None, buf.data_ptr(),
+    check(devlib.avsep_op_attention_proj(qp, ldq, kp, ldk, vp, ldk, wo.data_ptr(), bo.data_ptr() if bias else None, buf.data_ptr(),
                                       B, h, dh, Lq, Lk, _stream()))
     assert torch.isfinite(want).all()
     assert torch.equal(buf[:Mq * d].view(Mq, d), want)
     assert torch.isnan(buf[Mq * d:]).all()
 
 
-def test_op_attention_proj_rejects_long_sequences(lib, dev):
+def test_op_attention_proj_rejects_long_sequences(devlib, dev):
+    lib = devlib
     y = torch.empty(64 * 1024, device=dev)
     p_ = y.data_ptr()
     assert lib.avsep_op_attention_proj(p_, 256, p_, 256, p_, 256, p_, None, p_, 1, 4, 64, 251, 251, _stream()) == -1
