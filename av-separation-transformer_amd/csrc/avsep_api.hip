@@ -63,6 +63,8 @@ struct FusLayerW {   // CrossAttentionLayer (model.py:152-164); its K/V rows liv
   float *wq, *bq, *wo, *bo, *w1, *b1, *w2, *b2, *g1, *be1, *g2, *be2;
 };
 
+struct LnxW { float *w, *c1, *c2; };   // operands of the LayerNorm-in-the-epilogue GEMM (kernels.h GemmParams::lnx_c1)
+
 struct Workspace {   // all float*, carved from the caller's buffer
   float *xt, *a_h0, *a_x, *ln, *qkv, *att, *ffn;
   float *act1, *act2, *act3, *pool, *v_x, *v_ln, *v_qkv, *v_att, *v_ffn, *v_up;
@@ -103,6 +105,8 @@ struct avsep_ctx {
   float *wkv_all, *bkv_all;
   std::vector<FusLayerW> f_layers;
   float *fn_g, *fn_b, *d_w1, *d_b1, *d_w2, *d_b2;
+  std::unordered_map<const float*, LnxW> lnx;     // by the packed weight of the linear layer that follows a LayerNorm
+  bool use_lnx = true, lnx_all = false;
   // streams / events for the audio || visual fork-join and graph replay
   int device = 0;                                  // the device the context (arena, streams, events, graphs) lives on
   hipStream_t side = nullptr;                      // eager forwards: the visual branch's stream
@@ -168,6 +172,18 @@ void layout_arena(avsep_ctx* c, F&& take) {
   c->fn_g = take(d); c->fn_b = take(d);
   c->d_w1 = take((size_t)2 * d * d); c->d_b1 = take(2 * d);
   c->d_w2 = take((size_t)S * c->F * 2 * d); c->d_b2 = take((size_t)S * c->F);
+  c->lnx.clear();
+  if (c->use_lnx) {
+    auto site = [&](const float* w, int n) {
+      LnxW x;
+      x.w = take((size_t)n * d); x.c1 = take(n); x.c2 = take(n);
+      if (w) c->lnx[w] = x;
+    };
+    for (auto* v : {&c->a_layers, &c->v_layers})
+      for (auto& L : *v) { site(L.wqkv, 3 * d); site(L.w1, 4 * d); }
+    for (auto& L : c->f_layers) { site(L.wq, d); site(L.w1, 4 * d); }
+    site(c->d_w1, 2 * d);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ raw weights
@@ -391,9 +407,11 @@ int run_attention_proj(avsep_ctx* c, const float* q, int ldq, const float* k, in
   return run_gemm(c, po, s);
 }
 
-// y = act( LayerNorm(x) W^T + b ).  At small M the LayerNorm is fused into the GEMM's A staging (one launch
-// less per LayerNorm, 13 per forward); once the problem is big enough for 64x64 tiles to fill the chip the
-// fused kernel's 32x32 tiles would sit at the L2 feed limit, so the stand-alone LayerNorm + big-tile GEMM wins.
+// y = act( LayerNorm(x) W^T + b ).  At small M the LayerNorm is folded into the GEMM (one launch less per LayerNorm, 13 per
+// forward): algebraically, into the epilogue of a plain GEMM on the raw rows (GemmParams::lnx_c1; round 3) -- the round-2
+// form, statistics and normalisation of a whole-K register slab in front of the first MFMA (gemm_ln_kernel), remains as
+// avsep_op_ln_linear form 1 and behind AVSEP_NO_LNX.  Once the problem is big enough for 64x64 tiles to fill the chip the
+// stand-alone LayerNorm + big-tile GEMM wins.
 int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be, float* ln_buf, const float* W,
                   const float* bias, float* y, int M, int N, int act, hipStream_t s) {
   const int d = c->d;
@@ -405,6 +423,13 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
   p.act = act;
   const long big_tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
   static const bool no_fuse = dev_env("AVSEP_NO_LN_FUSE") != nullptr;   // developer A/B switch
+  if (c->use_lnx && (big_tiles < 1024 || c->lnx_all)) {
+    auto it = c->lnx.find(W);
+    if (it != c->lnx.end()) {
+      p.W = it->second.w; p.bias = nullptr; p.lnx_c1 = it->second.c1; p.lnx_c2 = it->second.c2; p.ln_eps = 1e-5f;
+      return run_gemm(c, p, s);
+    }
+  }
   if (!no_fuse && gemm_ln_supported(d) && big_tiles < 1024) {
     p.ln_gamma = g; p.ln_beta = be; p.ln_eps = 1e-5f;
     return run_gemm(c, p, s);
@@ -886,6 +911,12 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   c->cfg = *cfg;
   c->F = cfg->freq_bins; c->Fp = (int)align_up(cfg->freq_bins, 32); c->d = cfg->d_model; c->h = cfg->nhead;
   c->dh = dh; c->Le = cfg->num_encoder_layers; c->Lf = cfg->num_fusion_layers; c->S = cfg->num_speakers;
+  // LayerNorm -> Linear sites of the d_model <= 256 models run as LayerNorm-in-the-epilogue GEMMs below 1024 64x64 tiles
+  // (+5 % on the cfg2 step, profiles/r03_ab_ln_epilogue.txt).  Large problems and d_model = 512 keep LayerNorm launch +
+  // big-tile GEMM: measured 2.7 % faster there, and every batch size of such a model then computes the same bits.
+  // Developer A/B: AVSEP_NO_LNX=1 restores the in-kernel LayerNorm form of round 2, AVSEP_LNX=all takes every site.
+  c->use_lnx = dev_env("AVSEP_NO_LNX") == nullptr && (gemm_ln_supported(c->d) || dev_env("AVSEP_LNX"));
+  c->lnx_all = dev_env("AVSEP_LNX") && !strcmp(dev_env("AVSEP_LNX"), "all");
   size_t off = 0;
   layout_arena(c, [&](size_t n) { off += align_up(n ? n : 1, 64); return (float*)nullptr; });
   c->arena_floats = off;
@@ -1100,6 +1131,29 @@ int avsep_finalize_weights(avsep_ctx* c, void* stream) try {
   }
   if (!(c->ok_audio || c->ok_visual || c->ok_fusion || c->ok_decoder))
     return fail(AVSEP_ENOWEIGHT, "no stage has a complete set of weights");
+  if (c->use_lnx) {   // W o gamma, its row sums, W beta + b for every LayerNorm -> Linear site (after the packs above, same stream)
+    auto site = [&](const float* w, const float* b, const float* g, const float* be, int n) {
+      auto it = c->lnx.find(w);
+      if (it == c->lnx.end()) return hipErrorInvalidValue;
+      return launch_pack_lnx(w, b, g, be, it->second.w, it->second.c1, it->second.c2, n, d, s);
+    };
+    auto enc = [&](std::vector<EncLayerW>& v) {
+      for (auto& L : v) {
+        HCK(site(L.wqkv, L.bqkv, L.g1, L.be1, 3 * d));
+        HCK(site(L.w1, L.b1, L.g2, L.be2, 4 * d));
+      }
+      return (int)AVSEP_OK;
+    };
+    if (c->ok_audio) RCK(enc(c->a_layers));
+    if (c->ok_visual) RCK(enc(c->v_layers));
+    if (c->ok_fusion) {
+      for (auto& L : c->f_layers) {
+        HCK(site(L.wq, L.bq, L.g1, L.be1, d));
+        HCK(site(L.w1, L.b1, L.g2, L.be2, 4 * d));
+      }
+      if (c->ok_decoder) HCK(site(c->d_w1, c->d_b1, c->fn_g, c->fn_b, 2 * d));
+    }
+  }
   c->finalized = true;
   return AVSEP_OK;
 } catch (...) {
@@ -1332,8 +1386,15 @@ int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, co
     if (!gemm_ln_staged_supported(K)) return fail(AVSEP_EINVAL, "staged LayerNorm form: K is not supported");
     HCK(launch_layernorm_stats(x, scratch, M, K, eps, s));
     p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.ln_stats = scratch;
+  } else if (form == 3) {                // LayerNorm in the epilogue: GEMM on the raw rows against W o gamma
+    if (!scratch) return fail(AVSEP_EINVAL, "form 3 needs N*K + 2*N floats of scratch");
+    if (N % 4) return fail(AVSEP_EINVAL, "form 3: N must be a multiple of 4");
+    float* wp = scratch;
+    float* c1 = scratch + (size_t)N * K;
+    HCK(launch_pack_lnx(w, bias, gamma, beta, wp, c1, c1 + N, N, K, s));
+    p.W = wp; p.bias = nullptr; p.lnx_c1 = c1; p.lnx_c2 = c1 + N; p.ln_eps = eps;
   } else {
-    return fail(AVSEP_EINVAL, "form must be 0, 1 or 2");
+    return fail(AVSEP_EINVAL, "form must be 0, 1, 2 or 3");
   }
   HCK(launch_gemm(p, s));
   return AVSEP_OK;

@@ -271,6 +271,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
   }
 }
 
+// Epilogue of the LayerNorm-in-the-epilogue GEMM (GemmParams::lnx_c1): y = act( rstd (acc - mean c1) + c2 ) with the tile's row
+// statistics in LDS (st[2r] = mean, st[2r+1] = rstd of tile row r).  N % 4 == 0 (checked by the launcher); straight line:
+// loads, arithmetic, stores.
+template <int WBM, int WBN>
+__device__ __forceinline__ void lnx_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], const float* st, int m0, int n0,
+                                             int mw, int nw, int fr, int fq) {
+  f32x4 c1v[WBN], c2v[WBN];
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int n = min(n0 + nw + 16 * j + 4 * fq, p.N - 4);
+    c1v[j] = *reinterpret_cast<const f32x4*>(p.lnx_c1 + n);
+    c2v[j] = *reinterpret_cast<const f32x4*>(p.lnx_c2 + n);
+  }
+  float mu[WBM], rs[WBM];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    mu[i] = st[2 * (mw + 16 * i + fr)];
+    rs[i] = st[2 * (mw + 16 * i + fr) + 1];
+  }
+  f32x4 out[WBM][WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) {
+      f32x4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = rs[i] * (acc[i][j][e] - mu[i] * c1v[j][e]) + c2v[j][e];
+      switch (p.act) {                              // block-uniform
+        case ACT_RELU:
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.0f);
+          break;
+        case ACT_GELU: x = act4_outofline<ACT_GELU>(x); break;
+        case ACT_SIGMOID: x = act4_outofline<ACT_SIGMOID>(x); break;
+        default: break;
+      }
+      out[i][j] = x;
+    }
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) {
+      const int m = m0 + mw + 16 * i + fr, n = n0 + nw + 16 * j + 4 * fq;
+      if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = out[i][j];
+    }
+}
+
 // One K-chunk of MFMAs from the LDS image (shared by the GEMM kernels).
 // PF = false: fragments of a k-step are read right before its MFMAs (what the compiler schedules best for occupancy).
 // PF = true : all fragment reads of step s+1 are issued BEFORE the MFMAs of step s (second register set, pinned with a
@@ -333,7 +380,7 @@ __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int slot) {
 // staged-LayerNorm instances whose LDS image admits three workgroups per CU get the same bound: 128x64 sits at 186
 // without it, and with it spills 24 registers around -- not inside -- the K loop.)
 template <int BM, int BN, int BK, int AMODE, bool PF = false, int RING = 0>
-__global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + BN) * BK <= 6144)) ? 3 : 1) void gemm_kernel(const GemmParams pin) {
+__global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * BK <= 4096 ? 4 : 3) : (PF || (AMODE == AMODE_LN && (BM + BN) * BK <= 6144)) ? 3 : 1) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
   dbg_stamp(p, 0);
   if (p.ksplit > 1) {                      // block-uniform: slice blockIdx.y of the contraction
@@ -398,7 +445,7 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
     a_st[i] = r * BK + ((sslot ^ swz<SLOTS>(r)) << 2);
     int m = m0 + r;
     m = m < p.M ? m : p.M - 1;
-    if (AMODE == AMODE_PLAIN || AMODE == AMODE_LN) {
+    if (AMODE == AMODE_PLAIN || AMODE == AMODE_LN || AMODE == AMODE_LNX) {
       a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;
       a_aux0[i] = a_aux1[i] = 0;
     } else if (AMODE == AMODE_TAPS3) {
@@ -432,7 +479,7 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
   }
 
   const int nk = p.K / BK;
-  const int cpt = (AMODE == AMODE_PLAIN || AMODE == AMODE_LN || AMODE == AMODE_FRAMES) ? nk : (p.Kt / BK);   // chunks per tap
+  const int cpt = (AMODE == AMODE_PLAIN || AMODE == AMODE_LN || AMODE == AMODE_LNX || AMODE == AMODE_FRAMES) ? nk : (p.Kt / BK);   // chunks per tap
   int tap = 0, sub = 0;                                        // (tap, chunk-in-tap) of the NEXT chunk to load
   int kload = 0;                                               // index of the next chunk to load
 
@@ -442,7 +489,7 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
   auto load_chunk = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      if (AMODE == AMODE_PLAIN || AMODE == AMODE_LN) {
+      if (AMODE == AMODE_PLAIN || AMODE == AMODE_LN || AMODE == AMODE_LNX) {
         ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + kload * BK);
       } else if (AMODE == AMODE_TAPS3) {
         // unconditional load from an always-valid address; out-of-sequence taps are zeroed when the chunk is
@@ -474,6 +521,13 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
     }
   };
   // kc = index of the chunk being written (AMODE_LN picks its gamma / beta columns by it)
+  // AMODE_LNX: shifted one-pass sums of this thread's rows (relative to the row's first element, like gemm_ln_kernel)
+  float lx_c[APASS], lx_s1[APASS], lx_s2[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    lx_s1[i] = lx_s2[i] = 0.0f;
+    lx_c[i] = AMODE == AMODE_LNX ? *(a_src[i] - 4 * sslot) : 0.0f;   // the row's first element
+  }
   auto store_chunk = [&](int slot, int buf, int kc) {
     float* a = As + buf * BM * BK;
     float* b = Bs + buf * BN * BK;
@@ -488,6 +542,13 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
       if (AMODE == AMODE_LN) {   // nn.LayerNorm on the way to LDS: the formula (and rounding) of layernorm_kernel
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (v[e] - ln_mu[i]) * ln_rs[i] * g4[e] + b4[e];
+      } else if (AMODE == AMODE_LNX) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dlt = v[e] - lx_c[i];
+          lx_s1[i] += dlt;
+          lx_s2[i] = fmaf(dlt, dlt, lx_s2[i]);
+        }
       } else if (AMODE != AMODE_PLAIN) {
         v = rok[slot][i] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -559,7 +620,30 @@ __global__ __launch_bounds__(256, RING ? 4 : (PF || (AMODE == AMODE_LN && (BM + 
   }
 
   dbg_stamp(p, 2);
-  gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  if (AMODE == AMODE_LNX) {
+    // row statistics: combine the SLOTS lanes that staged a row, park (mean, rstd) per tile row in LDS (free after the loop's
+    // last barrier) for the lanes that hold the row's accumulators
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      float s1 = lx_s1[i], s2 = lx_s2[i];
+#pragma unroll
+      for (int off = SLOTS / 2; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+      }
+      const float inv = 1.0f / (float)p.K;
+      const float m1 = s1 * inv;
+      const float var = fmaxf(s2 * inv - m1 * m1, 0.0f);
+      if (sslot == 0) {
+        lds[2 * (srow + RPP * i)] = lx_c[i] + m1;
+        lds[2 * (srow + RPP * i) + 1] = 1.0f / sqrtf(var + p.ln_eps);
+      }
+    }
+    __syncthreads();
+    lnx_epilogue<WBM, WBN>(p, acc, lds, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  } else {
+    gemm_epilogue<WBM, WBN>(p, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
+  }
   if (p.dbg) {                                                   // block-uniform, diagnostics only
     dbg_stamp(p, 3);
     __builtin_amdgcn_s_waitcnt(0);                               // vmcnt(0): the stores have left
@@ -1573,6 +1657,20 @@ Tile pick_tile(const GemmParams& p) {
     Tile t{0, 0, 32};
     if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
   }
+  if (p.lnx_c1) {
+    // LayerNorm in the epilogue: BK = 32 on every tile, so that the side sums of the row statistics run over the same 8
+    // lanes per row in the same order whatever the tile -- the results do not depend on the tile (nor, through it, on the
+    // batch size).  Inside the cfg2 step the 32x64 tile (24 KB of LDS, 4 workgroups per SIMD) measured best at every
+    // LayerNorm -> Linear site (profiles/r03_ab_ln_epilogue.txt); large problems take the tiles of the plain GEMM.
+    if (const char* e = dev_env("AVSEP_LNX_TILE")) {
+      Tile t{0, 0, 32};
+      if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
+    }
+    auto blocks = [&](int bm, int bn) { return row_tiles(p, bm) * ((p.N + bn - 1) / bn); };
+    if (blocks(128, 64) >= 1000) return Tile{128, 64, 32};
+    if (blocks(64, 64) >= 1024) return Tile{64, 64, 32};
+    return p.N >= 64 ? Tile{32, 64, 32} : Tile{32, 32, 32};
+  }
   if (p.amode == AMODE_CONV2D) {
     if (const char* e = dev_env("AVSEP_CONV_TILE")) {
       Tile t{0, 0, 32};
@@ -1595,7 +1693,9 @@ Tile pick_tile(const GemmParams& p) {
   else if (blocks(64, 64) >= t64) pick = Tile{64, 64, 32};
   else if (blocks(64, 32) >= t6432) pick = Tile{64, 32, 32};
   const int kunit = (p.amode == AMODE_TAPS3 || p.amode == AMODE_CONV2D) ? p.Kt : p.K;   // a chunk must not straddle a tap
-  if (pick.bm + pick.bn <= 96 && kunit % 64 == 0) pick.bk = 64;
+  const char* bk32 = dev_env("AVSEP_BK32");   // developer A/B: "plain" / "all" keep BK = 32 on the small tiles
+  const bool keep32 = bk32 && (!strcmp(bk32, "all") || (!strcmp(bk32, "plain") && p.amode == AMODE_PLAIN));
+  if (pick.bm + pick.bn <= 96 && kunit % 64 == 0 && !keep32) pick.bk = 64;
   return pick;
 }
 
@@ -1765,7 +1865,12 @@ const char* gemm_instance_name(const GemmParams& p) {
 #else
   const bool ring4 = false;
 #endif
-  if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !ring4)
+  const int am = p.lnx_c1 ? (int)AMODE_LNX : p.amode;
+  if (t.bm == 64 && t.bn == 64 && t.bk == 32 && am == AMODE_LNX)
+    snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, %d, false, 2>", am);
+  else if (p.lnx_c1)
+    snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false, 0>", t.bm, t.bn, t.bk, am);
+  else if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !ring4)
     snprintf(buf, sizeof buf, "gemm_kernel<64, 64, 32, 0, false, 2>");
   else snprintf(buf, sizeof buf, "gemm_kernel<%d, %d, %d, %d, false, 0>", t.bm, t.bn, t.bk, p.amode);
   return buf;
@@ -1880,6 +1985,13 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   if (p.alt.M <= 0) p.alt.M = 0;
   if (p.drop_p < 0.0f || p.drop_p >= 1.0f || (p.drop_p > 0.0f && (p.ldc != p.N || p.C2 || p.mag_F > 0 || p.ksplit > 1)))
     return hipErrorInvalidValue;
+  if (p.lnx_c1) {                                      // LayerNorm in the epilogue (GemmParams::lnx_c1)
+    if (!p.lnx_c2 || p.amode != AMODE_PLAIN || p.bias || p.R || p.C2 || p.ln_gamma || p.ln_stats || p.ksplit > 1 || p.mag_F > 0 ||
+        p.drop_p > 0.0f || p.alt.M > 0 || (p.N & 3) || (p.ldc & 3))
+      return hipErrorInvalidValue;
+    p.amode = AMODE_LNX;
+    if (pick_tile(p).bk != 32) return hipErrorInvalidValue;   // (a developer override: the statistics' summation order is BK's)
+  }
   if (p.ln_gamma && p.ln_stats) {                      // LayerNorm applied while staging A, statistics given
 #ifdef AVSEP_DEV
     if (!p.ln_beta || p.amode != AMODE_PLAIN || !gemm_ln_staged_supported(p.K) || p.ksplit > 1 || p.alt.M > 0) return hipErrorInvalidValue;
@@ -1931,6 +2043,7 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   // (profiles/r02_ab_ring2_64x64.txt: +1..3 % on the N = 512 shapes)
   if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_PLAIN && !ring4)
     return launch_t<64, 64, 32, AMODE_PLAIN, false, 2>(p, s);
+  if (t.bm == 64 && t.bn == 64 && t.bk == 32 && p.amode == AMODE_LNX) return launch_t<64, 64, 32, AMODE_LNX, false, 2>(p, s);
 #define AVSEP_CASE(BM_, BN_, BK_, AM_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && p.amode == AM_) return launch_t<BM_, BN_, BK_, AM_>(p, s);
 #ifdef AVSEP_DEV
@@ -1949,6 +2062,8 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   AVSEP_MODES(32, 32, 64)
   AVSEP_CASE(32, 32, 64, AMODE_FRAMES) AVSEP_CASE(64, 32, 64, AMODE_FRAMES) AVSEP_CASE(64, 64, 32, AMODE_FRAMES)
   AVSEP_CASE(32, 32, 32, AMODE_FRAMES) AVSEP_CASE(64, 32, 32, AMODE_FRAMES) AVSEP_CASE(128, 64, 32, AMODE_FRAMES)
+  AVSEP_CASE(32, 64, 32, AMODE_LNX) AVSEP_CASE(32, 32, 32, AMODE_LNX) AVSEP_CASE(64, 32, 32, AMODE_LNX)
+  AVSEP_CASE(128, 64, 32, AMODE_LNX)
 #ifdef AVSEP_DEV   // reachable only through the tile overrides
   AVSEP_MODES(64, 64, 64)
   AVSEP_CASE(32, 32, 128, AMODE_PLAIN)

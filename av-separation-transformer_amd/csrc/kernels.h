@@ -27,7 +27,7 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
 }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
-enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2, AMODE_FRAMES = 3, AMODE_LN = 4 };
+enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2, AMODE_FRAMES = 3, AMODE_LN = 4, AMODE_LNX = 5 };
 enum { LN_KMAX = 512 };   // widest LayerNorm the staged form (AMODE_LN) keeps gamma / beta in LDS for
 
 // C[M,N] = epilogue( A'[M,K] * W[N,K]^T ), fp32 in / fp32 accumulate on the matrix cores.
@@ -69,6 +69,18 @@ struct GemmParams {
   const float* ln_beta;
   float ln_eps;
   const float* ln_stats;
+  // LayerNorm in the EPILOGUE (AMODE_LNX, round 3).  With W' = W o gamma, c1[n] = sum_k W'[n][k], c2[n] = sum_k W[n][k] beta[k]
+  // + bias[n] (all made once by the weight packer):
+  //     LayerNorm(x) W^T + b  =  rstd_m ( x W'^T )[m][n]  -  rstd_m mean_m c1[n]  +  c2[n]
+  // so the GEMM runs on the RAW rows with the ring-pipelined staging of the plain kernel -- no whole-K register slab, no
+  // statistics pass in front of the first MFMA -- and the row statistics are summed on the side from the A chunks the
+  // workgroup stages anyway (shifted one-pass sums, the formula of gemm_ln_kernel) and applied after the K loop.
+  // W = W' here, bias = null, K = the normalised width.  The same function as LayerNorm launch + GEMM, not the same bits: the
+  // rounding error grows with |mean| / std of the rows (0.4-0.9 at the model's LayerNorm sites; against float64 the two
+  // forms measure the same error on every fixture).  Every instance has BK = 32: the side sums then run over
+  // the same 8 lanes per row in the same order on every tile, so the result does not depend on the tile or the batch size.
+  const float* lnx_c1;
+  const float* lnx_c2;
   // Split-K (weight gradients: K = rows >> M, N): gridDim.y = ksplit slices of kchunk columns each (kchunk % 64 == 0),
   // slice z reads A/W columns [z*kchunk, ...) and writes its partial product to C + z*cstride; the caller sums the
   // slices with a column reduction (deterministic, no atomics).  PLAIN mode, no bias/act/residual.  0/1 = off.
@@ -203,3 +215,7 @@ hipError_t launch_pack_conv2d_bn(const float* w, const float* b, const float* ga
                                  const float* mean, const float* var, float* wp, float* bp, int Co, int Ci,
                                  float eps, hipStream_t s);
 hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, int scale_n, hipStream_t s);
+// operands of the LayerNorm-in-the-epilogue GEMM (GemmParams::lnx_c1) from a packed weight [N][K] and bias [N] (or null):
+// wp = w o gamma, c1[n] = sum_k wp[n][k], c2[n] = sum_k w[n][k] beta[k] + bias[n]  (sums in double, rounded once)
+hipError_t launch_pack_lnx(const float* w, const float* bias, const float* gamma, const float* beta, float* wp, float* c1,
+                           float* c2, int N, int K, hipStream_t s);

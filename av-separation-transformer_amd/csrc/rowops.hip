@@ -311,6 +311,46 @@ hipError_t launch_pack_conv2d_bn(const float* w, const float* b, const float* ga
   return hipGetLastError();
 }
 
+namespace {
+// one workgroup per output feature n: wp[n][:] = w[n][:] o gamma, c1[n] = sum_k wp[n][k], c2[n] = sum_k w[n][k] beta[k] + bias[n]
+__global__ __launch_bounds__(256) void pack_lnx_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ wp, float* __restrict__ c1, float* __restrict__ c2,
+                                                       int K) {
+  const int n = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float wv = w[(size_t)n * K + k];
+    const float v = wv * gamma[k];
+    wp[(size_t)n * K + k] = v;
+    s1 += (double)v;                       // the sum of the ROUNDED products: what the GEMM multiplies by
+    s2 += (double)wv * (double)beta[k];
+  }
+  __shared__ double r1[256], r2[256];
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      r1[threadIdx.x] += r1[threadIdx.x + off];
+      r2[threadIdx.x] += r2[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    c1[n] = (float)r1[0];
+    c2[n] = (float)(r2[0] + (bias ? (double)bias[n] : 0.0));
+  }
+}
+}  // namespace
+
+hipError_t launch_pack_lnx(const float* w, const float* bias, const float* gamma, const float* beta, float* wp, float* c1,
+                           float* c2, int N, int K, hipStream_t s) {
+  if (!w || !gamma || !beta || !wp || !c1 || !c2 || N <= 0 || K <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_lnx_kernel, dim3(N), dim3(256), 0, s, w, bias, gamma, beta, wp, c1, c2, K);
+  return hipGetLastError();
+}
+
 hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, int scale_n, hipStream_t s) {
   hipLaunchKernelGGL(scale_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, scale, scale_n);
   return hipGetLastError();

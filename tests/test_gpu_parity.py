@@ -445,6 +445,51 @@ def test_op_ln_linear_instances_bit_identical(lib, devlib, dev, M, N, K):
         assert torch.equal(y, ref), tile
 
 
+@pytest.mark.parametrize("M,N,K,act,shift", [(2016, 768, 256, 0, 0.0), (2016, 1024, 256, 1, 0.0), (1008, 768, 256, 0, 0.0),
+                                             (1001, 260, 256, 2, 0.0), (333, 96, 64, 0, 0.0), (129, 64, 480, 3, 0.0),
+                                             (700, 384, 512, 1, 0.0), (2016, 768, 256, 0, 40.0), (500, 512, 128, 2, -25.0)])
+def test_op_ln_linear_epilogue_form(lib, devlib, dev, M, N, K, act, shift):
+    """Form 3, LayerNorm in the EPILOGUE: y = rstd (x (W o gamma)^T - mean c1) + c2, a GEMM on the raw rows with the row
+    statistics summed on the side.  Same function as form 0, different rounding: the error against float64 is within the
+    gate of the other forms and within 3 x form 0's own error (+ 1e-6); rows with a large common offset (|mean| / std ~ 17)
+    grow the error by about that ratio and are gated on it.  Every tile computes the same bits: same k order in the matrix
+    cores, and BK = 32 everywhere, so the statistics are summed by the same 8 lanes per row in the same order."""
+    import os
+    x = seeded.tensor(19, "x", (M, K), -3, 5) + np.float32(shift)
+    w = seeded.tensor(19, "w", (N, K), -0.2, 0.2)
+    g_, be_, b_ = seeded.tensor(19, "g", (K,), 0.5, 1.5), seeded.tensor(19, "be", (K,), -1, 1), seeded.tensor(19, "b", (N,), -1, 1)
+    xd, wd, gd, bed, bd = (t(a, dev) for a in (x, w, g_, be_, b_))
+    scratch = torch.empty(max(M * K, N * K + 2 * N), device=dev)
+
+    def run(form, which):
+        y = torch.full((M, N), float("nan"), device=dev)
+        rc = which.avsep_op_ln_linear(xd.data_ptr(), gd.data_ptr(), bed.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(),
+                                      scratch.data_ptr(), M, N, K, act, 1e-5, form, _stream())
+        assert rc == 0, which.avsep_last_error()
+        return y
+
+    ln = onp.layer_norm(x.astype(np.float64), g_.astype(np.float64), be_.astype(np.float64))
+    ref = torch.from_numpy(ln @ w.astype(np.float64).T + b_.astype(np.float64))
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.nn.functional.gelu(ref), 3: torch.sigmoid(ref)}[act]
+    e0 = (run(0, lib).double().cpu() - ref).abs().max().item()
+    y3 = run(3, lib)
+    e3 = (y3.double().cpu() - ref).abs().max().item()
+    assert torch.isfinite(y3).all()
+    ratio = 1.0 + abs(shift) / 2.3           # |mean| / std of the rows (uniform(-3, 5): std 2.31)
+    assert e3 < 2e-5 * ratio, (e0, e3)
+    assert e3 < 3.0 * ratio * e0 + 1e-6, (e0, e3)
+    try:
+        for tile in ("32x32x32", "32x64x32", "64x32x32", "64x64x32", "128x64x32"):
+            os.environ["AVSEP_LNX_TILE"] = tile
+            assert torch.equal(run(3, devlib), y3), tile
+        os.environ["AVSEP_LNX_TILE"] = "32x32x64"      # another BK would sum the statistics in another order: refused
+        y = torch.empty((M, N), device=dev)
+        assert devlib.avsep_op_ln_linear(xd.data_ptr(), gd.data_ptr(), bed.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(),
+                                         scratch.data_ptr(), M, N, K, act, 1e-5, 3, _stream()) == -3
+    finally:
+        os.environ.pop("AVSEP_LNX_TILE", None)
+
+
 def test_op_ln_linear_rejects_bad_forms(lib, devlib, dev):
     y = torch.empty(64 * 1024, device=dev)
     p_ = y.data_ptr()
@@ -454,6 +499,8 @@ def test_op_ln_linear_rejects_bad_forms(lib, devlib, dev):
     assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 512, 0, 1e-5, 1, _stream()) == -1    # K > 256
     assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, None, 4, 4, 64, 0, 1e-5, 2, _stream()) == -1    # no scratch
     assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 4, 64, 0, 1e-5, 7, _stream()) == -1
+    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, None, 4, 4, 64, 0, 1e-5, 3, _stream()) == -1    # no scratch
+    assert lib.avsep_op_ln_linear(p_, p_, p_, p_, None, p_, p_, 4, 6, 64, 0, 1e-5, 3, _stream()) == -1      # N % 4
 
 
 @pytest.mark.parametrize("M0,M1,N,K,act,res,ln", [(2016, 1600, 768, 256, 0, False, True), (2016, 1600, 256, 256, 0, True, False),
