@@ -98,6 +98,8 @@ def _open(path):
     lib.avsep_op_ln_linear.argtypes = [fp, fp, fp, fp, fp, fp, fp, i, i, i, i, C.c_float, i, p]
     lib.avsep_op_attention.argtypes = [fp, i, fp, i, fp, i, fp, i, i, i, i, i, i, p]
     lib.avsep_op_interp_linear.argtypes = [fp, fp, i, i, i, i, p]
+    if hasattr(lib, "avsep_op_mask_head"):          # developer build only
+        lib.avsep_op_mask_head.argtypes = [fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, i, p]
     if hasattr(lib, "avsep_op_attention_proj"):     # developer build only
         lib.avsep_op_attention_proj.argtypes = [fp, i, fp, i, fp, i, fp, fp, fp, i, i, i, i, i, p]
     if hasattr(lib, "avsep_op_linear_pair"):        # developer build only (paired-launch experiment)

@@ -1442,6 +1442,16 @@ int avsep_op_stft_mag(const float* audio, const float* basis, float* spec, int B
 }
 
 #ifdef AVSEP_DEV
+int avsep_op_mask_head(const float* x, const float* w, const float* bias, const float* xt, float* masks, float* sep, int M,
+                       int N, int K, int F, int ldx, int act, int general, void* stream) {
+  if (!x || !w || !xt || !masks || !sep || M <= 0 || N <= 0 || K <= 0 || F <= 0 || ldx < F) return fail(AVSEP_EINVAL, "bad argument");
+  GemmParams p = linear_params(x, K, w, K, bias, masks, N, M, N, act);
+  p.C2 = sep; p.X = xt; p.ldx = ldx; p.F = F;
+  p.epi_general = general ? 1 : 0;
+  HCK(launch_gemm(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
 int avsep_op_attention_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
                             const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, void* stream) {
   if (!q || !k || !v || !wo || !x) return fail(AVSEP_EINVAL, "null pointer");

@@ -180,6 +180,63 @@ __device__ __forceinline__ void epilogue_finish_act(const GemmParams& p, const f
   }
 }
 
+// Straight-line epilogue of the mask head (decoder.decoder.3 + Sigmoid + SeparationDecoder.separate, model.py:195-220):
+// N = S * F is even but not a multiple of 4 (F = 257), two outputs -- C = act(acc + bias), C2 = C * X[m][n % F] -- in 8-byte
+// pairs.  Same arithmetic as the block-by-block general path below (tested bit for bit against it), in the order of the
+// fast path: every load of the tile (bias pairs, the mixture's magnitudes), the arithmetic, then nothing but stores.
+template <int WBM, int WBN>
+__device__ __forceinline__ void mask_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], int mbase, int nbase, int fr,
+                                              int fq) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool has_b = p.bias != nullptr;                                     // block-uniform
+  const float* bsrc = has_b ? p.bias : p.W;
+  f32x2 b0[WBN], b1[WBN];
+  float xv[WBM][WBN][4];
+#pragma unroll
+  for (int j = 0; j < WBN; ++j) {
+    const int n = nbase + 16 * j + 4 * fq;
+    b0[j] = *reinterpret_cast<const f32x2*>(bsrc + min(n, p.N - 2));
+    b1[j] = *reinterpret_cast<const f32x2*>(bsrc + min(n + 2, p.N - 2));
+  }
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    const float* xrow = p.X + (size_t)min(mbase + 16 * i + fr, p.M - 1) * p.ldx;
+#pragma unroll
+    for (int j = 0; j < WBN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xv[i][j][e] = xrow[min(nbase + 16 * j + 4 * fq + e, p.N - 1) % p.F];
+  }
+  f32x4 c[WBM][WBN], c2[WBM][WBN];
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) {
+      f32x4 x = acc[i][j];
+      if (has_b) { x[0] += b0[j][0]; x[1] += b0[j][1]; x[2] += b1[j][0]; x[3] += b1[j][1]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = apply_act(x[e], p.act);
+      c[i][j] = x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c2[i][j][e] = x[e] * xv[i][j][e];
+    }
+#pragma unroll
+  for (int i = 0; i < WBM; ++i)
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) {
+      const int m = mbase + 16 * i + fr, n = nbase + 16 * j + 4 * fq;
+      if (m < p.M && n < p.N) {
+        float* d = p.C + (size_t)m * p.ldc + n;
+        float* d2 = p.C2 + (size_t)m * p.ldc + n;
+        *reinterpret_cast<f32x2*>(d) = f32x2{c[i][j][0], c[i][j][1]};
+        *reinterpret_cast<f32x2*>(d2) = f32x2{c2[i][j][0], c2[i][j][1]};
+        if (n + 2 < p.N) {
+          *reinterpret_cast<f32x2*>(d + 2) = f32x2{c[i][j][2], c[i][j][3]};
+          *reinterpret_cast<f32x2*>(d2 + 2) = f32x2{c2[i][j][2], c2[i][j][3]};
+        }
+      }
+    }
+}
+
 // ORDER MATTERS: on CDNA loads and stores share one in-order counter (vmcnt), so a load issued after a store cannot be
 // waited for without also waiting for that store to be acknowledged by memory (1-2 us under load).  The first version
 // of this epilogue went block by block -- load bias / residual, compute, store -- and every block's loads waited for
@@ -223,8 +280,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
     }
     return;
   }
-  // ---- general path: N not a multiple of 4 and / or the mask head's second output (separated = masks * mixture,
-  //      model.py:220), block by block
+  if (p.C2 && v2 && !p.R && p.drop_p <= 0.0f && !p.epi_general) {   // block-uniform: the mask head
+    mask_epilogue<WBM, WBN>(p, acc, m0 + mw, n0 + nw, fr, fq);
+    return;
+  }
+  // ---- general path: N not a multiple of 4 and / or a residual beside the second output, block by block
 #pragma unroll
   for (int i = 0; i < WBM; ++i) {
     const int m = m0 + mw + 16 * i + fr;
@@ -1947,7 +2007,7 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
 #ifdef AVSEP_DEV
   static const bool epi_general = getenv("AVSEP_EPI_GENERAL") != nullptr;   // A/B: block-by-block epilogue
-  p.epi_general = epi_general ? 1 : 0;
+  p.epi_general = (epi_general || p_in.epi_general || (p_in.C2 && getenv("AVSEP_MASK_GENERAL"))) ? 1 : 0;   // (mask head only: A/B)
   static const bool dbg = getenv("AVSEP_GEMM_DBG") != nullptr;
   if (dbg && !p.dbg) return launch_gemm_dbg(p, s);
   static const bool no_remap = getenv("AVSEP_NO_XCD_REMAP") != nullptr;     // A/B: launch-order tiles

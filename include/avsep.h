@@ -153,6 +153,11 @@ int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const f
  * updated in place.  Bit-identical to avsep_op_attention followed by avsep_op_linear(residual = x). */
 int avsep_op_attention_proj(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* wo,
                             const float* bo, float* x, int B, int nhead, int dh, int Lq, int Lk, void* stream);
+/* The mask head alone (decoder.decoder.3 + Sigmoid + separate(), model.py:195-220): masks = act(x w^T + bias) (M, N),
+ * sep = masks * xt[m][n % F] with xt (M, ldx); general != 0 forces the block-by-block epilogue the straight-line one is
+ * tested against bit for bit. */
+int avsep_op_mask_head(const float* x, const float* w, const float* bias, const float* xt, float* masks, float* sep, int M,
+                       int N, int K, int F, int ldx, int act, int general, void* stream);
 #endif  /* AVSEP_DEV */
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream);
 #ifdef AVSEP_DEV

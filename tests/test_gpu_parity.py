@@ -589,6 +589,38 @@ def test_op_attention_pair_equals_two_launches(lib, devlib, dev, B, h, dh, L0, L
         assert torch.isnan(po[j][B * L * d:]).all()
 
 
+@pytest.mark.parametrize("M,S,F,K", [(2016, 2, 257, 512), (1008, 2, 257, 512), (500, 3, 257, 1024), (130, 2, 129, 256)])
+def test_mask_head_epilogue_bit_identical_to_block_by_block(devlib, dev, M, S, F, K):
+    """The mask head's straight-line epilogue (loads, arithmetic, stores) against the block-by-block one it replaced: same
+    bits in both outputs on every tile; masks against float64; separated = masks * mixture exactly."""
+    import os
+    N, ldx = S * F, (F + 31) // 32 * 32
+    x = t(seeded.tensor(23, "x", (M, K), -1, 1), dev)
+    w = t(seeded.tensor(23, "w", (N, K), -0.1, 0.1), dev)
+    b_ = t(seeded.tensor(23, "b", (N,), -1, 1), dev)
+    xt = t(seeded.tensor(23, "xt", (M, ldx), 0, 4), dev)
+
+    def run(general):
+        masks = torch.full((M, N), float("nan"), device=dev)
+        sep = torch.full((M, N), float("nan"), device=dev)
+        rc = devlib.avsep_op_mask_head(x.data_ptr(), w.data_ptr(), b_.data_ptr(), xt.data_ptr(), masks.data_ptr(), sep.data_ptr(),
+                                       M, N, K, F, ldx, 3, general, _stream())
+        assert rc == 0, devlib.avsep_last_error()
+        return masks, sep
+    try:
+        for tile in (None, "32x32x32", "64x32x64", "64x64x32", "128x64x32"):
+            if tile:
+                os.environ["AVSEP_GEMM_TILE"] = tile
+            (m0, s0), (m1, s1) = run(0), run(1)
+            assert torch.isfinite(m0).all() and torch.isfinite(s0).all()
+            assert torch.equal(m0, m1) and torch.equal(s0, s1), tile
+    finally:
+        os.environ.pop("AVSEP_GEMM_TILE", None)
+    ref = torch.sigmoid(x.double() @ w.double().T + b_.double())
+    assert (m0.double() - ref).abs().max().item() < 2e-6
+    assert torch.equal(s0, m0 * xt[:, :F].repeat(1, S))
+
+
 def test_op_linear_rejects_bad_k(lib, dev):
     y = torch.empty(4, 4, device=dev)
     assert lib.avsep_op_linear(y.data_ptr(), y.data_ptr(), None, None, y.data_ptr(), 4, 4, 30, 0, _stream()) == -1
