@@ -754,9 +754,7 @@ hipError_t launch_attention_ex(const float* q, int ldq, const float* k, int ldk,
       hipLaunchKernelGGL((attention_lds_kernel<2, 2, true>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,
                          nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
     } else if (two) {
-      const char* pad_s = dev_env("AVSEP_ATTN_PAD_LDS");   // developer diagnostic: extra dynamic LDS (bytes) caps the workgroups per CU
-      const unsigned pad = pad_s ? (unsigned)atoi(pad_s) : 0u;
-      hipLaunchKernelGGL((attention_lds_kernel<2, 2, false>), dim3((unsigned)wgs2), block, pad, s, q, ldq, k, ldk, v, ldv, o, ldo,
+      hipLaunchKernelGGL((attention_lds_kernel<2, 2, false>), dim3((unsigned)wgs2), block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo,
                          nhead, Lq, Lk, nqt, qscale, lse, drop_p, drop_seed);
     } else if (drop) {
       hipLaunchKernelGGL((attention_lds_kernel<1, 2, true>), grid, block, 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt,

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Developer diagnostic (GPU box, developer library): long-sequence attention against the number of resident workgroups per
-CU (capped by extra dynamic LDS, AVSEP_ATTN_PAD_LDS) -- does the matrix-pipe share grow with the waves per SIMD?"""
+CU (capped by extra dynamic LDS, AVSEP_ATTN_PAD_LDS) -- does the matrix-pipe share grow with the waves per SIMD?
+Needs the launch of attention_lds_kernel<2, 2, false> in attention.hip to pass `dev_env("AVSEP_ATTN_PAD_LDS")` bytes as its
+dynamic shared memory (a three-line developer patch, not kept in the sources; result in profiles/r03_mfma_valu_exclusive.txt)."""
 import ctypes as C, os, sys
 os.environ["AVSEP_LIB"] = "dev"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
