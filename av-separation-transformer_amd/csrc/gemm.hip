@@ -378,6 +378,14 @@ __device__ __forceinline__ void lnx_epilogue(const GemmParams& p, const f32x4 (&
     }
 }
 
+// Sum over the aligned group of 8 lanes a lane belongs to (every lane gets the total; fixed order)
+__device__ __forceinline__ float lane8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  return v;
+}
+
 // One K-chunk of MFMAs from the LDS image (shared by the GEMM kernels).
 // PF = false: fragments of a k-step are read right before its MFMAs (what the compiler schedules best for occupancy).
 // PF = true : all fragment reads of step s+1 are issued BEFORE the MFMAs of step s (second register set, pinned with a
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
   const int nbn = (p.N + BN - 1) / BN;
   int tile = xcd_tile(p);
   select_pair(p, tile);
-  const int bm = tile / nbn;
+  const int bm = p.nbn_magic ? (int)__umulhi((unsigned)tile, p.nbn_magic) : tile / nbn;   // uniform: s_mul_hi_u32
   const int bn = tile - bm * nbn;
   const int m0 = bm * BM, n0 = bn * BN;
 
@@ -683,20 +691,18 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
   if (AMODE == AMODE_LNX) {
     // row statistics: combine the SLOTS lanes that staged a row, park (mean, rstd) per tile row in LDS (free after the loop's
     // last barrier) for the lanes that hold the row's accumulators
+    static_assert(AMODE != AMODE_LNX || SLOTS == 8, "the LayerNorm-in-the-epilogue instances have BK = 32 (8 lanes per row)");
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      float s1 = lx_s1[i], s2 = lx_s2[i];
-#pragma unroll
-      for (int off = SLOTS / 2; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off);
-        s2 += __shfl_xor(s2, off);
-      }
-      const float inv = 1.0f / (float)p.K;
+      // the 8 lanes of a row are one half of a DPP row: lane ^ 1, lane ^ 2 (quad permutes), then 7 - lane (half mirror);
+      // three v_add_f32 with a DPP operand per sum instead of three ds_bpermute with their address arithmetic
+      const float s1 = lane8_sum(lx_s1[i]), s2 = lane8_sum(lx_s2[i]);
+      const float inv = p.ln_inv_k;
       const float m1 = s1 * inv;
       const float var = fmaxf(s2 * inv - m1 * m1, 0.0f);
       if (sslot == 0) {
         lds[2 * (srow + RPP * i)] = lx_c[i] + m1;
-        lds[2 * (srow + RPP * i) + 1] = 1.0f / sqrtf(var + p.ln_eps);
+        lds[2 * (srow + RPP * i) + 1] = __builtin_amdgcn_rsqf(var + p.ln_eps);   // v_rsq_f32, 1 ulp (1 / sqrtf: ~35 VALU instructions)
       }
     }
     __syncthreads();
@@ -1682,10 +1688,19 @@ inline long row_tiles(const GemmParams& p, int bm) {
   return (long)(p.M + bm - 1) / bm + (p.alt.M > 0 ? (long)(p.alt.M + bm - 1) / bm : 0);
 }
 
+// GemmParams::nbn_magic: exact for every tile < ntiles when ntiles * nbn < 2^32 (the quotient's error term is tile * e / (nbn 2^32)
+// with e <= nbn)
+unsigned tile_row_magic(long ntiles, int nbn) {
+  if (nbn < 2 || ntiles * (long)nbn >= (1L << 32)) return 0u;
+  return (unsigned)((1ULL << 32) / (unsigned)nbn) + 1u;
+}
+
 template <int BM, int BN, int BK, int AMODE, bool PF = false, int RING = 0>
 hipError_t launch_t(GemmParams p, hipStream_t s) {
   const int nbn = (p.N + BN - 1) / BN;
   p.g_tiles0 = p.alt.M > 0 ? ((p.M + BM - 1) / BM) * nbn : 0;
+  p.nbn_magic = tile_row_magic(row_tiles(p, BM) * nbn, nbn);
+  p.ln_inv_k = 1.0f / (float)p.K;
 #ifdef AVSEP_DEV
   if (p.dbg) {   // diagnostics: what the runtime says about residency of this instance
     int nb = 0;

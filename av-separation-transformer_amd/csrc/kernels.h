@@ -97,6 +97,12 @@ struct GemmParams {
   float drop_p;
   unsigned long long drop_seed;
   int g_tiles0;
+  // Set by the launcher (fp32 MFMA and VALU instructions do not overlap on a SIMD, profiles/r03_mfma_valu_exclusive.txt, so
+  // what can leave the VALU leaves it): nbn_magic = floor(2^32 / column tiles) + 1, the workgroup's tile row is
+  // mulhi(tile, nbn_magic) on the scalar unit instead of an integer division (a ~25-instruction VALU sequence even for
+  // uniform operands); 0 = divide (one column tile, or tiles x column tiles >= 2^32).  ln_inv_k = 1 / K (AMODE_LNX).
+  unsigned nbn_magic;
+  float ln_inv_k;
   struct Alt {
     const float *A, *W, *bias, *R, *ln_gamma, *ln_beta;
     float* C;
