@@ -36,8 +36,14 @@ struct ConvStackParams {
   float* pooled;         // (Mv, 128)
   int Mv, H, W, H1, W1, H2, W2, H3, W3;
   int a1_frame, a2_frame;   // floats per frame image incl. halo
+  // floor(2^32 / d) + 1 for d = P1, W1, P2, W2, P3, W3 (0 where d == 1): pixel -> (frame, row, column) by v_mul_hi_u32
+  // instead of integer divisions of ~25 VALU instructions each (fp32 MFMA and VALU do not overlap on a SIMD)
+  unsigned mg_p1, mg_w1, mg_p2, mg_w2, mg_p3, mg_w3;
   unsigned long long* dbg;  // developer diagnostics (AVSEP_CONV_DBG): per-workgroup phase clock sums, null otherwise
 };
+
+// m / d for 0 <= m < 2^16, 1 <= d < 2^16 with mg = floor(2^32 / d) + 1 (exact: m * d < 2^32); mg == 0 <=> d == 1
+__device__ __forceinline__ int qdiv(int m, unsigned mg) { return mg ? (int)__umulhi((unsigned)m, mg) : m; }
 
 // AVSEP_CONV_DBG: thread 0 of every workgroup accumulates the 100 MHz wall-clock time of each phase over its passes
 // into dbg[blockIdx * 8 + phase]; launch_conv_stack prints the means.  One scalar clock read per phase otherwise unused.
@@ -81,21 +87,24 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   // per-lane LDS base offsets of the 3x3 window origin of each output row (row = 16*rb + c)
   const int cb2 = wave & 3;                 // conv2 column block of this wave
   const int rb2_0 = (wave >> 2) * RB2MAX;   // first conv2 row block of this wave
-  int base2[RB2MAX], base3[RB3MAX];
+  // (and, for conv2, where the lane's output position lands in the a2 image: pass-invariant, so computed once here and
+  // not in every pass's epilogue; -1 = no such position)
+  int base2[RB2MAX], dst2[RB2MAX], base3[RB3MAX];
 #pragma unroll
   for (int i = 0; i < RB2MAX; ++i) {
-    int m = 16 * (rb2_0 + i) + c;
-    m = m < G * P2 ? m : 0;
-    const int g = m / P2, pos = m - g * P2;
-    const int y = pos / p.W2, x = pos - y * p.W2;
+    const int mu = 16 * (rb2_0 + i) + c;
+    const int m = mu < G * P2 ? mu : 0;
+    const int g = qdiv(m, p.mg_p2), pos = m - g * P2;
+    const int y = qdiv(pos, p.mg_w2), x = pos - y * p.W2;
     base2[i] = g * p.a1_frame + ((2 * y) * s1w + 2 * x) * C1P + 4 * q;
+    dst2[i] = mu < G * P2 ? g * p.a2_frame + ((y + 1) * s2w + (x + 1)) * C2P + 16 * cb2 + 4 * q : -1;
   }
 #pragma unroll
   for (int i = 0; i < RB3MAX; ++i) {
     int m = 16 * i + c;
     m = m < G * P3 ? m : 0;
-    const int g = m / P3, pos = m - g * P3;
-    const int y = pos / p.W3, x = pos - y * p.W3;
+    const int g = qdiv(m, p.mg_p3), pos = m - g * P3;
+    const int y = qdiv(pos, p.mg_w3), x = pos - y * p.W3;
     base3[i] = g * p.a2_frame + ((2 * y) * s2w + 2 * x) * C2P + 4 * q;
   }
   // weights of this wave's output channels: conv2 col-block cb2, conv3 col-blocks CB3*wave .. CB3*wave+CB3-1
@@ -136,6 +145,35 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   };
   if ((int)blockIdx.x < ngroups) fetch_raw(blockIdx.x);
 
+  // conv1's gather is pass-invariant too: which raw pixels feed this lane's three MFMA steps of each of its 16-pixel blocks,
+  // and where the block's output lands in a1.  When one sweep of U blocks per wave covers the pass (G * P1 <= 16 U NW pixels:
+  // the 32 x 32 lips of configs 1-4) the offsets are computed ONCE; larger frames recompute them per pass as before.
+  constexpr int U1 = 4;                                  // blocks in flight per wave
+  const int npb1 = (G * P1 + 15) >> 4;                   // 16-pixel blocks of a pass
+  const bool c1_once = npb1 <= U1 * NW;                  // workgroup-uniform
+  int c1_src[U1][3], c1_dst[U1], c1_g[U1];              // raw offset per step (-1 = outside the frame / beyond tap 8)
+  auto conv1_coords = [&](int pb, int (&src)[3], int& dst, int& g) {
+    const int px = 16 * pb + c;
+    const bool in = px < G * P1;                         // also false for blocks beyond npb1
+    const int pxc = in ? px : 0;
+    g = qdiv(pxc, p.mg_p1);
+    const int pos = pxc - g * P1;
+    const int y = qdiv(pos, p.mg_w1), x = pos - y * p.W1;
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int k = 4 * s3 + q;                          // tap index of this lane in MFMA step s3
+      const int ky = k / 3, kx = k - 3 * ky;
+      const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
+      const bool ok = k < 9 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      src[s3] = ok ? g * (p.H * p.W) + iy * p.W + ix : -1;
+    }
+    dst = in ? g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * q : -1;
+  };
+  if (c1_once) {
+#pragma unroll
+    for (int u = 0; u < U1; ++u) conv1_coords(wave + u * NW, c1_src[u], c1_dst[u], c1_g[u]);
+  }
+
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int f0 = grp * G;
@@ -158,30 +196,25 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
     // The MFMA is a k-ordered fma chain starting from C, i.e. bias, tap 0, tap 1, ... -- bit-identical to the VALU
     // loop it replaces (which took 7.8 of a pass's 28 us with the matrix pipes idle: in-kernel phase clocks).
     {
-      const int npb = (G * P1 + 15) >> 4;                 // 16-pixel blocks of this pass
-      constexpr int U = 4;                                // blocks in flight per wave: independent gather -> MFMA -> store chains
-      for (int pb0 = wave; pb0 < npb; pb0 += U * NW) {    // wave-uniform trip count
+      constexpr int U = U1;                               // blocks in flight per wave: independent gather -> MFMA -> store chains
+      for (int pb0 = wave; pb0 < npb1; pb0 += U * NW) {   // wave-uniform trip count
         float xv[U][3];
         int dst[U];
         bool pin[U], live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int px = 16 * (pb0 + u * NW) + c;
-          pin[u] = px < G * P1;                           // also false for blocks beyond npb
-          const int pxc = pin[u] ? px : 0;
-          const int g = pxc / P1, pos = pxc - g * P1;
-          const int y = pos / p.W1, x = pos - y * p.W1;
-          const float* fr = raw + g * HW;
+          int src[3], g;
+          if (c1_once) {
 #pragma unroll
-          for (int s3 = 0; s3 < 3; ++s3) {
-            const int k = 4 * s3 + q;                     // tap index of this lane in MFMA step s3
-            const int ky = k / 3, kx = k - 3 * ky;
-            const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
-            const bool ok = k < 9 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            xv[u][s3] = ok ? fr[ok ? iy * p.W + ix : 0] : 0.0f;
+            for (int s3 = 0; s3 < 3; ++s3) src[s3] = c1_src[u][s3];
+            dst[u] = c1_dst[u]; g = c1_g[u];
+          } else {
+            conv1_coords(pb0 + u * NW, src, dst[u], g);
           }
+          pin[u] = dst[u] >= 0;
+#pragma unroll
+          for (int s3 = 0; s3 < 3; ++s3) xv[u][s3] = src[s3] >= 0 ? raw[src[s3] >= 0 ? src[s3] : 0] : 0.0f;
           live[u] = pin[u] && (f0 + g < p.Mv);
-          dst[u] = g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * q;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -238,14 +271,11 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
       // per block instead of sixteen of each (the same products in the same order: bit-identical).
 #pragma unroll
       for (int i = 0; i < RB2MAX; ++i) {
-        const int m = 16 * (rb2_0 + i) + c;
-        if (m < G * P2) {
-          const int g = m / P2, pos = m - g * P2;
-          const int y = pos / p.W2, x = pos - y * p.W2;
+        if (dst2[i] >= 0) {
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][r] + bias2v[r], 0.0f);
-          *reinterpret_cast<f32x4*>(a2 + g * p.a2_frame + ((y + 1) * s2w + (x + 1)) * C2P + 16 * cb2 + 4 * q) = v;
+          *reinterpret_cast<f32x4*>(a2 + dst2[i]) = v;
         }
       }
     }
@@ -421,6 +451,10 @@ hipError_t launch_conv_stack(const float* frames, const float* w1, const float* 
   p.a1_frame = (2 * p.H2 + 1) * (2 * p.W2 + 1) * C1P;
   p.a2_frame = (2 * p.H3 + 1) * (2 * p.W3 + 1) * C2P;
   const int P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
+  auto magic = [](int d) { return d > 1 ? (unsigned)((1ULL << 32) / (unsigned)d) + 1u : 0u; };
+  if (H * W >= 65536) return hipErrorNotSupported;   // (qdiv's range; far beyond what fits LDS anyway)
+  p.mg_p1 = magic(p.H1 * p.W1); p.mg_w1 = magic(p.W1); p.mg_p2 = magic(P2); p.mg_w2 = magic(p.W2);
+  p.mg_p3 = magic(P3); p.mg_w3 = magic(p.W3);
   // per frame: the two haloed images + the raw pixels staged for conv1
   const size_t frame_bytes = (size_t)(p.a1_frame + p.a2_frame + H * W) * sizeof(float);
   static const bool four_waves = dev_env("AVSEP_CONV_NW4") != nullptr;
