@@ -134,10 +134,15 @@ int avsep_op_linear(const float* x, const float* w, const float* bias, const flo
 int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                        float eps, void* stream);
 /* y = act(LayerNorm(x) W^T + b), the pair every pre-norm block of the model is made of (model.py:48-52 norm_first
- * layers, 145-149, 201): x (M,K), w (N,K).  `form` picks how the engine may run it -- all three are the same
- * function: 0 = LayerNorm launch into scratch (M*K floats) + GEMM; 1 = statistics and normalisation inside the GEMM
- * (K <= 256; what small batches use); 2 = a statistics launch into scratch (2*M floats: mean, 1/std per row) and a
- * GEMM that normalises its A tile on the way to LDS (K <= 512; what large batches use; bit-identical to form 0). */
+ * layers, 145-149, 201): x (M,K), w (N,K).  `form` picks how the engine may run it -- all four are the same
+ * function: 0 = LayerNorm launch into scratch (M*K floats) + GEMM (what large batches and d_model > 256 use);
+ * 1 = statistics and normalisation inside the GEMM, in front of its first MFMA (K <= 256; rounds 1-2);
+ * 2 = a statistics launch into scratch (2*M floats: mean, 1/std per row) and a GEMM that normalises its A tile on the
+ * way to LDS (K <= 512; bit-identical to form 0; developer library only, measured slower);
+ * 3 = LayerNorm in the EPILOGUE (what the model's d_model <= 256 sites use since round 3): the GEMM runs on the raw rows
+ * against W o gamma, the row statistics are summed on the side, y = act(rstd (acc - mean c1) + c2) with c1 = rowsum(W o gamma),
+ * c2 = W beta + b, which the call packs into scratch (N*K + 2*N floats; avsep_finalize_weights does it once per weight
+ * update for the model); N % 4 == 0.  Same function as form 0, not the same bits. */
 int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
                        float* y, float* scratch, int M, int N, int K, int act, float eps, int form, void* stream);
 /* softmax(q k^T) v per (batch, head); q is expected pre-scaled.  q (B,Lq,ldq) etc. with head h at
