@@ -275,6 +275,22 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def test_op_linear_every_column_tile_count(lib, dev):
+    """The workgroup -> (tile row, tile column) map is a multiply-high by a host-computed magic number (round 3: integer
+    divisions cost VALU time the matrix cores cannot hide): every count of column tiles from 1 to 66 on the 32-wide tile, with
+    a row count that is not a multiple of the tile, against torch's float64 product -- a wrong quotient would put a whole tile
+    in the wrong place."""
+    from av_separation._native import check
+    M, K = 333, 64
+    x = t(seeded.tensor(29, "x", (M, K), -2, 2), dev)
+    for N in list(range(4, 2113, 32)) + [1, 2, 3, 31, 33, 2080]:
+        w = t(seeded.tensor(29, f"w{N}", (N, K), -0.5, 0.5), dev)
+        y = torch.full((M, N), float("nan"), device=dev)
+        check(lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), M, N, K, 0, _stream()))
+        ref = x.double() @ w.double().T
+        assert (y.double() - ref).abs().max().item() < 2e-5, N
+
+
 @pytest.mark.parametrize("M,N,K,act,res", [(504, 256, 256, 0, True), (2016, 1024, 256, 1, False),
                                            (2016, 514, 512, 3, False), (400, 768, 256, 0, False),
                                            (37, 50, 64, 2, True), (1, 1, 32, 0, False),
