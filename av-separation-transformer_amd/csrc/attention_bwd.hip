@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
       float dpe = dp[r];
       if (drop_p > 0.0f) {   // d/dP of the dropped-and-rescaled probabilities: same mask as the forward
         const unsigned long long e = ((unsigned long long)bh * Lq + (qt * 16 + c)) * Lk + key;
-        dpe = dropout_keep(drop_seed, e, drop_p) ? dpe / (1.0f - drop_p) : 0.0f;
+        dpe = dropout_keep(drop_seed, e, drop_p) ? dpe * dropout_scale(drop_p) : 0.0f;
       }
       ds[r] = pr * (dpe - D);
     }

@@ -94,8 +94,9 @@ __device__ __attribute__((noinline)) f32x4 act4_outofline(f32x4 v) {
 // Training-only epilogue step (GemmParams::drop_p), out of line for the same reason: the 64-bit hash of the mask must not
 // cost the inference instances registers.
 __device__ __attribute__((noinline)) f32x4 drop4_outofline(f32x4 v, unsigned long long seed, unsigned long long e0, float p) {
+  const float ks = dropout_scale(p);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = dropout_keep(seed, e0 + e, p) ? v[e] / (1.0f - p) : 0.0f;
+  for (int e = 0; e < 4; ++e) v[e] = dropout_keep(seed, e0 + e, p) ? v[e] * ks : 0.0f;
   return v;
 }
 
@@ -302,7 +303,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
         float x = (p.bias && in) ? v[e] + p.bias[n + e] : v[e];
         x = apply_act(x, p.act);
         if (p.drop_p > 0.0f)
-          x = dropout_keep(p.drop_seed, (unsigned long long)m * p.N + (n + e), p.drop_p) ? x / (1.0f - p.drop_p) : 0.0f;
+          x = dropout_keep(p.drop_seed, (unsigned long long)m * p.N + (n + e), p.drop_p) ? x * dropout_scale(p.drop_p) : 0.0f;
         if (p.R && in) x += p.R[(size_t)rr * p.ldr + n + e];
         v[e] = x;
         w[e] = (p.C2 && in) ? x * p.X[(size_t)m * p.ldx + (n + e) % p.F] : 0.0f;

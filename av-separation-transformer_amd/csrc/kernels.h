@@ -16,15 +16,28 @@ inline const char* dev_env(const char*) { return nullptr; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Counter-based dropout mask (training path): splitmix64 of (seed, element index) -> uniform [0,1) from the top 24
-// bits; an element is kept when u >= p.  Stateless, so the backward regenerates exactly the forward's mask.
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
-  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
+// Counter-based dropout mask (training path): a 32-bit hash of (seed, element index), kept when hash >= p * 2^32.
+// Stateless, so the backward regenerates exactly the forward's mask.  Rounds 1-2 used splitmix64: three 64-bit multiplies =
+// twelve quarter-rate 32-bit multiplies, ~240 VALU cycles per ELEMENT -- and VALU cycles are matrix-pipe cycles on this chip
+// (profiles/r03_mfma_valu_exclusive.txt): 560 M mask elements per cfg4 training step were ~4 % of the step.  Now: the
+// two-round xorshift-multiply integer hash "lowbias32" on (index ^ seed_lo), the seed's high word (and an index's, beyond
+// 2^32 elements) folded in before a third multiply: three 32-bit multiplies, ~85 cycles.
+__device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsigned long long idx) {
+  unsigned x = (unsigned)idx ^ (unsigned)seed;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  x ^= (unsigned)(seed >> 32) + (unsigned)(idx >> 32);
+  x *= 0x9e3779b1u;
+  x ^= x >> 15;
+  return x;
 }
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
+  return dropout_hash(seed, idx) >= (unsigned)(p * 4294967296.0f);     // 0 <= p < 1 (checked by the launchers)
+}
+// the kept elements' factor: ONE rounding of 1 / (1 - p), then a multiply per element at every site (a division per element
+// is ~10 VALU instructions)
+__device__ __forceinline__ float dropout_scale(float p) { return 1.0f / (1.0f - p); }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
 enum { AMODE_PLAIN = 0, AMODE_TAPS3 = 1, AMODE_CONV2D = 2, AMODE_FRAMES = 3, AMODE_LN = 4, AMODE_LNX = 5 };

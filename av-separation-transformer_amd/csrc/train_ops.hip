@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __re
   if (idx >= nv) return;
   T g = reinterpret_cast<const T*>(dy)[idx], a = reinterpret_cast<const T*>(y)[idx];
 #pragma unroll
-  for (int e = 0; e < V; ++e) lane_of<V>(g, e) = lane_of<V>(a, e) > 0.0f ? lane_of<V>(g, e) / (1.0f - p) : 0.0f;
+  for (int e = 0; e < V; ++e) lane_of<V>(g, e) = lane_of<V>(a, e) > 0.0f ? lane_of<V>(g, e) * dropout_scale(p) : 0.0f;
   reinterpret_cast<T*>(dx)[idx] = g;
 }
 
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   if (idx >= nv) return;
   T v = reinterpret_cast<const T*>(x)[idx];
 #pragma unroll
-  for (int e = 0; e < V; ++e) lane_of<V>(v, e) = dropout_keep(seed, idx * V + e, p) ? lane_of<V>(v, e) / (1.0f - p) : 0.0f;
+  for (int e = 0; e < V; ++e) lane_of<V>(v, e) = dropout_keep(seed, idx * V + e, p) ? lane_of<V>(v, e) * dropout_scale(p) : 0.0f;
   reinterpret_cast<T*>(y)[idx] = v;
 }
 
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restric
   T w = reinterpret_cast<const T*>(r)[idx];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    const float d = dropout_keep(seed, idx * V + e, p) ? lane_of<V>(v, e) / (1.0f - p) : 0.0f;
+    const float d = dropout_keep(seed, idx * V + e, p) ? lane_of<V>(v, e) * dropout_scale(p) : 0.0f;
     lane_of<V>(v, e) = lane_of<V>(w, e) + d;
   }
   reinterpret_cast<T*>(y)[idx] = v;

@@ -401,23 +401,33 @@ def test_dropout_training_is_self_consistent():
     s2, _ = train_forward(m, mixed, lips, seed=11)
     s3, _ = train_forward(m, mixed, lips, seed=12)
     assert torch.equal(s1, s2) and not torch.equal(s1, s3)
-    m.zero_grad()
-    crit(s1, tg).backward()
+    # Directional derivative, three mask seeds.  The functional is LINEAR in the outputs and the step small: along a random
+    # direction of all parameters the SI-SNR loss (logarithms of energy ratios of a 2-clip batch) is so curved that its central
+    # difference moves by 25 % between eps = 5e-4 and 2.5e-4 (tools/fd_dropout_check.py), which tests the difference, not the
+    # gradient; with a linear functional it converges on the analytic value to 0.1-1.6 % at eps = 2.5e-4.
+    wt = torch.randn(s1.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    func = lambda s: (s * wt).sum() / 64.0
     params = [p for p in m.parameters()]
     gen = torch.Generator(device="cpu").manual_seed(5)
     dirs = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
-    analytic = sum(float((p.grad * d_).sum()) for p, d_ in zip(params, dirs))
-    eps = 2e-3
-    vals = []
-    with torch.no_grad():
-        for sgn in (+1, -1):
-            for p, d_ in zip(params, dirs):
-                p.add_(sgn * eps * d_)
-            vals.append(float(crit(train_forward(m, mixed, lips, seed=11)[0], tg)))
-            for p, d_ in zip(params, dirs):
-                p.sub_(sgn * eps * d_)
-    numeric = (vals[0] - vals[1]) / (2 * eps)
-    assert abs(numeric - analytic) < 0.05 * max(1.0, abs(analytic)), (numeric, analytic)
+    eps = 2.5e-4
+    for seed in (11, 12, 13):
+        m.zero_grad()
+        func(train_forward(m, mixed, lips, seed=seed)[0]).backward()
+        analytic = sum(float((p.grad * d_).sum()) for p, d_ in zip(params, dirs))
+        vals = []
+        with torch.no_grad():
+            for sgn in (+1, -1):
+                for p, d_ in zip(params, dirs):
+                    p.add_(sgn * eps * d_)
+                vals.append(float(func(train_forward(m, mixed, lips, seed=seed)[0]).double()))
+                for p, d_ in zip(params, dirs):
+                    p.sub_(sgn * eps * d_)
+        numeric = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(numeric - analytic) < 0.04 * max(1.0, abs(analytic)), (seed, numeric, analytic)
+    m.zero_grad()
+    crit(train_forward(m, mixed, lips, seed=11)[0], tg).backward()   # the real loss differentiates too (finite gradients everywhere)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
 
 
 def _dp_worker(rank, world, port, name, out):
