@@ -301,6 +301,75 @@ template <int V> __device__ __forceinline__ float& lane_of(typename VecT<V>::typ
 template <> __device__ __forceinline__ float& lane_of<1>(float& v, int) { return v; }
 template <> __device__ __forceinline__ float& lane_of<4>(f32x4& v, int e) { return reinterpret_cast<float*>(&v)[e]; }
 
+// ---- im2col2d / col2im2d, round 3: the kernels above pay five runtime integer divisions (two of them 64-bit) PER SCALAR ELEMENT,
+// ~150 VALU instructions per float moved: 56 us per launch where the bytes take 20 (PMC: the three im2col2d launches of a cfg4
+// step were the third-largest VALU consumer of the whole step).  Here one thread moves V = 4 channels with 16-byte accesses
+// and every quotient is a multiply-high by a host-computed magic number (floor(2^32 / d) + 1, exact while n * d < 2^32 --
+// the launcher checks the ranges and otherwise takes the kernels above).  Same values, element for element.
+__device__ __forceinline__ unsigned mdiv(unsigned n, unsigned mg) { return mg ? __umulhi(n, mg) : n; }   // mg == 0 <=> d == 1
+
+template <int V>
+__global__ __launch_bounds__(256) void im2col2d_fast_kernel(const float* __restrict__ x, float* __restrict__ col, unsigned total,
+                                                            int H, int W, int C, int Ho, int Wo, int Kp, unsigned mg_kpv,
+                                                            unsigned mg_c, unsigned mg_hw, unsigned mg_wo) {
+  typedef typename VecT<V>::type T;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned kpv = (unsigned)Kp / V;
+  const unsigned row = mdiv(idx, mg_kpv);
+  const int k = (int)(idx - row * kpv) * V;
+  T v;
+#pragma unroll
+  for (int e = 0; e < V; ++e) lane_of<V>(v, e) = 0.0f;
+  if (k < 9 * C) {
+    const int tap = (int)mdiv((unsigned)k, mg_c), c = k - tap * C;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const unsigned img = mdiv(row, mg_hw);
+    const int rem = (int)(row - img * (unsigned)(Ho * Wo));
+    const int y = (int)mdiv((unsigned)rem, mg_wo), xo = rem - y * Wo;
+    const int iy = 2 * y - 1 + ky, ix = 2 * xo - 1 + kx;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const T*>(x + (((size_t)img * H + iy) * W + ix) * C + c);
+  }
+  *reinterpret_cast<T*>(col + (size_t)idx * V) = v;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void col2im2d_fast_kernel(const float* __restrict__ dcol, float* __restrict__ dx, unsigned total,
+                                                            int H, int W, int C, int Ho, int Wo, int Kp, unsigned mg_cv,
+                                                            unsigned mg_w, unsigned mg_h) {
+  typedef typename VecT<V>::type T;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned cv = (unsigned)C / V;
+  const unsigned px = mdiv(idx, mg_cv);
+  const int c = (int)(idx - px * cv) * V;
+  const unsigned rowp = mdiv(px, mg_w);
+  const int ix = (int)(px - rowp * (unsigned)W);
+  const unsigned img = mdiv(rowp, mg_h);
+  const int iy = (int)(rowp - img * (unsigned)H);
+  T acc;
+#pragma unroll
+  for (int e = 0; e < V; ++e) lane_of<V>(acc, e) = 0.0f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;          // 2*y = iy + 1 - ky
+    if (ty < 0 || (ty & 1)) continue;
+    const int y = ty >> 1;
+    if (y >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int txx = ix + 1 - kx;
+      if (txx < 0 || (txx & 1)) continue;
+      const int xo = txx >> 1;
+      if (xo >= Wo) continue;
+      T w = *reinterpret_cast<const T*>(dcol + (((size_t)img * Ho + y) * Wo + xo) * Kp + (ky * 3 + kx) * C + c);
+#pragma unroll
+      for (int e = 0; e < V; ++e) lane_of<V>(acc, e) += lane_of<V>(w, e);
+    }
+  }
+  *reinterpret_cast<T*>(dx + (size_t)idx * V) = acc;
+}
+
 __device__ __forceinline__ float act_value(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.0f);
   if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -556,13 +625,41 @@ hipError_t launch_col2im1d(const float* dcol, float* dx, int M, int T, int C, hi
   hipLaunchKernelGGL(col2im1d_kernel, dim3(nblk((size_t)M * (C / 4))), dim3(256), 0, s, dcol, dx, M, T, C);
   return hipGetLastError();
 }
+namespace {
+unsigned magic32(unsigned d) { return d > 1 ? (unsigned)((1ULL << 32) / d) + 1u : 0u; }
+// mdiv(n, magic32(d)) is exact for every n < nmax when nmax * d < 2^32
+bool magic_ok(unsigned long long nmax, unsigned long long d) { return d >= 1 && nmax * d < (1ULL << 32); }
+}  // namespace
+
 hipError_t launch_im2col2d(const float* x, float* col, int I, int H, int W, int C, int Ho, int Wo, int Kp,
                            hipStream_t s) {
+  if (I <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || Kp < 9 * C) return hipErrorInvalidValue;
+  {
+    const int V = (!(C & 3) && !(Kp & 3) && !((uintptr_t)x & 15) && !((uintptr_t)col & 15)) ? 4 : 1;
+    const unsigned long long rows = (unsigned long long)I * Ho * Wo, total = rows * (Kp / V);
+    if (magic_ok(total, Kp / V) && magic_ok(Kp, C) && magic_ok(rows, (unsigned long long)Ho * Wo) && magic_ok((unsigned long long)Ho * Wo, Wo)) {
+      const unsigned mk = magic32(Kp / V), mc = magic32(C), mhw = magic32(Ho * Wo), mwo = magic32(Wo);
+      if (V == 4) hipLaunchKernelGGL((im2col2d_fast_kernel<4>), dim3(nblk(total)), dim3(256), 0, s, x, col, (unsigned)total, H, W, C, Ho, Wo, Kp, mk, mc, mhw, mwo);
+      else hipLaunchKernelGGL((im2col2d_fast_kernel<1>), dim3(nblk(total)), dim3(256), 0, s, x, col, (unsigned)total, H, W, C, Ho, Wo, Kp, mk, mc, mhw, mwo);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(im2col2d_kernel, dim3(nblk((size_t)I * Ho * Wo * Kp)), dim3(256), 0, s, x, col, I, H, W, C, Ho, Wo, Kp);
   return hipGetLastError();
 }
 hipError_t launch_col2im2d(const float* dcol, float* dx, int I, int H, int W, int C, int Ho, int Wo, int Kp,
                            hipStream_t s) {
+  if (I <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || Kp < 9 * C) return hipErrorInvalidValue;
+  {
+    const int V = (!(C & 3) && !(Kp & 3) && !((uintptr_t)dcol & 15) && !((uintptr_t)dx & 15)) ? 4 : 1;
+    const unsigned long long pixels = (unsigned long long)I * H * W, total = pixels * (C / V);
+    if (magic_ok(total, C / V) && magic_ok(pixels, W) && magic_ok((unsigned long long)I * H, H)) {
+      const unsigned mcv = magic32(C / V), mw = magic32(W), mh = magic32(H);
+      if (V == 4) hipLaunchKernelGGL((col2im2d_fast_kernel<4>), dim3(nblk(total)), dim3(256), 0, s, dcol, dx, (unsigned)total, H, W, C, Ho, Wo, Kp, mcv, mw, mh);
+      else hipLaunchKernelGGL((col2im2d_fast_kernel<1>), dim3(nblk(total)), dim3(256), 0, s, dcol, dx, (unsigned)total, H, W, C, Ho, Wo, Kp, mcv, mw, mh);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(col2im2d_kernel, dim3(nblk((size_t)I * H * W * C)), dim3(256), 0, s, dcol, dx, I, H, W, C, Ho, Wo, Kp);
   return hipGetLastError();
 }

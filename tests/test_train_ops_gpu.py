@@ -271,3 +271,31 @@ def test_wgrad_bias_direct_against_float64(dev, R, N, K):
         assert torch.isfinite(gw).all() and torch.isfinite(gb).all(), name
         assert _rel(gw.double(), ref_w) < tol, (name, _rel(gw.double(), ref_w))
         assert _rel(gb.double(), ref_b) < tol, (name, _rel(gb.double(), ref_b))
+
+
+@pytest.mark.parametrize("I,H,W,C,Kp", [(1200, 32, 32, 1, 32), (1200, 16, 16, 32, 288), (1200, 8, 8, 64, 576),
+                                        (7, 13, 9, 3, 32), (5, 48, 48, 1, 32), (3, 24, 24, 32, 288), (2, 5, 7, 8, 96)])
+def test_im2col2d_and_its_adjoint_against_unfold(dev, I, H, W, C, Kp):
+    """im2col2d (Conv2d k3 s2 p1 as a GEMM on a channels-last image, K = 9 C zero-padded to Kp) and col2im2d, its adjoint,
+    against F.unfold / F.fold -- exactly: both only move (and, in the adjoint, add up to four) floats.  Round 3 replaced the
+    per-element integer divisions by multiply-highs and moves four channels per thread; the odd shapes take the one-channel
+    instance."""
+    import ctypes as C_
+    from av_separation import _native
+    lib = _native.load()
+    st = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu").manual_seed(I + H + W + C)
+    x = torch.randn(I, H, W, C, generator=g).to(dev)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    col = torch.full((I * Ho * Wo, Kp), float("nan"), device=dev)
+    _native.check(lib.avsep_op_im2col2d(x.data_ptr(), col.data_ptr(), I, H, W, C, Kp, st))
+    unf = F.unfold(x.permute(0, 3, 1, 2), kernel_size=3, padding=1, stride=2)            # (I, C*9, L), channel-major
+    ref = unf.view(I, C, 9, Ho * Wo).permute(0, 3, 2, 1).reshape(I * Ho * Wo, 9 * C)     # row (img, y, x), column tap*C + c
+    assert torch.equal(col[:, :9 * C], ref)
+    assert (col[:, 9 * C:] == 0).all()
+    dcol = torch.randn(I * Ho * Wo, Kp, generator=g).to(dev)
+    dx = torch.full((I, H, W, C), float("nan"), device=dev)
+    _native.check(lib.avsep_op_col2im2d(dcol.data_ptr(), dx.data_ptr(), I, H, W, C, Kp, st))
+    cols = dcol[:, :9 * C].view(I, Ho * Wo, 9, C).permute(0, 3, 2, 1).reshape(I, C * 9, Ho * Wo)
+    fold = F.fold(cols, output_size=(H, W), kernel_size=3, padding=1, stride=2).permute(0, 2, 3, 1)
+    assert float((dx - fold).abs().max()) <= 4e-6 * float(fold.abs().max())            # <= 4 terms, any order

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: 32-bit dropout hash: training tests + training bench (previous figure on this box class: 989 clips/s, 16.18 ms)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03ac; mkdir -p $O; cd $R
-timeout -k 10 900 python3 -m pytest tests -q -m gpu > $O/tests.txt 2>&1; echo "tests rc=$?"; tail -4 $O/tests.txt
+timeout -k 10 900 python3 -m pytest tests/test_train_ops_gpu.py tests/test_train_gpu.py tests/test_fuzz_gpu.py -q -m gpu > $O/tests.txt 2>&1; echo "tests rc=$?"; tail -4 $O/tests.txt
 for i in 1 2; do
 python3 bench.py --mode train --steps 10 --warmup 3 --no-cpu 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('train', d['value'], d['ms_per_step'], d['timing']['ms_per_step_rounds'])"
