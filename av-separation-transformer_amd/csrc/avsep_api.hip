@@ -105,6 +105,7 @@ struct avsep_ctx {
   float *wkv_all, *bkv_all;
   std::vector<FusLayerW> f_layers;
   float *fn_g, *fn_b, *d_w1, *d_b1, *d_w2, *d_b2;
+  float* zeros = nullptr;
   std::unordered_map<const float*, LnxW> lnx;     // by the packed weight of the linear layer that follows a LayerNorm
   bool use_lnx = true, lnx_all = false;
   // streams / events for the audio || visual fork-join and graph replay
@@ -172,6 +173,7 @@ void layout_arena(avsep_ctx* c, F&& take) {
   c->fn_g = take(d); c->fn_b = take(d);
   c->d_w1 = take((size_t)2 * d * d); c->d_b1 = take(2 * d);
   c->d_w2 = take((size_t)S * c->F * 2 * d); c->d_b2 = take((size_t)S * c->F);
+  c->zeros = take((size_t)std::max(c->Fp, c->d) + 64);   // GemmParams::zeros (zeroed by avsep_create)
   c->lnx.clear();
   if (c->use_lnx) {
     auto site = [&](const float* w, int n) {
@@ -574,12 +576,12 @@ int audio_front(avsep_ctx* c, const Workspace& w, const float* mixed, int B, int
                [&] { return launch_transpose_pad(mixed, w.xt, B, c->F, T, c->Fp, s); }));
   GemmParams p{};
   p.A = w.xt; p.lda = c->Fp; p.W = c->a_w1; p.ldw = 3 * c->Fp; p.bias = c->a_b1; p.C = w.a_h0; p.ldc = d;
-  p.M = M; p.N = d; p.K = 3 * c->Fp; p.amode = AMODE_TAPS3; p.T = T; p.Kt = c->Fp; p.act = ACT_RELU;
+  p.M = M; p.N = d; p.K = 3 * c->Fp; p.amode = AMODE_TAPS3; p.T = T; p.Kt = c->Fp; p.act = ACT_RELU; p.zeros = c->zeros;
   RCK(run_gemm(c, p, s, 3 * c->F));
   RCK(record_tap(c, w, "a_conv1", w.a_h0, (size_t)M * d, s));
   GemmParams p2{};
   p2.A = w.a_h0; p2.lda = d; p2.W = c->a_w2; p2.ldw = 3 * d; p2.bias = c->a_b2; p2.C = w.a_x; p2.ldc = d;
-  p2.M = M; p2.N = d; p2.K = 3 * d; p2.amode = AMODE_TAPS3; p2.T = T; p2.Kt = d; p2.act = ACT_RELU;
+  p2.M = M; p2.N = d; p2.K = 3 * d; p2.amode = AMODE_TAPS3; p2.T = T; p2.Kt = d; p2.act = ACT_RELU; p2.zeros = c->zeros;
   p2.R = c->a_pe; p2.ldr = d; p2.rperiod = T;   // x + pe[:, :T]  (model.py:300), fused after the ReLU
   RCK(run_gemm(c, p2, s));
   RCK(record_tap(c, w, "a_pe", w.a_x, (size_t)M * d, s));
@@ -925,6 +927,8 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   if (e != hipSuccess) { delete c; return fail_hip(e, "hipMalloc(weight arena)"); }
   off = 0;
   layout_arena(c, [&](size_t n) { float* p = c->arena + off; off += align_up(n ? n : 1, 64); return p; });
+  e = hipMemset(c->zeros, 0, ((size_t)std::max(c->Fp, c->d) + 64) * sizeof(float));
+  if (e != hipSuccess) { (void)hipFree(c->arena); delete c; return fail_hip(e, "hipMemset(zero row)"); }
   bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_vdone, hipEventDisableTiming) == hipSuccess &&

@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
     }
   }
   const float* a_src[APASS];
-  int a_aux0[APASS], a_aux1[APASS];   // TAPS3: t index;  CONV2D: iy0, ix0
+  const float *a_prev[APASS], *a_next[APASS], *a_cur[APASS];   // TAPS3: rows of tap 0 / tap 2 / the tap being loaded
+  int a_aux0[APASS], a_aux1[APASS];   // CONV2D: iy0, ix0;  FRAMES: first sample
   int a_st[APASS], b_st[BPASS];       // swizzled LDS float offsets of this thread's staging slots
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
@@ -518,9 +519,13 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
       a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;
       a_aux0[i] = a_aux1[i] = 0;
     } else if (AMODE == AMODE_TAPS3) {
-      a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;
-      a_aux0[i] = m % p.T;
-      a_aux1[i] = 0;
+      a_src[i] = p.A + (size_t)m * p.lda + 4 * sslot;   // the centre tap's row
+      const int t = m % p.T;
+      const float* zrow = p.zeros + 4 * sslot;
+      a_prev[i] = t > 0 ? a_src[i] - p.lda : zrow;       // tap 0: row t - 1, or zeros in front of the sequence
+      a_next[i] = t + 1 < p.T ? a_src[i] + p.lda : zrow; // tap 2: row t + 1, or zeros behind it
+      a_cur[i] = a_prev[i];
+      a_aux0[i] = a_aux1[i] = 0;
     } else if (AMODE == AMODE_FRAMES) {
       const int b = m / p.T, t = m - b * p.T;
       a_src[i] = p.A + (size_t)b * p.frame_len;        // the clip; the frame offset is kept separately for the bound
@@ -561,13 +566,8 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
       if (AMODE == AMODE_PLAIN || AMODE == AMODE_LN || AMODE == AMODE_LNX) {
         ra[slot][i] = *reinterpret_cast<const f32x4*>(a_src[i] + kload * BK);
       } else if (AMODE == AMODE_TAPS3) {
-        // unconditional load from an always-valid address; out-of-sequence taps are zeroed when the chunk is
-        // written to LDS (store_chunk), so the load needs no exec-mask region and stays asynchronous in the ring
-        const int t = a_aux0[i] + tap - 1;
-        const bool ok = (t >= 0) && (t < p.T);
-        const float* src = a_src[i] + (ptrdiff_t)(ok ? tap - 1 : 0) * p.lda + sub * BK;
-        ra[slot][i] = *reinterpret_cast<const f32x4*>(src);
-        rok[slot][i] = ok;
+        // the tap's row, or the zero row (GemmParams::zeros) for a tap outside the sequence: no predicate, no select
+        ra[slot][i] = *reinterpret_cast<const f32x4*>(a_cur[i] + sub * BK);
       } else if (AMODE == AMODE_FRAMES) {
         const int smp = a_aux0[i] + kload * BK;          // multiples of 4 throughout: a float4 is inside or outside whole
         const bool ok = smp < p.frame_len;
@@ -586,7 +586,13 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
     for (int i = 0; i < BPASS; ++i) rb[slot][i] = *reinterpret_cast<const f32x4*>(b_src[i] + kload * BK);
     ++kload;
     if (AMODE == AMODE_TAPS3 || AMODE == AMODE_CONV2D) {
-      if (++sub == cpt) { sub = 0; ++tap; }
+      if (++sub == cpt) {                                 // block-uniform: next tap
+        sub = 0; ++tap;
+        if (AMODE == AMODE_TAPS3) {
+#pragma unroll
+          for (int i = 0; i < APASS; ++i) a_cur[i] = tap == 1 ? a_src[i] : a_next[i];
+        }
+      }
     }
   };
   // kc = index of the chunk being written (AMODE_LN picks its gamma / beta columns by it)
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
           lx_s1[i] += dlt;
           lx_s2[i] = fmaf(dlt, dlt, lx_s2[i]);
         }
-      } else if (AMODE != AMODE_PLAIN) {
+      } else if (AMODE != AMODE_PLAIN && AMODE != AMODE_TAPS3) {
         v = rok[slot][i] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       *reinterpret_cast<f32x4*>(a + a_st[i]) = v;
@@ -2050,6 +2056,7 @@ hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStrea
 hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 31)) return hipErrorInvalidValue;
   if ((p.amode == AMODE_TAPS3 || p.amode == AMODE_CONV2D) && (p.Kt <= 0 || (p.Kt & 31))) return hipErrorInvalidValue;
+  if (p.amode == AMODE_TAPS3 && !p.zeros) return hipErrorInvalidValue;
   if (p.amode == AMODE_FRAMES && (p.T <= 0 || p.frame_hop <= 0 || (p.frame_hop & 3) || p.frame_len <= 0 || (p.frame_len & 3)))
     return hipErrorInvalidValue;
   if (p.mag_F > 0 && ((p.N & 1) || p.N != 2 * p.mag_F || p.T <= 0 || p.bias || p.R || p.C2 || p.act != ACT_NONE))

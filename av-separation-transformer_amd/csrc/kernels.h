@@ -116,6 +116,9 @@ struct GemmParams {
   // uniform operands); 0 = divide (one column tile, or tiles x column tiles >= 2^32).  ln_inv_k = 1 / K (AMODE_LNX).
   unsigned nbn_magic;
   float ln_inv_k;
+  // TAPS3: at least Kt floats of zeros.  A tap outside its sequence (t - 1 < 0, t + 1 >= T) reads THIS row instead of being
+  // loaded from a valid address and zeroed by four selects per float4 on the way to LDS: the same zeros without the VALU.
+  const float* zeros;
   struct Alt {
     const float *A, *W, *bias, *R, *ln_gamma, *ln_beta;
     float* C;
