@@ -1753,6 +1753,12 @@ Tile pick_tile(const GemmParams& p) {
     if (blocks(64, 64) >= 1024) return Tile{64, 64, 32};
     return p.N >= 64 ? Tile{32, 64, 32} : Tile{32, 32, 32};
   }
+  if (p.amode == AMODE_TAPS3) {
+    if (const char* e = dev_env("AVSEP_TAPS_TILE")) {
+      Tile t{0, 0, 32};
+      if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2) return t;
+    }
+  }
   if (p.amode == AMODE_CONV2D) {
     if (const char* e = dev_env("AVSEP_CONV_TILE")) {
       Tile t{0, 0, 32};
@@ -1774,6 +1780,16 @@ Tile pick_tile(const GemmParams& p) {
   else if (blocks(128, 64) >= 2048) pick = Tile{128, 64, 32};
   else if (blocks(64, 64) >= t64) pick = Tile{64, 64, 32};
   else if (blocks(64, 32) >= t6432) pick = Tile{64, 32, 32};
+  // the two audio convolutions of a small batch run beside conv_stack, the most contended phase of the step: 32x64x32 (24 KB,
+  // half the staging instructions per MFMA of 32x32) is 1 % faster one step at a time, equal with two in flight
+  // (profiles/r03_ab_ln_epilogue.txt, item 7c)
+  if (p.amode == AMODE_TAPS3 && pick.bm == 32 && pick.bn == 32 && p.N >= 64 && !(p.N & 3) && !p.C2) return Tile{32, 64, 32};
+  if (p.amode == AMODE_PLAIN && pick.bm == 32 && pick.bn == 32 && slices == 1) {
+    if (const char* e = dev_env("AVSEP_SMALL_TILE")) {       // developer A/B: the tile of the small plain GEMMs
+      Tile t{0, 0, 32};
+      if (sscanf(e, "%dx%dx%d", &t.bm, &t.bn, &t.bk) >= 2 && p.K % t.bk == 0) return t;
+    }
+  }
   const int kunit = (p.amode == AMODE_TAPS3 || p.amode == AMODE_CONV2D) ? p.Kt : p.K;   // a chunk must not straddle a tap
   const char* bk32 = dev_env("AVSEP_BK32");   // developer A/B: "plain" / "all" keep BK = 32 on the small tiles
   const bool keep32 = bk32 && (!strcmp(bk32, "all") || (!strcmp(bk32, "plain") && p.amode == AMODE_PLAIN));
@@ -2147,7 +2163,9 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   AVSEP_CASE(32, 32, 32, AMODE_FRAMES) AVSEP_CASE(64, 32, 32, AMODE_FRAMES) AVSEP_CASE(128, 64, 32, AMODE_FRAMES)
   AVSEP_CASE(32, 64, 32, AMODE_LNX) AVSEP_CASE(32, 32, 32, AMODE_LNX) AVSEP_CASE(64, 32, 32, AMODE_LNX)
   AVSEP_CASE(128, 64, 32, AMODE_LNX)
+  AVSEP_CASE(32, 64, 32, AMODE_TAPS3)
 #ifdef AVSEP_DEV   // reachable only through the tile overrides
+  AVSEP_CASE(32, 64, 32, AMODE_PLAIN) AVSEP_CASE(32, 64, 64, AMODE_PLAIN)
   AVSEP_MODES(64, 64, 64)
   AVSEP_CASE(32, 32, 128, AMODE_PLAIN)
   AVSEP_CASE(32, 32, 128, AMODE_TAPS3)
