@@ -201,6 +201,8 @@ hipError_t launch_add_rows(const float* x, const float* r, float* y, size_t M, i
 hipError_t launch_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_bwd(const float* dy, float* dx, int B, int N, int T, int d, hipStream_t s);
 // dres (may be null): added to dx -- the gradient that reaches x along the residual path of a pre-norm block
+hipError_t launch_layernorm_bwd_affine(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
+                                       float* dgamma, float* dbeta, float* part, int M, int d, float eps, hipStream_t s);
 hipError_t launch_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
                                 float* xhat, int M, int d, float eps, hipStream_t s);
 // (B,F,T) -> (B,T,Fp) zero padded

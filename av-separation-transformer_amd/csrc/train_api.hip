@@ -362,8 +362,7 @@ int avsep_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, 
                            float* xhat_scratch, float* scratch, int M, int d, float eps, void* stream) {
   if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !xhat_scratch || !scratch) return fail(AVSEP_EINVAL, "null pointer");
   hipStream_t s = S(stream);
-  TCK(launch_layernorm_bwd(dy, x, gamma, nullptr, dx, xhat_scratch, M, d, eps, s));
-  TCK(launch_colreduce(dy, xhat_scratch, scratch, dbeta, dgamma, M, d, 1.0f, s));
+  TCK(launch_layernorm_bwd_affine(dy, x, gamma, nullptr, dx, dgamma, dbeta, scratch, M, d, eps, s));   // (xhat_scratch: unused since round 3)
   return AVSEP_OK;
 }
 
@@ -372,8 +371,7 @@ int avsep_op_layernorm_bwd_res(const float* dy, const float* x, const float* gam
                                void* stream) {
   if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !xhat_scratch || !scratch) return fail(AVSEP_EINVAL, "null pointer");
   hipStream_t s = S(stream);
-  TCK(launch_layernorm_bwd(dy, x, gamma, dres, dx, xhat_scratch, M, d, eps, s));
-  TCK(launch_colreduce(dy, xhat_scratch, scratch, dbeta, dgamma, M, d, 1.0f, s));
+  TCK(launch_layernorm_bwd_affine(dy, x, gamma, dres, dx, dgamma, dbeta, scratch, M, d, eps, s));
   return AVSEP_OK;
 }
 

@@ -601,6 +601,107 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// LayerNorm backward with the affine gradients' first reduction stage inside (round 3): a workgroup takes 4 * RPW consecutive
+// rows (wave w the rows RPW w .. RPW w + RPW - 1 of the strip), every lane keeps the column sums of dy and dy * xhat of its
+// wave's rows in registers, the four waves' sums are added in wave order through LDS, and the strip's two partial rows go to
+// part[strip][2][d] -- the layout colreduce2_kernel reads.  Against layernorm_bwd_kernel + colreduce1_kernel: xhat is never
+// written (M d floats) and dy / xhat are not read a second time (2 M d floats), one launch less per LayerNorm.  The row
+// arithmetic is layernorm_bwd_kernel's, statement for statement (dx bit-identical); the column sums are added in another
+// (fixed) order than colreduce1's.
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ gam, const float* __restrict__ dres,
+                                                                  float* __restrict__ dx, float* __restrict__ part, int M, int d,
+                                                                  int rpw, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * rpw;
+  f32x4 cs[VEC], csx[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) cs[i] = csx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rr = 0; rr < rpw; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;                                            // wave-uniform
+    const float* xr = x + (size_t)row * d;
+    const float* gr = dy + (size_t)row * d;
+    f32x4 v[VEC], g[VEC], dyv[VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int col = (lane + 64 * i) * 4;
+      const bool ok = col < d;
+      v[i] = ok ? *reinterpret_cast<const f32x4*>(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      dyv[i] = ok ? *reinterpret_cast<const f32x4*>(gr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      g[i] = ok ? dyv[i] * *reinterpret_cast<const f32x4*>(gam + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if ((lane + 64 * i) * 4 < d) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float c = v[i][e] - mean;
+          sq += c * c;
+        }
+      }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.0f / sqrtf(sq / (float)d + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if ((lane + 64 * i) * 4 < d) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[i][e] = (v[i][e] - mean) * rstd;   // xhat
+          sg += g[i][e];
+          sgx = fmaf(g[i][e], v[i][e], sgx);
+        }
+      }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      sg += __shfl_xor(sg, off);
+      sgx += __shfl_xor(sgx, off);
+    }
+    const float mg = sg / (float)d, mgx = sgx / (float)d;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int col = (lane + 64 * i) * 4;
+      if (col < d) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - mg - v[i][e] * mgx);
+        if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * d + col);   // the residual path's gradient
+        *reinterpret_cast<f32x4*>(dx + (size_t)row * d + col) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // dbeta += dy, dgamma += dy * xhat (a product, then a sum: colreduce1's)
+          cs[i][e] += dyv[i][e];
+          csx[i][e] += dyv[i][e] * v[i][e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int col = (lane + 64 * i) * 4;
+    if (col < d) {
+      *reinterpret_cast<f32x4*>(red + (size_t)(wave * 2 + 0) * d + col) = cs[i];
+      *reinterpret_cast<f32x4*>(red + (size_t)(wave * 2 + 1) * d + col) = csx[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * d; c += 256) {           // c = j * d + column: exactly the partial row's layout
+    float t = red[c];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += red[(size_t)w * 2 * d + c];
+    part[(size_t)blockIdx.x * 2 * d + c] = t;
+  }
+}
+
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -686,6 +787,27 @@ hipError_t launch_bn_var(const float* x, const float* mean, float* part, float* 
   return hipGetLastError();
 }
 int colreduce_part_floats(int M, int C) { return red_plan(M, C).nb * 2 * C; }
+
+// dx (+ dres) and dgamma / dbeta in two launches: the fused backward above, then the second reduction stage.  `part` holds
+// colreduce_part_floats(M, d) floats (the strips are never more than the generic plan's workgroups).
+hipError_t launch_layernorm_bwd_affine(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
+                                       float* dgamma, float* dbeta, float* part, int M, int d, float eps, hipStream_t s) {
+  if (M <= 0 || d <= 0 || (d & 3) || d > 2048) return hipErrorInvalidValue;
+  const RedPlan pl = red_plan(M, d);
+  const int rpw = (pl.rows + 3) / 4;                         // rows per wave: 4 rpw >= pl.rows, so strips <= pl.nb
+  const int strips = (M + 4 * rpw - 1) / (4 * rpw);
+  const size_t lds = (size_t)8 * d * sizeof(float);
+  const int vec = (d + 255) / 256;
+  const dim3 grid(strips), block(256);
+  if (vec <= 1) hipLaunchKernelGGL((layernorm_bwd_fused_kernel<1>), grid, block, lds, s, dy, x, gamma, dres, dx, part, M, d, rpw, eps);
+  else if (vec <= 2) hipLaunchKernelGGL((layernorm_bwd_fused_kernel<2>), grid, block, lds, s, dy, x, gamma, dres, dx, part, M, d, rpw, eps);
+  else if (vec <= 4) hipLaunchKernelGGL((layernorm_bwd_fused_kernel<4>), grid, block, lds, s, dy, x, gamma, dres, dx, part, M, d, rpw, eps);
+  else hipLaunchKernelGGL((layernorm_bwd_fused_kernel<8>), grid, block, lds, s, dy, x, gamma, dres, dx, part, M, d, rpw, eps);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(colreduce2_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, s, part, dbeta, dgamma, strips, 2, d, 1.0f);
+  return hipGetLastError();
+}
 hipError_t launch_sum_slices(const float* part, float* out, int S, size_t n, hipStream_t s) {
   if (n & 3) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sum_slices_kernel, dim3(nblk(n / 4)), dim3(256), 0, s, part, out, S, n / 4);
