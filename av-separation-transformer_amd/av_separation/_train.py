@@ -29,7 +29,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 import weakref
 
 import torch
@@ -109,9 +108,10 @@ def _colsum(a, b=None):
 # the in-line path.  Measured on the cfg4 step (profiles/r02_ab_train_side_stream.txt): +2 % while the bias gradient was
 # two more launches per layer, -1.5 % since it rides the weight-gradient kernel -- the step's host enqueue time (13.5 ms
 # of 17.5) grows by 1.5 ms with the stream switches, which costs more than the overlap returns.  So it is OFF unless
-# AVSEP_TRAIN_SIDE_STREAM=1 (or ``_train.SIDE_STREAM_WGRAD = True``); tests/test_train_gpu.py keeps it bit-identical.
+# a test or tool sets ``_train.SIDE_STREAM_WGRAD = True`` (a module attribute: the product package reads no environment
+# variable but AVSEP_LIB, tests/test_abi.py); tests/test_train_gpu.py keeps it bit-identical.
 _SIDE = {}
-SIDE_STREAM_WGRAD = os.environ.get("AVSEP_TRAIN_SIDE_STREAM") is not None
+SIDE_STREAM_WGRAD = False
 
 
 def _side(device):
@@ -254,7 +254,7 @@ class _WtTable:
 
 
 _WT = {}
-BATCHED_WT = os.environ.get("AVSEP_TRAIN_NO_BATCHED_WT") is None      # developer A/B switch
+BATCHED_WT = True      # module attribute for A/B tools (no environment switch in the product package)
 
 
 def _wt_table(device):
@@ -424,11 +424,11 @@ class LayerNormFn(torch.autograd.Function):
         x, g = ctx.saved_tensors
         dy = _c(dy)
         M, d = x.shape
-        dx, xh = torch.empty_like(x), torch.empty_like(x)
+        dx = torch.empty_like(x)
         dg, db = torch.empty_like(g), torch.empty_like(g)
         s = _scratch(M, d, x)
         _ck(_lib().avsep_op_layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr(), dx.data_ptr(), dg.data_ptr(),
-                                          db.data_ptr(), xh.data_ptr(), s.data_ptr(), M, d, ctx.eps, _st(x)), "layernorm_bwd")
+                                          db.data_ptr(), None, s.data_ptr(), M, d, ctx.eps, _st(x)), "layernorm_bwd")
         return dx, dg, db, None
 
 
@@ -457,12 +457,12 @@ class ResidualNormFn(torch.autograd.Function):
         dy = _c(dy)
         dres = _c(dres) if dres is not None else None
         M, d = x.shape
-        dx, xh = torch.empty_like(x), torch.empty_like(x)
+        dx = torch.empty_like(x)
         dg, db = torch.empty_like(g), torch.empty_like(g)
         s = _scratch(M, d, x)
         _ck(_lib().avsep_op_layernorm_bwd_res(dy.data_ptr(), x.data_ptr(), g.data_ptr(),
                                               dres.data_ptr() if dres is not None else None, dx.data_ptr(), dg.data_ptr(),
-                                              db.data_ptr(), xh.data_ptr(), s.data_ptr(), M, d, ctx.eps, _st(x)),
+                                              db.data_ptr(), None, s.data_ptr(), M, d, ctx.eps, _st(x)),
             "layernorm_bwd_res")
         return dx, dg, db, None
 
@@ -845,7 +845,7 @@ def make_drop(module, probs, seed=None, group=None):
     return _Drop(seed, active)
 
 
-FUSED_DROPOUT_ADD = os.environ.get("AVSEP_TRAIN_NO_DROPOUT_ADD") is None    # developer A/B switch (same values either way)
+FUSED_DROPOUT_ADD = True    # module attribute for A/B tools (same values either way)
 # dropout inside the GEMM epilogue (round 3) and the residual gradient inside the LayerNorm backward: module switches so
 # that tests can compare with the launch-per-op forms (same values bit for bit either way)
 EPILOGUE_DROPOUT = True

@@ -364,10 +364,17 @@ inline int conv_out(int x) { return (x - 1) / 2 + 1; }
 template <int G, int RB2, int RB3, int NW>
 hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) {
   auto kern = conv_stack_kernel<G, RB2, RB3, NW>;
-  // the instance's dynamic-LDS ceiling is raised once (to the hardware's 160 KiB), not on every launch
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr != hipSuccess) return attr;
+  // the instance's dynamic-LDS ceiling is raised (to the hardware's 160 KiB) once PER DEVICE, not on every launch: the
+  // library keeps contexts on several devices in one process (avsep_ctx::device), and a failure is not latched
+  static bool raised[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+  if (dev < 0 || !raised[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    if (dev >= 0) raised[dev] = true;
+  }
   const int ngroups = (p.Mv + G - 1) / G;
   // One workgroup per CU: the audio branch runs concurrently on the other stream and its GEMMs need LDS too
   // (measured: with the CUs' LDS full of conv images the two branches serialise, profiles/r01c_step_timeline.txt).

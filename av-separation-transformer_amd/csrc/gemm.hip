@@ -57,12 +57,14 @@ __device__ __forceinline__ int xcd_tile(const GemmParams& p) {
 // Pair launch (GemmParams::alt): virtual tiles past g_tiles0 belong to the second problem -- same N, K, leading dimensions
 // and epilogue, other operands and row count.  Block-uniform: a handful of scalar selects at kernel entry.
 __device__ __forceinline__ void select_pair(GemmParams& p, int& tile) {
+#ifdef AVSEP_DEV
   if (p.g_tiles0 > 0 && tile >= p.g_tiles0) {
     tile -= p.g_tiles0;
     p.A = p.alt.A; p.W = p.alt.W; p.bias = p.alt.bias; p.R = p.alt.R; p.rperiod = p.alt.rperiod;
     p.ln_gamma = p.alt.ln_gamma; p.ln_beta = p.alt.ln_beta;
     p.C = p.alt.C; p.M = p.alt.M;
   }
+#endif
 }
 
 // Fused epilogue shared by the GEMM kernels.  The MFMAs are issued with the operands swapped (A operand = W rows,
@@ -596,13 +598,15 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
     }
   };
   // kc = index of the chunk being written (AMODE_LN picks its gamma / beta columns by it)
-  // AMODE_LNX: shifted one-pass sums of this thread's rows (relative to the row's first element, like gemm_ln_kernel)
+  // AMODE_LNX: one-pass sums of this thread's rows, taken of x - pilot, where the row's pilot lx_c is the mean of its FIRST
+  // CHUNK (32 floats = the 8 lanes that stage the row; set in front of the first store_chunk).  The shifted values -- not the
+  // raw ones -- are what goes to LDS (round 4): LayerNorm(x) = LayerNorm(x - pilot) exactly, and by Cauchy-Schwarz
+  // |mean(x) - pilot| <= sqrt(K / 32) std(x) for EVERY row, so the cancellation rstd (acc - mean c1) of the epilogue works on
+  // a mean of at most 2.83 standard deviations at K = 256, whatever offset the residual stream carries (round 3 staged the raw
+  // rows: its error grew with |mean| / std without bound).  Same VALU count: the subtraction was already made for the sums.
   float lx_c[APASS], lx_s1[APASS], lx_s2[APASS];
 #pragma unroll
-  for (int i = 0; i < APASS; ++i) {
-    lx_s1[i] = lx_s2[i] = 0.0f;
-    lx_c[i] = AMODE == AMODE_LNX ? *(a_src[i] - 4 * sslot) : 0.0f;   // the row's first element
-  }
+  for (int i = 0; i < APASS; ++i) lx_s1[i] = lx_s2[i] = lx_c[i] = 0.0f;
   auto store_chunk = [&](int slot, int buf, int kc) {
     float* a = As + buf * BM * BK;
     float* b = Bs + buf * BN * BK;
@@ -623,6 +627,7 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
           const float dlt = v[e] - lx_c[i];
           lx_s1[i] += dlt;
           lx_s2[i] = fmaf(dlt, dlt, lx_s2[i]);
+          v[e] = dlt;
         }
       } else if (AMODE != AMODE_PLAIN && AMODE != AMODE_TAPS3) {
         v = rok[slot][i] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -660,6 +665,13 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
   for (int j = 0; j < D; ++j)
     if (j < nk) load_chunk(j);
   if (AMODE == AMODE_LN) __syncthreads();   // gamma / beta are in LDS
+  if (AMODE == AMODE_LNX) {                 // the rows' pilots: mean of the first chunk, summed in a fixed order (tile-independent)
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const f32x4 v = ra[0][i];
+      lx_c[i] = lane8_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 32.0f);
+    }
+  }
   store_chunk(0, 0, 0);
   __syncthreads();
   dbg_stamp(p, 1);
@@ -708,7 +720,7 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
       const float m1 = s1 * inv;
       const float var = fmaxf(s2 * inv - m1 * m1, 0.0f);
       if (sslot == 0) {
-        lds[2 * (srow + RPP * i)] = lx_c[i] + m1;
+        lds[2 * (srow + RPP * i)] = m1;             // mean of the SHIFTED row, the rows the MFMAs saw
         lds[2 * (srow + RPP * i) + 1] = __builtin_amdgcn_rsqf(var + p.ln_eps);   // v_rsq_f32, 1 ulp (1 / sqrtf: ~35 VALU instructions)
       }
     }
@@ -2054,6 +2066,7 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t s) {
   return launch_gemm_impl(p, s);
 }
 
+#ifdef AVSEP_DEV
 // Two problems that differ only in their operands and row count, as ONE launch (GemmParams::alt).
 hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t s) {
   const bool same = p0.N == p1.N && p0.K == p1.K && p0.lda == p1.lda && p0.ldw == p1.ldw && p0.ldc == p1.ldc &&
@@ -2068,6 +2081,7 @@ hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStrea
   p.alt.ln_gamma = p1.ln_gamma; p.alt.ln_beta = p1.ln_beta; p.alt.C = p1.C; p.alt.M = p1.M;
   return launch_gemm(p, s);
 }
+#endif  // AVSEP_DEV
 
 hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 31)) return hipErrorInvalidValue;
@@ -2081,7 +2095,9 @@ hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
     if (p.amode != AMODE_PLAIN || p.bias || p.R || p.C2 || p.ln_gamma || p.act != ACT_NONE || p.alt.M > 0) return hipErrorInvalidValue;
     if (p.kchunk <= 0 || (p.kchunk & 63) || (long long)(p.ksplit - 1) * p.kchunk >= p.K) return hipErrorInvalidValue;
   }
+#ifdef AVSEP_DEV
   if (p.alt.M <= 0) p.alt.M = 0;
+#endif
   if (p.drop_p < 0.0f || p.drop_p >= 1.0f || (p.drop_p > 0.0f && (p.ldc != p.N || p.C2 || p.mag_F > 0 || p.ksplit > 1)))
     return hipErrorInvalidValue;
   if (p.lnx_c1) {                                      // LayerNorm in the epilogue (GemmParams::lnx_c1)

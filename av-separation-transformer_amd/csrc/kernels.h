@@ -32,6 +32,16 @@ __device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsign
   x ^= x >> 15;
   return x;
 }
+// The seed a caller hands to the C ABI is mixed ONCE on the host (murmur3's 64-bit finaliser) before it reaches a kernel:
+// dropout_hash() xors the raw low word into the index, so two user seeds with equal high words (consecutive seeds, small
+// integers) would otherwise give masks that are xor-permutations of each other, with identical drop counts over aligned
+// index ranges.  After the mix both words differ for any two seeds; no per-element cost.
+inline unsigned long long dropout_mix_seed(unsigned long long s) {
+  s ^= s >> 33; s *= 0xff51afd7ed558ccdULL;
+  s ^= s >> 33; s *= 0xc4ceb9fe1a85ec53ULL;
+  s ^= s >> 33;
+  return s;
+}
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
   return dropout_hash(seed, idx) >= (unsigned)(p * 4294967296.0f);     // 0 <= p < 1 (checked by the launchers)
 }
@@ -119,16 +129,24 @@ struct GemmParams {
   // TAPS3: at least Kt floats of zeros.  A tap outside its sequence (t - 1 < 0, t + 1 >= T) reads THIS row instead of being
   // loaded from a valid address and zeroed by four selects per float4 on the way to LDS: the same zeros without the VALU.
   const float* zeros;
+#ifdef AVSEP_DEV
   struct Alt {
     const float *A, *W, *bias, *R, *ln_gamma, *ln_beta;
     float* C;
     int M, rperiod;
   } alt;
+#else
+  // product library: no pair launches (measured slower, profiles/r03_ab_paired_schedule.txt) -- no second problem in the
+  // kernel arguments, select_pair() compiles to nothing, launch_gemm_pair() does not exist
+  struct Alt { static constexpr int M = 0; } alt;
+#endif
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 // p0 and p1 in ONE launch; they must agree in everything but A, W, bias, C, R (+ rperiod), the LayerNorm vectors and M
+#ifdef AVSEP_DEV
 hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t s);
+#endif
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
 // with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)

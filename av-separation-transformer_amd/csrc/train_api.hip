@@ -59,7 +59,7 @@ int avsep_op_linear_drop(const float* x, int lda, const float* w, int ldw, const
   p.amode = AMODE_PLAIN;
   p.act = act;
   p.R = residual; p.ldr = ldr; p.rperiod = rperiod;
-  p.drop_p = drop_p; p.drop_seed = drop_seed;
+  p.drop_p = drop_p; p.drop_seed = dropout_mix_seed(drop_seed);
   TCK(launch_gemm(p, S(stream)));
   return AVSEP_OK;
 }
@@ -178,20 +178,20 @@ int avsep_op_attention_train(const float* q, int ldq, const float* k, int ldk, c
                              uint64_t drop_seed, void* stream) {
   if (!q || !k || !v || !out || !lse) return fail(AVSEP_EINVAL, "null pointer");
   if (drop_p < 0.0f || drop_p >= 1.0f) return fail(AVSEP_EINVAL, "dropout probability must be in [0, 1)");
-  TCK(launch_attention_ex(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, qscale, lse, drop_p, drop_seed, S(stream)));
+  TCK(launch_attention_ex(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, qscale, lse, drop_p, dropout_mix_seed(drop_seed), S(stream)));
   return AVSEP_OK;
 }
 
 int avsep_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
   if (!x || !y || n <= 0 || p < 0.0f || p >= 1.0f) return fail(AVSEP_EINVAL, "bad argument");
-  TCK(launch_dropout(x, y, (size_t)n, p, seed, S(stream)));
+  TCK(launch_dropout(x, y, (size_t)n, p, dropout_mix_seed(seed), S(stream)));
   return AVSEP_OK;
 }
 
 int avsep_op_dropout_add(const float* x, const float* residual, float* y, int64_t n, float p, uint64_t seed,
                          void* stream) {
   if (!x || !residual || !y || n <= 0 || p < 0.0f || p >= 1.0f) return fail(AVSEP_EINVAL, "bad argument");
-  TCK(launch_dropout_add(x, residual, y, (size_t)n, p, seed, S(stream)));
+  TCK(launch_dropout_add(x, residual, y, (size_t)n, p, dropout_mix_seed(seed), S(stream)));
   return AVSEP_OK;
 }
 
@@ -202,7 +202,7 @@ int avsep_op_attention_bwd(const float* q, int ldq, const float* k, int ldk, con
   if (!q || !k || !v || !o || !d_out || !lse || !dvec || !dq || !dk || !dv) return fail(AVSEP_EINVAL, "null pointer");
   if (dh % 16) return fail(AVSEP_EINVAL, "training path: head dim must be a multiple of 16");
   TCK(launch_attention_bwd(q, ldq, k, ldk, v, ldv, o, ldo, d_out, lddo, lse, dvec, dq, lddq, dk, lddk, dv, lddv, B, nhead,
-                           dh, Lq, Lk, qscale, drop_p, drop_seed, S(stream)));
+                           dh, Lq, Lk, qscale, drop_p, dropout_mix_seed(drop_seed), S(stream)));
   return AVSEP_OK;
 }
 
@@ -360,16 +360,18 @@ int avsep_op_interp_linear_bwd(const float* dy, float* dx, int B, int N, int T, 
 }
 int avsep_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
                            float* xhat_scratch, float* scratch, int M, int d, float eps, void* stream) {
-  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !xhat_scratch || !scratch) return fail(AVSEP_EINVAL, "null pointer");
+  (void)xhat_scratch;   // unused since round 3 (the kernel keeps its column sums in registers); may be null
+  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(AVSEP_EINVAL, "null pointer");
   hipStream_t s = S(stream);
-  TCK(launch_layernorm_bwd_affine(dy, x, gamma, nullptr, dx, dgamma, dbeta, scratch, M, d, eps, s));   // (xhat_scratch: unused since round 3)
+  TCK(launch_layernorm_bwd_affine(dy, x, gamma, nullptr, dx, dgamma, dbeta, scratch, M, d, eps, s));
   return AVSEP_OK;
 }
 
 int avsep_op_layernorm_bwd_res(const float* dy, const float* x, const float* gamma, const float* dres, float* dx,
                                float* dgamma, float* dbeta, float* xhat_scratch, float* scratch, int M, int d, float eps,
                                void* stream) {
-  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !xhat_scratch || !scratch) return fail(AVSEP_EINVAL, "null pointer");
+  (void)xhat_scratch;   // unused; may be null
+  if (!dy || !x || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(AVSEP_EINVAL, "null pointer");
   hipStream_t s = S(stream);
   TCK(launch_layernorm_bwd_affine(dy, x, gamma, dres, dx, dgamma, dbeta, scratch, M, d, eps, s));
   return AVSEP_OK;

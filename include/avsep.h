@@ -304,6 +304,7 @@ int avsep_op_add_rows(const float* x, const float* r, float* y, int64_t M, int C
 int avsep_op_avgpool_fwd(const float* x, float* y, int M, int P, int C, void* stream);
 int avsep_op_avgpool_bwd(const float* dy, float* dx, int M, int P, int C, void* stream);
 int avsep_op_interp_linear_bwd(const float* dy, float* dx, int B, int N, int T, int d, void* stream);
+/* xhat_scratch: unused since round 3 (kept in the signature for ABI stability); pass NULL */
 int avsep_op_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx, float* dgamma, float* dbeta,
                            float* xhat_scratch, float* scratch, int M, int d, float eps, void* stream);
 /* The same with the gradient that reaches x along the RESIDUAL path of a pre-norm block (nn.TransformerEncoderLayer

@@ -13,7 +13,8 @@ Fixture families
   fwd_*      eval forward: stage taps (hooked run) + final (separated, masks) (un-hooked run, i.e. with
              torch's fused encoder fast path exactly as demo.py:42-49 executes it)
   trained_*  same, with weights after a few Adam steps of the reference's own recipe (demo.py:83-113)
-             incl. non-trivial BatchNorm running stats; weights are committed
+             incl. non-trivial BatchNorm running stats; weights are committed (trained_cfg1: the d = 256 model of
+             BASELINE configs 1/2 after the reference's own quick_train, 100 steps)
   dataset_*  SyntheticAVDataset items (dataset.py:70-151)
   losses     si_snr / SeparationLoss known answers (losses.py:14-73)
 """
@@ -231,6 +232,70 @@ def make_trained(outdir):
           f"masks[{masks.min():.5f},{masks.max():.5f}]")
 
 
+def make_trained_cfg1(outdir):
+    """BASELINE config 1's model (d = 256, nhead 4, 2 + 2 layers, 2 speakers) after the reference's OWN
+    `quick_train` (/root/reference/demo.py:83-113, called as it is: DataLoader(batch 8, shuffle), Adam lr 3e-4, clip 1.0,
+    SeparationLoss(0.5), 100 steps, train mode, dropout 0.1) on demo.py's dataset (demo.py:126-137).  The trained matrices
+    (ndim >= 2) are then rounded to the bfloat16 grid (round-to-nearest-even on the upper 16 bits; vectors -- biases,
+    LayerNorm / BatchNorm parameters and running statistics -- stay full float32), loaded back into the reference model, and
+    the fixture stores THAT model's eval outputs: the committed weights are half the bytes and the reference's outputs are
+    exact for them.  Stored: weights (matrices as uint16 upper halves under `wh.`, vectors under `w.`), SyntheticAVDataset
+    items 0, 1 as inputs, full (separated, masks) in float32 and from the float64 copy, every stage tap as strided slices +
+    float64 checksums, the training losses."""
+    sys.path.insert(0, "/root/reference")
+    import demo as refdemo
+    c = dict(CONFIGS["cfg1"], seed=41, full=False)
+    dkw = c.pop("dataset")
+    torch.manual_seed(4321)
+    m = ref.AVSeparationTransformer(freq_bins=c["F"], d_model=c["d"], nhead=c["h"], num_encoder_layers=c["Le"],
+                                    num_fusion_layers=c["Lf"], num_speakers=c["S"], dropout=0.1)
+    ds = ref.SyntheticAVDataset(num_samples=500, n_fft=512, hop_length=128, **dkw)
+    losses = refdemo.quick_train(m, ds, torch.device("cpu"), steps=100, lr=3e-4)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    out = {"config": np.array(json.dumps(c)), "losses": np.array(losses)}
+    for k, v in sd.items():
+        if k.endswith(".pe") or k.endswith("num_batches_tracked"):
+            continue
+        a = v.numpy()
+        if a.ndim >= 2:
+            u = a.view(np.uint32).astype(np.uint64)
+            u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)          # round to nearest even, keep 16 bits
+            out["wh." + k] = u
+            sd[k] = torch.from_numpy((u.astype(np.uint32) << 16).view(np.float32).reshape(a.shape).copy())
+        else:
+            out["w." + k] = a.copy()
+    mq = ref.AVSeparationTransformer(freq_bins=c["F"], d_model=c["d"], nhead=c["h"], num_encoder_layers=c["Le"],
+                                     num_fusion_layers=c["Lf"], num_speakers=c["S"], dropout=0.1)
+    mq.load_state_dict(sd)
+    mq.eval()
+    items = [ds[i] for i in (0, 1)]
+    mixed = torch.stack([x["mixed_spec"] for x in items])
+    lips = torch.stack([x["lip_frames"] for x in items])
+    with torch.no_grad():
+        sep, masks = mq(mixed, lips)
+        m64 = ref.AVSeparationTransformer(freq_bins=c["F"], d_model=c["d"], nhead=c["h"], num_encoder_layers=c["Le"],
+                                          num_fusion_layers=c["Lf"], num_speakers=c["S"], dropout=0.1)
+        m64.load_state_dict(sd)
+        sep64, masks64 = m64.double().eval()(mixed.double(), lips.double())
+    taps = hooked_taps(mq, mixed, lips)
+    # |mean| / std of the rows that enter the LayerNorm sites, for the record (DESIGN (c))
+    for k in ("a_pe", "a_enc0", "a_enc1", "v_enc0", "f_layer0", "f_layer1"):
+        r = taps[k].reshape(-1, c["d"]).astype(np.float64)
+        print(f"  {k}: |mean|/std of rows min {np.min(np.abs(r.mean(1)) / r.std(1)):.2f} max {np.max(np.abs(r.mean(1)) / r.std(1)):.2f}")
+    out["in.mixed"], out["in.lips"] = mixed.numpy(), lips.numpy()
+    pack_outputs(out, c, taps, sep.contiguous().numpy(), masks.contiguous().numpy(),
+                 sep64.contiguous().numpy(), masks64.contiguous().numpy())
+    out["separated"], out["masks"] = sep.contiguous().numpy(), masks.contiguous().numpy()
+    out["masks64"] = masks64.contiguous().numpy().astype(np.float64)
+    in_snr, out_snr = refdemo.evaluate_separation(mq, ds, torch.device("cpu"))
+    out["eval.in_snr"], out["eval.out_snr"] = np.float64(in_snr), np.float64(out_snr)
+    path = os.path.join(outdir, "trained_cfg1.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB loss {losses[0]:.2f}->{losses[-1]:.2f} "
+          f"masks[{masks.min():.5f},{masks.max():.5f}] fp32-vs-fp64 masks {np.abs(masks.double() - masks64).max():.2e} "
+          f"SNR in {in_snr:.2f} out {out_snr:.2f} dB")
+
+
 def make_dataset(outdir):
     out = {}
     small = dict(num_samples=8, sample_rate=8000, duration=0.496, n_fft=128, hop_length=128, num_frames=5,
@@ -383,6 +448,8 @@ def main():
             make_forward(name, c, a.out)
     if a.only in (None, "trained"):
         make_trained(a.out)
+    if a.only in (None, "trained_cfg1"):
+        make_trained_cfg1(a.out)
     if a.only in (None, "dataset"):
         make_dataset(a.out)
     if a.only in (None, "losses"):

@@ -54,6 +54,23 @@ def test_product_library_reads_no_environment_variable():
     assert "getenv" in out
 
 
+def test_product_package_reads_no_environment_variable_but_the_library_selector():
+    """like the product library (no getenv import, above), the Python package decides nothing from the
+    environment -- the one read is AVSEP_LIB in _native.py, which selects WHICH library file is opened (the developer build
+    for tools/ and the bit-identity tests).  A/B switches of the training path are module attributes set by tests and tools."""
+    import glob
+    import os
+    import re
+    pkg = os.path.dirname(os.path.abspath(_native.__file__))
+    hits = []
+    for path in sorted(glob.glob(os.path.join(pkg, "*.py"))):
+        for no, line in enumerate(open(path), 1):
+            code = line.split("#", 1)[0]
+            if re.search(r"environ|getenv", code):
+                hits.append((os.path.basename(path), no, code.strip()))
+    assert hits == [("_native.py", hits[0][1], '_want = os.environ.get("AVSEP_LIB")')], hits
+
+
 def test_version_and_error_string_without_gpu():
     lib = _native.load()
     assert lib.avsep_abi_version() == 1

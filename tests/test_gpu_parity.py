@@ -145,6 +145,87 @@ def test_full_batch_properties_cfg2(dev):
     assert maxabs(sep[:2].cpu().numpy(), rs) < MASK_TOL * float(mixed.max())
 
 
+def test_forward_matches_reference_trained_config1(golden, dev):
+    """the d = 256, 2 + 2-layer model of BASELINE configs 1 / 2 with weights TRAINED by the reference's
+    own quick_train (tests/golden/make_golden.py::make_trained_cfg1), on dataset items 0, 1: full masks / separated against
+    the reference's float32 and float64 outputs, every stage tap against the reference's (strided slices).  This is the
+    fixture that runs every LayerNorm-in-the-epilogue site of the bench workload on trained LayerNorm / BatchNorm parameters
+    and saturated masks ([4e-4, 0.9998])."""
+    g = golden("trained_cfg1")
+    c = g["config"]
+    m = build_model(g, dev).enable_debug_taps(True)
+    mixed, lips = golden_inputs(g)
+    scale = max(1.0, float(np.abs(mixed).max()))
+    with torch.no_grad():
+        sep, masks = m(t(mixed, dev), t(lips, dev))
+    assert maxabs(masks.cpu().numpy(), g["masks"]) < MASK_TOL
+    assert maxabs(masks.cpu().numpy(), g["masks64"]) < MASK_TOL
+    assert maxabs(sep.cpu().numpy(), g["separated"]) < MASK_TOL * scale
+    for key in [k for k in g if k.startswith("tap.") and k.endswith(".slice")]:
+        name_ = key[4:-6]
+        if name_ in ("a_conv2", "v_proj", "d_logits"):   # fused away on the HIP path (PE / sigmoid epilogues)
+            continue
+        ref = g[key]
+        shp = {"a": (c["B"], c["T"], c["d"]), "f": (c["B"], c["T"], c["d"]), "v": (c["B"], c["N"], c["d"])}[name_[0]]
+        if name_.startswith("v_conv"):                   # HIP keeps conv activations channels-last
+            j = int(name_[6])
+            hw, Cc = c["H"] >> (j + 1), 32 << j
+            got = m.read_tap(name_, (c["B"] * c["N"], hw, hw, Cc)).permute(0, 3, 1, 2)
+        elif name_ == "v_pool":
+            got = m.read_tap(name_, (c["B"] * c["N"], 128))
+        elif name_ == "v_interp":
+            got = m.read_tap(name_, (c["B"], c["T"], c["d"]))
+        else:
+            got = m.read_tap(name_, shp)
+        tol = 2e-6 * max(1.0, float(np.abs(ref).max())) * 4
+        assert maxabs(sliced(got.contiguous().cpu().numpy(), 97), ref) < tol, name_
+    # without taps (the fused conv stack, the two-stream schedule) and as a sub-batch: same answers
+    m2 = build_model(g, dev)
+    with torch.no_grad():
+        sep2, masks2 = m2(t(mixed, dev), t(lips, dev))
+    assert maxabs(masks2.cpu().numpy(), g["masks"]) < MASK_TOL
+    assert maxabs(sep2.cpu().numpy(), g["separated"]) < MASK_TOL * scale
+
+
+@pytest.mark.parametrize("offset", [0.0, 20.0, 100.0, 250.0, -1000.0])
+def test_offset_residual_streams_against_float64_oracle(dev, offset):
+    """the LayerNorm-in-the-epilogue GEMM (every LayerNorm -> Linear site of the d_model <= 256 models)
+    on residual streams that carry a large common offset.  BASELINE config 1's model (d = 256, 2 + 2 layers) with `offset`
+    added to every entry of both PositionalEncoding tables (state_dict buffers `*.pos_enc.pe`, model.py:297-300): the audio,
+    visual and fusion streams then sit at |mean| / std of ~4, ~18, ~45, ~175 (audio encoder and the first fusion LayerNorm) and
+    4x that (visual encoder) -- measured below on the float64 oracle's own taps and asserted -- where the seeded weights alone give
+    0.3-0.75.  The reference path in float32 keeps masks within 4.7e-7 of float64 at all of these (measured with
+    oracle/torch_cpu.py); the HIP path must stay within MASK_TOL, the gate of the un-shifted fixtures."""
+    import av_separation as av
+    F, d, h, Le, Lf, S = 257, 256, 4, 2, 2, 2
+    B, T, N, H, W = 2, 63, 50, 32, 32
+    state = seeded.fill_state(seeded.model_shapes(F, d, h, Le, Lf, S), 4242)
+    pe = (seeded.sinusoid_pe(5000, d) + np.float32(offset)).astype(np.float32)
+    state["audio_encoder.pos_enc.pe"] = pe
+    state["visual_encoder.pos_enc.pe"] = pe.copy()
+    mixed, lips = seeded.inputs(4242, B, F, T, N, H, W)
+    m = av.AVSeparationTransformer(F, d, h, Le, Lf, S, dropout=0.0)
+    sd = m.state_dict()
+    for k, v in state.items():
+        sd[k] = torch.from_numpy(np.ascontiguousarray(v))
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        sep, masks = m(t(mixed, dev), t(lips, dev))
+    taps = {}
+    rs, rm = onp.forward(state, mixed, lips, h, S, dtype=np.float64, taps=taps)
+    if offset:
+        want = {20.0: 4.0, 100.0: 20.0, 250.0: 50.0, -1000.0: 200.0}[offset]
+        # inputs of the encoders' LayerNorm sites and of the first fusion LayerNorm (a_enc1); the cross-attention then adds
+        # W_v (visual + offset) to the fusion stream, whose spread grows with the offset (ratio ~1 there, magnitudes ~offset)
+        for k in ("a_pe", "a_enc0", "a_enc1", "v_enc0"):
+            r = taps[k].reshape(-1, d)
+            ratio = np.abs(r.mean(1)) / r.std(1)
+            assert ratio.min() > want, (k, float(ratio.min()))
+    assert maxabs(masks.cpu().numpy(), rm) < MASK_TOL
+    assert maxabs(sep.cpu().numpy(), rs) < MASK_TOL * max(1.0, float(np.abs(mixed).max()))
+
+
 @pytest.mark.parametrize("wl", ["cfg3", "cfg5"])
 def test_full_batch_properties_big_configs(golden, dev, wl):
     """BASELINE configs[2] / [4] at their FULL per-GPU batch (64 / 32 clips, M = 16 k rows: the large-tile GEMM, the
@@ -463,13 +544,17 @@ def test_op_ln_linear_instances_bit_identical(lib, devlib, dev, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,act,shift", [(2016, 768, 256, 0, 0.0), (2016, 1024, 256, 1, 0.0), (1008, 768, 256, 0, 0.0),
                                              (1001, 260, 256, 2, 0.0), (333, 96, 64, 0, 0.0), (129, 64, 480, 3, 0.0),
-                                             (700, 384, 512, 1, 0.0), (2016, 768, 256, 0, 40.0), (500, 512, 128, 2, -25.0)])
+                                             (700, 384, 512, 1, 0.0), (2016, 768, 256, 0, 40.0), (500, 512, 128, 2, -25.0),
+                                             (2016, 768, 256, 0, 115.0), (2016, 1024, 256, 2, -1000.0), (504, 256, 256, 0, 1e4)])
 def test_op_ln_linear_epilogue_form(lib, devlib, dev, M, N, K, act, shift):
-    """Form 3, LayerNorm in the EPILOGUE: y = rstd (x (W o gamma)^T - mean c1) + c2, a GEMM on the raw rows with the row
-    statistics summed on the side.  Same function as form 0, different rounding: the error against float64 is within the
-    gate of the other forms and within 3 x form 0's own error (+ 1e-6); rows with a large common offset (|mean| / std ~ 17)
-    grow the error by about that ratio and are gated on it.  Every tile computes the same bits: same k order in the matrix
-    cores, and BK = 32 everywhere, so the statistics are summed by the same 8 lanes per row in the same order."""
+    """Form 3, LayerNorm in the EPILOGUE: y = rstd ((x - pilot) (W o gamma)^T - mean' c1) + c2, a GEMM on the rows shifted by
+    their pilot (the mean of the row's first 32 elements, round 4) with the row statistics of the shifted rows summed on the
+    side.  Same function as form 0, different rounding.  |mean(x) - pilot| <= sqrt(K / 32) std(x) for every row, so the error
+    does NOT grow with a common offset of the rows: the same gate holds at |mean| / std = 0.4 and at 4000 (round 3's form,
+    which staged the raw rows, needed the gate scaled by that ratio).  What does grow with the offset is the input's own
+    quantisation (a float32 x carries |x| 2^-24 of noise before any kernel sees it), which form 0 suffers equally -- hence
+    the comparison against form 0 on the SAME float32 rows.  Every tile computes the same bits: same k order in the matrix
+    cores, and BK = 32 everywhere, so the pilot and the statistics are summed by the same 8 lanes per row in the same order."""
     import os
     x = seeded.tensor(19, "x", (M, K), -3, 5) + np.float32(shift)
     w = seeded.tensor(19, "w", (N, K), -0.2, 0.2)
@@ -491,9 +576,9 @@ def test_op_ln_linear_epilogue_form(lib, devlib, dev, M, N, K, act, shift):
     y3 = run(3, lib)
     e3 = (y3.double().cpu() - ref).abs().max().item()
     assert torch.isfinite(y3).all()
-    ratio = 1.0 + abs(shift) / 2.3           # |mean| / std of the rows (uniform(-3, 5): std 2.31)
-    assert e3 < 2e-5 * ratio, (e0, e3)
-    assert e3 < 3.0 * ratio * e0 + 1e-6, (e0, e3)
+    # reference on the float32 rows as the kernels see them (x + shift is rounded once, in numpy, before either form runs)
+    assert e3 < 2e-5, (e0, e3)
+    assert e3 < 3.0 * e0 + 1e-6, (e0, e3)
     try:
         for tile in ("32x32x32", "32x64x32", "64x32x32", "64x64x32", "128x64x32"):
             os.environ["AVSEP_LNX_TILE"] = tile

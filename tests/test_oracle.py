@@ -72,6 +72,32 @@ def test_oracle_baseline_configs(golden, name):
         assert maxabs(sliced(v, 97), ref) < tol, k
 
 
+def test_oracles_on_the_reference_trained_config1_model(golden):
+    """trained_cfg1: BASELINE config 1's model (d = 256, 2 + 2 layers) after the reference's own quick_train
+    (demo.py:83-113), evaluated by the reference on SyntheticAVDataset items 0, 1: both CPU oracles against the reference's
+    full outputs and every stage tap."""
+    import torch
+    from oracle import torch_cpu
+    g = golden("trained_cfg1")
+    c = g["config"]
+    state = golden_state(g)
+    mixed, lips = golden_inputs(g)
+    scale = max(1.0, float(np.abs(mixed).max()))
+    taps = {}
+    sep, masks = onp.forward(state, mixed, lips, c["h"], c["S"], dtype=np.float32, taps=taps)
+    assert maxabs(masks, g["masks"]) < 5e-6 and maxabs(sep, g["separated"]) < 5e-6 * scale
+    for k, v in taps.items():
+        ref = g["tap." + k + ".slice"]
+        assert maxabs(sliced(v, 97), ref) < 5e-5 * max(1.0, float(np.abs(ref).max())), k
+    _, m64 = onp.forward(state, mixed, lips, c["h"], c["S"], dtype=np.float64)
+    assert maxabs(m64, g["masks64"]) < 1e-6          # float32 sin/cos of the pe table (numpy vs torch) is all that differs
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}
+    sp, mk = torch_cpu.forward(st, torch.from_numpy(mixed), torch.from_numpy(lips), c["h"], c["S"])
+    assert maxabs(mk.contiguous().numpy(), g["masks"]) < 2e-6
+    assert maxabs(sp.contiguous().numpy(), g["separated"]) < 2e-6 * scale
+    assert float(g["eval.out_snr"]) - float(g["eval.in_snr"]) > 35.0     # the README's +37 dB recipe (README.md:61-65)
+
+
 def test_seeded_generator_known_answers():
     # splitmix64 reference values (seed 0): published test vector of the algorithm
     z = seeded.splitmix64(0, 3)
