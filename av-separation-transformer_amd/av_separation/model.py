@@ -220,6 +220,7 @@ class _Engine:
         self.sig = None
         self.ws = None
         self.taps = False
+        self.schedule = (0, 8, 0.0)   # avsep_set_schedule arguments, re-applied to every native context this engine creates
         self.static = None     # graph-replay buffers
         self._flat, self._flat_epoch = None, -1
 
@@ -234,6 +235,9 @@ class _Engine:
         self.ctx, self.device, self.sig, self.ws = ctx, device, None, None
         if self.taps:
             _native.check(lib.avsep_set_debug_taps(self.ctx, 1))
+        if self.schedule[0]:
+            _native.check(lib.avsep_set_schedule(self.ctx, int(self.schedule[0]), int(self.schedule[1]), float(self.schedule[2])),
+                          "avsep_set_schedule")
 
     def close(self):
         if self.ctx is not None:
@@ -293,6 +297,12 @@ class _Engine:
         if self.ws is None or self.ws.numel() < need or self.ws.device != device:
             self.ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self.ws, need
+
+    def set_schedule(self, schedule: int, group: int = 8, skew: float = 0.0):
+        self.schedule = (int(schedule), int(group), float(skew))
+        if self.ctx is not None:
+            _native.check(_native.load().avsep_set_schedule(self.ctx, *self.schedule[:2], C.c_float(self.schedule[2])),
+                          "avsep_set_schedule")
 
     def set_taps(self, on: bool):
         self.taps = bool(on)
@@ -523,6 +533,19 @@ class AVSeparationTransformer(_Tracked):
         self._engine.set_taps(on)
         return self
 
+    def set_schedule(self, schedule: int = 0, group: int = 8, skew: float = 0.0):
+        """Launch schedule of the fused eval forward (include/avsep.h avsep_set_schedule): 0 = one launch per op (default), 1 =
+        the encoder layers of each branch as one dependency-driven persistent launch; same output bits either way."""
+        self._engine.set_schedule(schedule, group, skew)
+        for eng in self.__dict__.get("_slot_engines", {}).values():
+            eng.set_schedule(schedule, group, skew)
+        return self
+
+    def chain_status(self):
+        """Raises if a chained launch (schedule 1) of the last forward gave up waiting for a producer tile."""
+        eng = self._engine
+        _native.check(_native.load().avsep_chain_status(eng.ctx, _stream(eng.device)), "avsep_chain_status")
+
     def read_tap(self, name: str, shape):
         eng = self._engine
         B, T, N, H, W = eng.last_dims
@@ -550,6 +573,7 @@ class AVSeparationTransformer(_Tracked):
             eng = extra.get(slot)
             if eng is None:
                 eng = extra[slot] = _Engine(self, "", *self._engine.cfg)
+                eng.schedule = self._engine.schedule
         lib = _native.load()
         with torch.cuda.device(dev):
             st = _stream(dev)

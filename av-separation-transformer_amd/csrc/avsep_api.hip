@@ -116,6 +116,11 @@ struct avsep_ctx {
   bool paired = false;                             // developer experiment: encoder layers of both branches in shared launches
   bool tail_split = true;                          // two-stream schedule: fusion+decoder, half the batch per stream after the join
   std::vector<GraphEntry> graphs;
+  // schedule 1 (avsep_set_schedule): the encoder layers of a branch as ONE dependency-driven persistent launch (chain.hip)
+  int schedule = 0, chain_group = 8;
+  float chain_skew = 0.0f;
+  struct ChainEntry { const float* x; int B, L; const void* layers; ChainPlanImpl* plan; };
+  std::vector<ChainEntry> chains;
   // live per-kernel profiler (HIP events around every launch, on the launch's own stream)
   struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
   bool prof_on = false;
@@ -509,6 +514,83 @@ GemmParams linear_params(const float* A, int lda, const float* W, int K, const f
   return p;
 }
 
+// ---- schedule 1: all pre-norm encoder layers of one branch as ONE persistent, dependency-driven launch (chain.hip).
+// The ops and their operands are exactly those of encoder_layer() below (LayerNorm-epilogue QKV / FFN-1, short-sequence
+// attention, plain out-projection / FFN-2 with the residual in place), so the outputs are the launch-per-op path's bit for bit.
+bool chain_usable(const avsep_ctx* c, const std::vector<EncLayerW>& layers, int B, int L) {
+  const int d = c->d, M = B * L;
+  if (c->schedule != 1 || c->keep_taps || layers.empty() || !c->use_lnx || c->lnx_all) return false;
+  if (c->dh != 64 || L <= 48 || L > 64 || (d & 63)) return false;
+  // the launch-per-op path takes the LayerNorm-epilogue form below 1024 64x64 tiles only (run_ln_linear): same rule, same bits
+  if ((long)((M + 63) / 64) * ((4 * d + 63) / 64) >= 1024) return false;
+  for (const auto& Lw : layers)
+    if (c->lnx.find(Lw.wqkv) == c->lnx.end() || c->lnx.find(Lw.w1) == c->lnx.end()) return false;
+  return true;
+}
+
+// the plan of (x, B, L, layers): device tables built once (hipMalloc + blocking copies -- NOT under stream capture: callers
+// that capture call prepare_chains() first), kept until the context dies or avsep_set_schedule() changes the order
+int get_chain(avsep_ctx* c, const std::vector<EncLayerW>& layers, float* x, float* qkv, float* att, float* ffn, int B, int L,
+              ChainPlanImpl** out) {
+  for (auto& e : c->chains)
+    if (e.x == x && e.B == B && e.L == L && e.layers == (const void*)layers.data()) { *out = e.plan; return AVSEP_OK; }
+  const int d = c->d, M = B * L;
+  ChainBuilder* b = chain_builder_new();
+  if (!b) return fail(AVSEP_ENOMEM, "host allocation failed");
+  int prev = -1;
+  bool ok = true;
+  for (const auto& Lw : layers) {
+    GemmParams pq = linear_params(x, d, nullptr, d, nullptr, qkv, 3 * d, M, 3 * d, ACT_NONE);
+    const LnxW& lq = c->lnx.at(Lw.wqkv);
+    pq.W = lq.w; pq.lnx_c1 = lq.c1; pq.lnx_c2 = lq.c2; pq.ln_eps = 1e-5f;
+    const int o_qkv = chain_add_gemm(b, pq, prev, L);
+    const AttnProblem pa{qkv, qkv + d, qkv + 2 * d, att, 3 * d, 3 * d, 3 * d, d, B, L, L};
+    const int o_att = chain_add_attention(b, pa, c->h, o_qkv);
+    GemmParams po = linear_params(att, d, Lw.wo, d, Lw.bo, x, d, M, d, ACT_NONE);
+    po.R = x; po.ldr = d; po.rperiod = 0;
+    const int o_out = chain_add_gemm(b, po, o_att, L);
+    GemmParams p1 = linear_params(x, d, nullptr, d, nullptr, ffn, 4 * d, M, 4 * d, ACT_RELU);
+    const LnxW& l1 = c->lnx.at(Lw.w1);
+    p1.W = l1.w; p1.lnx_c1 = l1.c1; p1.lnx_c2 = l1.c2; p1.ln_eps = 1e-5f;
+    const int o_f1 = chain_add_gemm(b, p1, o_out, L);
+    GemmParams p2 = linear_params(ffn, 4 * d, Lw.w2, 4 * d, Lw.b2, x, d, M, d, ACT_NONE);
+    p2.R = x; p2.ldr = d; p2.rperiod = 0;
+    prev = chain_add_gemm(b, p2, o_f1, L);
+    ok = ok && o_qkv >= 0 && o_att >= 0 && o_out >= 0 && o_f1 >= 0 && prev >= 0;
+  }
+  ChainPlanImpl* plan = nullptr;
+  hipError_t e = ok ? chain_build(b, c->chain_group, c->chain_skew, &plan) : hipErrorInvalidValue;
+  chain_builder_free(b);
+  if (e != hipSuccess) return fail_hip(e, "chain_build (encoder layers)");
+  c->chains.push_back({x, B, L, (const void*)layers.data(), plan});
+  *out = plan;
+  return AVSEP_OK;
+}
+
+int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
+                  int Lseq, hipStream_t s);
+
+// every encoder layer of one branch, in place on x
+int encoder_layers(avsep_ctx* c, const std::vector<EncLayerW>& layers, const Workspace& w, bool audio, int B, int L,
+                   hipStream_t s) {
+  float* x = audio ? w.a_x : w.v_x;
+  float* ln = audio ? w.ln : w.v_ln;
+  float* qkv = audio ? w.qkv : w.v_qkv;
+  float* att = audio ? w.att : w.v_att;
+  float* ffn = audio ? w.ffn : w.v_ffn;
+  if (chain_usable(c, layers, B, L)) {
+    ChainPlanImpl* plan = nullptr;
+    RCK(get_chain(c, layers, x, qkv, att, ffn, B, L, &plan));
+    return profiled(c, audio ? "chain_kernel (audio encoder layers)" : "chain_kernel (visual encoder layers)",
+                    chain_plan_flops(plan), chain_plan_bytes(plan), s, [&] { return launch_chain(plan, s); });
+  }
+  for (size_t i = 0; i < layers.size(); ++i) {
+    RCK(encoder_layer(c, layers[i], x, ln, qkv, att, ffn, B, L, s));
+    RCK(record_tap(c, w, ((audio ? "a_enc" : "v_enc") + std::to_string(i)).c_str(), x, (size_t)B * L * c->d, s));
+  }
+  return AVSEP_OK;
+}
+
 // one pre-norm encoder layer: x += Wo*Attn(LN1 x); x += W2*relu(W1*LN2 x)   (model.py:48-52, norm_first)
 int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
                   int Lseq, hipStream_t s) {
@@ -591,12 +673,7 @@ int audio_front(avsep_ctx* c, const Workspace& w, const float* mixed, int B, int
 // AudioEncoder.forward (model.py:54-60); result left in w.a_x.
 int audio_branch(avsep_ctx* c, const Workspace& w, const float* mixed, int B, int T, hipStream_t s) {
   RCK(audio_front(c, w, mixed, B, T, s));
-  const int d = c->d, M = B * T;
-  for (int i = 0; i < c->Le; ++i) {
-    RCK(encoder_layer(c, c->a_layers[i], w.a_x, w.ln, w.qkv, w.att, w.ffn, B, T, s));
-    RCK(record_tap(c, w, ("a_enc" + std::to_string(i)).c_str(), w.a_x, (size_t)M * d, s));
-  }
-  return AVSEP_OK;
+  return encoder_layers(c, c->a_layers, w, /*audio=*/true, B, T, s);
 }
 
 // VisualEncoder.conv + frame_proj + pos_enc (model.py:106-110): (B,N,H,W) -> w.v_x (B*N, d).
@@ -658,11 +735,7 @@ int visual_upsample(avsep_ctx* c, const Workspace& w, int B, int N, int T, hipSt
 int visual_branch(avsep_ctx* c, const Workspace& w, const float* lips, int B, int N, int H, int W, int T,
                   hipStream_t s) {
   RCK(visual_front(c, w, lips, B, N, H, W, s));
-  const int d = c->d, Mv = B * N;
-  for (int i = 0; i < c->Le; ++i) {
-    RCK(encoder_layer(c, c->v_layers[i], w.v_x, w.v_ln, w.v_qkv, w.v_att, w.v_ffn, B, N, s));
-    RCK(record_tap(c, w, ("v_enc" + std::to_string(i)).c_str(), w.v_x, (size_t)Mv * d, s));
-  }
+  RCK(encoder_layers(c, c->v_layers, w, /*audio=*/false, B, N, s));
   return visual_upsample(c, w, B, N, T, s);
 }
 
@@ -963,6 +1036,7 @@ void avsep_destroy(avsep_ctx* c) {
     (void)hipStreamDestroy(g.side);
   }
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto& e : c->chains) chain_plan_free(e.plan);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_vdone) (void)hipEventDestroy(c->ev_vdone);
   if (c->ev_adone) (void)hipEventDestroy(c->ev_adone);
@@ -971,6 +1045,38 @@ void avsep_destroy(avsep_ctx* c) {
   if (c->arena) (void)hipFree(c->arena);
   if (c->stamps) (void)hipFree(c->stamps);
   delete c;
+}
+
+int avsep_set_schedule(avsep_ctx* c, int schedule, int group, float skew) try {
+  if (!c) return fail(AVSEP_EINVAL, "null context");
+  if (schedule < 0 || schedule > 1) return fail(AVSEP_EINVAL, "schedule: 0 = one launch per op, 1 = chained encoder layers");
+  if (group < 0 || !(skew >= 0.0f) || skew > 64.0f) return fail(AVSEP_EINVAL, "bad work-list order");
+  DeviceScope guard(c->device);
+  // plans and captured graphs of the previous schedule may be in flight: drain, then drop them
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  for (auto& g : c->graphs) (void)hipStreamSynchronize(g.last_stream);
+  (void)hipDeviceSynchronize();
+  for (auto& g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipStreamDestroy(g.cap); (void)hipStreamDestroy(g.side); }
+  c->graphs.clear();
+  for (auto& e : c->chains) chain_plan_free(e.plan);
+  c->chains.clear();
+  c->schedule = schedule; c->chain_group = group; c->chain_skew = skew;
+  return AVSEP_OK;
+} catch (...) {
+  return on_exception();
+}
+
+int avsep_chain_status(avsep_ctx* c, void* stream) try {
+  if (!c) return fail(AVSEP_EINVAL, "null context");
+  int bad = 0;
+  for (auto& e : c->chains) {
+    unsigned word = 0;
+    HCK(chain_plan_error(e.plan, reinterpret_cast<hipStream_t>(stream), &word));
+    if (word) { bad = (int)word; g_err = "a chained launch gave up waiting for a producer tile (ticket " + std::to_string(word - 1) + ")"; }
+  }
+  return bad ? AVSEP_EINTERNAL : AVSEP_OK;
+} catch (...) {
+  return on_exception();
 }
 
 int avsep_profile_begin(avsep_ctx* c) try {
@@ -1195,6 +1301,16 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
     if (e != hipSuccess) { (void)hipStreamDestroy(g.cap); return fail_hip(e, "hipStreamCreate(capture side stream)"); }
     auto drop_streams = [&] { (void)hipStreamDestroy(g.cap); (void)hipStreamDestroy(g.side); };
     hipGraph_t graph = nullptr;
+    if (c->schedule == 1) {      // the chain plans allocate device tables: build them BEFORE the capture starts
+      Workspace w;
+      if (ws_bytes >= carve(c, &w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float)) {
+        ChainPlanImpl* plan = nullptr;
+        int r = AVSEP_OK;
+        if (chain_usable(c, c->a_layers, B, T)) r = get_chain(c, c->a_layers, w.a_x, w.qkv, w.att, w.ffn, B, T, &plan);
+        if (r == AVSEP_OK && chain_usable(c, c->v_layers, B, N)) r = get_chain(c, c->v_layers, w.v_x, w.v_qkv, w.v_att, w.v_ffn, B, N, &plan);
+        if (r != AVSEP_OK) { drop_streams(); return r; }
+      }
+    }
     e = hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { drop_streams(); return fail_hip(e, "hipStreamBeginCapture"); }
     hipStream_t ctx_side = c->side;

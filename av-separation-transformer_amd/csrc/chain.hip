@@ -1,0 +1,356 @@
+// chain.hip -- a dependency-driven, persistent launch for chains of small dependent ops (round 4).
+//
+// The 32-clip step of BASELINE configs[1] is ~54 launches of 7-13 us on two streams; every launch boundary is a device-wide
+// barrier although NO dependency of the eval forward crosses a clip (/root/reference/src/av_separation/model.py:54-60, 103-117,
+// 166-173, 201-208: attention per clip, everything else per row).  Here a run of ops (the pre-norm encoder layers of one
+// branch: LayerNorm-epilogue QKV GEMM -> short-sequence attention -> out-projection + residual -> LayerNorm-epilogue FFN-1 ->
+// FFN-2 + residual, model.py:48-52 / 97-101 via nn.TransformerEncoderLayer) is ONE launch of resident workgroups that pull
+// tiles from a topologically ordered work list:
+//
+//   * item = one tile of one op: a 32-row x 64- (LayerNorm-epilogue) or 32-column (plain) GEMM tile, or the 4 query tiles of one
+//     (clip, head) of the attention.  The tile code is the code of the stand-alone kernels (gemm_tile.h, attn_tile.h): same
+//     k order, same epilogues, so every output bit equals the launch-per-op path's (tests/test_gpu_parity.py).
+//   * every op owns one arrival counter per 32-row block (GEMMs) or per clip (attention).  A tile starts when the counters of the
+//     producer units its rows need have reached the producer's tile count -- a clip's attention waits for the 2-3 row blocks of
+//     QKV that cover the clip, a row block of the out-projection for the 1-2 clips it touches, a GEMM behind a GEMM for its own
+//     row block -- and adds 1 to its own unit's counter when its stores have drained.
+//   * hand-off (cdna_hip_programming.md Guideline 16, form R1): every activation written inside the launch is stored
+//     write-through (buffer_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE
+//     lane adds to the counter (agent scope); the consumer's first wave polls the counters with sc1 loads, the workgroup meets at
+//     a barrier, and EVERY load of handed-off bytes is an L1-bypassing sc1 load.  No release / acquire fence, no dependence on
+//     which XCD a workgroup landed on.  Weights, biases and the LayerNorm side vectors are read-only for the launch: plain loads.
+//   * tickets come from one agent-scope atomic counter; the list order is a topological order, so a workgroup only ever waits for
+//     tiles with LOWER tickets, all of which have been claimed by running workgroups: no co-residency requirement, no deadlock.
+//     Every spin is bounded; a timeout sets an error word and the grid still drains.
+//   * counters, the ticket word and the error word are zeroed by a memset node in front of the launch (replayed with it).
+#include "kernels.h"
+#include "gemm_tile.h"
+#include "attn_tile.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+namespace {
+
+enum { CH_GEMM_PLAIN = 0, CH_GEMM_LNX = 1, CH_ATTN = 2 };
+
+struct ChainOp {              // device table, one per op; every field is wave-uniform
+  int kind, act;
+  const float *A, *W, *bias, *R, *c1, *c2;     // GEMM operands (R: residual or null; c1 / c2: LayerNorm-epilogue vectors)
+  float* C;
+  int M, N, K, lda, ldc, ldr;
+  float eps, inv_k;
+  const float *q, *k, *v;                      // attention operands (head h at column offset 64 h)
+  float* o;
+  int ldq, ldk, ldv, ldo, Lq, Lk, nhead, pad;
+};
+
+struct ChainItem {            // device table, one per ticket
+  int op, m0, n0;             // GEMM: tile origin; attention: m0 = clip, n0 = head
+  int dep_lo, dep_n, dep_target;   // counters [dep_lo, dep_lo + dep_n) must each have reached dep_target (dep_n = 0: no wait)
+  int sig;                    // counter this tile adds 1 to when its stores have drained
+  int pad;
+};
+
+struct ChainArgs {
+  const ChainOp* ops;
+  const ChainItem* items;
+  int n_items;
+  unsigned* state;            // [0] ticket head, [1] error word, [2..3] unused, [4..] counters
+};
+
+enum { CHAIN_STATE_HDR = 4, CHAIN_SPIN_LIMIT = 2000000 };
+
+template <typename T>
+__device__ __forceinline__ T uni(T v) {       // the value is wave-uniform: move it to SGPRs
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte scalars");
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+  } else {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+  }
+}
+
+// WPS = workgroups per CU the register budget is cut for: 4 (128 VGPRs: the persistent loop keeps lane constants of three tile
+// kinds alive and spills ~25 of them, a few reloads inside the K loops) or 3 (168 VGPRs, no spill)
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[8192];     // 32 KB: the 32x32x64 plain tile; the 32x64x32 tile takes 24 KB
+  __shared__ int s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned* const head = a.state;
+  unsigned* const err = a.state + 1;
+  unsigned* const cnt = a.state + CHAIN_STATE_HDR;
+  for (;;) {
+    if (tid == 0) s_ticket = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int t = uni(s_ticket);
+    if (t >= a.n_items) break;
+    const ChainItem* ip = a.items + t;
+    const int it_op = uni(ip->op), it_m0 = uni(ip->m0), it_n0 = uni(ip->n0);
+    const int dep_lo = uni(ip->dep_lo), dep_n = uni(ip->dep_n), dep_target = uni(ip->dep_target), sig = uni(ip->sig);
+    const ChainOp* op = a.ops + it_op;
+    const int kind = uni(op->kind);
+    if (dep_n > 0) {                                                    // block-uniform
+      if (wave == 0) {
+        const unsigned* w = cnt + dep_lo + min(lane, dep_n - 1);
+        for (int spins = 0;; ++spins) {
+          const unsigned v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load_dword sc1
+          if (__all((int)v >= dep_target)) break;
+          if (spins > CHAIN_SPIN_LIMIT) {                               // never hang the device: flag it and go on (wrong data)
+            if (lane == 0) __hip_atomic_store(err, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // no instruction: keeps the tile's loads below the poll
+      __syncthreads();
+    }
+    if (kind == CH_ATTN) {
+      const int Lq = uni(op->Lq), Lk = uni(op->Lk), ldq = uni(op->ldq), ldk = uni(op->ldk), ldv = uni(op->ldv), ldo = uni(op->ldo);
+      const int nqt = (Lq + 15) >> 4;
+      if (wave < nqt) {                                                 // wave = 16-query tile of (clip it_m0, head it_n0)
+        const int c = lane & 15, g = lane >> 4;
+        const float* qb = uni(op->q) + (size_t)it_m0 * Lq * ldq + it_n0 * 64;
+        const float* kb = uni(op->k) + (size_t)it_m0 * Lk * ldk + it_n0 * 64;
+        const float* vb = uni(op->v) + (size_t)it_m0 * Lk * ldv + it_n0 * 64;
+        float* ob = uni(op->o) + (size_t)it_m0 * Lq * ldo + it_n0 * 64;
+        f32x4 acc[4];
+        float lrun;
+        attn_short_tile<4, 4, true>(qb, kb, vb, ldq, ldk, ldv, Lq, Lk, wave, c, g, acc, lrun);
+        lrun = rows_sum(lrun);
+        const float inv = 1.0f / lrun;
+        const int qo = wave * 16 + c;
+        if (qo < Lq) {
+          const __amdgpu_buffer_rsrc_t ro = coh_rsrc(ob);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            coh_store16(ro, (qo * ldo + 4 * (4 * g + r)) * 4, f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv});
+        }
+      }
+    } else {
+      GemmParams p{};
+      p.A = uni(op->A); p.W = uni(op->W); p.bias = uni(op->bias); p.C = uni(op->C);
+      p.M = uni(op->M); p.N = uni(op->N); p.K = uni(op->K);
+      p.lda = uni(op->lda); p.ldw = p.K; p.ldc = uni(op->ldc);
+      p.act = uni(op->act);
+      p.R = uni(op->R); p.ldr = uni(op->ldr);
+      p.ln_eps = uni(op->eps); p.ln_inv_k = uni(op->inv_k);
+      if (kind == CH_GEMM_LNX) {
+        p.amode = AMODE_LNX;
+        p.lnx_c1 = uni(op->c1); p.lnx_c2 = uni(op->c2);
+        gemm_tile<32, 64, 32, AMODE_LNX, false, 0, true>(p, it_m0, it_n0, lds);
+      } else {
+        p.amode = AMODE_PLAIN;
+        gemm_tile<32, 32, 64, AMODE_PLAIN, false, 0, true>(p, it_m0, it_n0, lds);
+      }
+    }
+    // publish: every storing wave drains its write-through stores, the workgroup meets, ONE lane signals
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(cnt + sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------ host side
+struct ChainPlanImpl {
+  ChainOp* ops_dev = nullptr;
+  ChainItem* items_dev = nullptr;
+  unsigned* state_dev = nullptr;
+  int n_items = 0, n_ops = 0, grid = 0, wps = 4;
+  size_t state_bytes = 0;
+  double flops = 0.0, bytes = 0.0;
+};
+
+namespace {
+
+struct HostOp {
+  ChainOp op;
+  int units;                  // counters this op owns: row blocks (GEMM) or clips (attention)
+  int tiles_per_unit;         // arrivals that complete a unit
+  int dep;                    // producer op index or -1
+  int rows_per_clip;          // geometry of the sequence tensor the op works on (for GEMM <-> attention unit mapping)
+  int first_counter;
+};
+
+}  // namespace
+
+void chain_plan_free(ChainPlanImpl* p);
+
+struct ChainBuilder {
+  std::vector<HostOp> ops;
+  double flops = 0.0, bytes = 0.0;
+};
+
+ChainBuilder* chain_builder_new() { return new (std::nothrow) ChainBuilder(); }
+void chain_builder_free(ChainBuilder* b) { delete b; }
+
+// GEMM op from the launch-per-op path's own parameters (PLAIN A operand, or LayerNorm-in-the-epilogue when p.lnx_c1).
+// dep: index of the producer op whose output this op's A rows (and residual rows) come from, or -1.  L: rows per clip.
+int chain_add_gemm(ChainBuilder* b, const GemmParams& p, int dep, int L) {
+  const bool lnx = p.lnx_c1 != nullptr;
+  if (p.amode != AMODE_PLAIN || p.C2 || p.mag_F > 0 || p.ksplit > 1 || p.drop_p > 0.0f || (p.N & 3) || (p.ldc & 3) ||
+      (p.R && ((p.ldr & 3) || p.rperiod > 0)) || p.ln_gamma || p.ln_stats)
+    return -1;
+  if (lnx ? (p.K % 32 != 0 || p.bias || p.R) : (p.K % 64 != 0)) return -1;
+  if ((long long)p.M * std::max(p.lda, std::max(p.ldc, p.ldr)) * 4 >= (1LL << 31)) return -1;       // 32-bit buffer offsets
+  HostOp h{};
+  h.op.kind = lnx ? CH_GEMM_LNX : CH_GEMM_PLAIN;
+  h.op.act = p.act;
+  h.op.A = p.A; h.op.W = p.W; h.op.bias = p.bias; h.op.R = p.R; h.op.c1 = p.lnx_c1; h.op.c2 = p.lnx_c2; h.op.C = p.C;
+  h.op.M = p.M; h.op.N = p.N; h.op.K = p.K; h.op.lda = p.lda; h.op.ldc = p.ldc; h.op.ldr = p.ldr;
+  h.op.eps = p.ln_eps; h.op.inv_k = 1.0f / (float)p.K;
+  const int bn = lnx ? 64 : 32;
+  h.units = (p.M + 31) / 32;
+  h.tiles_per_unit = (p.N + bn - 1) / bn;
+  h.dep = dep;
+  h.rows_per_clip = L;
+  b->ops.push_back(h);
+  b->flops += 2.0 * p.M * p.N * p.K;
+  b->bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (p.R ? 2 : 1));
+  return (int)b->ops.size() - 1;
+}
+
+// Short-sequence attention (dh = 64, 49..64 keys) of B clips x nhead heads; dep: the op that wrote q / k / v (or -1).
+int chain_add_attention(ChainBuilder* b, const AttnProblem& a, int nhead, int dep) {
+  if (a.Lq <= 0 || a.Lq > 64 || a.Lk <= 48 || a.Lk > 64 || ((a.ldq | a.ldk | a.ldv | a.ldo) & 3)) return -1;
+  if ((long long)a.B * a.Lk * std::max(std::max(a.ldq, a.ldk), std::max(a.ldv, a.ldo)) * 4 >= (1LL << 31)) return -1;
+  HostOp h{};
+  h.op.kind = CH_ATTN;
+  h.op.q = a.q; h.op.k = a.k; h.op.v = a.v; h.op.o = a.o;
+  h.op.ldq = a.ldq; h.op.ldk = a.ldk; h.op.ldv = a.ldv; h.op.ldo = a.ldo; h.op.Lq = a.Lq; h.op.Lk = a.Lk; h.op.nhead = nhead;
+  h.op.M = a.B * a.Lq;
+  h.units = a.B;
+  h.tiles_per_unit = nhead;
+  h.dep = dep;
+  h.rows_per_clip = a.Lq;
+  b->ops.push_back(h);
+  b->flops += 4.0 * a.B * nhead * (double)a.Lq * a.Lk * 64;
+  b->bytes += 4.0 * a.B * nhead * 64 * (2.0 * a.Lq + 2.0 * a.Lk);
+  return (int)b->ops.size() - 1;
+}
+
+// Work list: one item per tile, in a topological order that follows `skew`: items are ranked by (op index + skew x clip group)
+// and emitted in rank order as soon as every producer tile they wait for has been emitted.  skew = 0: op-major (all tiles of an
+// op, then the next op's -- the launch-per-op order without the launch boundaries); skew > 0: groups of `group` clips run
+// `skew` ops apart, so that tiles of different ops (different phases: latency-bound attention, MFMA-bound FFN) share the CUs.
+hipError_t chain_build(ChainBuilder* b, int order_group, float order_skew, ChainPlanImpl** out) {
+  *out = nullptr;
+  const int n_ops = (int)b->ops.size();
+  if (n_ops == 0) return hipErrorInvalidValue;
+  int n_counters = 0;
+  for (auto& h : b->ops) { h.first_counter = n_counters; n_counters += h.units; }
+  struct Raw { ChainItem it; float rank; int idx; };
+  std::vector<Raw> raw;
+  for (int o = 0; o < n_ops; ++o) {
+    const HostOp& h = b->ops[o];
+    const int L = h.rows_per_clip;
+    for (int u = 0; u < h.units; ++u)
+      for (int t = 0; t < h.tiles_per_unit; ++t) {
+        ChainItem it{};
+        it.op = o;
+        int row_lo, row_hi;                                               // rows of the sequence tensor this tile reads / writes
+        if (h.op.kind == CH_ATTN) { it.m0 = u; it.n0 = t; row_lo = u * L; row_hi = u * L + L - 1; }
+        else { it.m0 = 32 * u; it.n0 = (h.op.kind == CH_GEMM_LNX ? 64 : 32) * t; row_lo = 32 * u; row_hi = std::min(32 * u + 31, h.op.M - 1); }
+        it.sig = h.first_counter + u;
+        if (h.dep >= 0) {
+          const HostOp& pr = b->ops[h.dep];
+          int lo, hi;
+          if (pr.op.kind == CH_ATTN) { lo = row_lo / pr.rows_per_clip; hi = row_hi / pr.rows_per_clip; }
+          else { lo = row_lo / 32; hi = row_hi / 32; }
+          if (hi >= pr.units) hi = pr.units - 1;
+          it.dep_lo = pr.first_counter + lo; it.dep_n = hi - lo + 1; it.dep_target = pr.tiles_per_unit;
+          if (it.dep_n > 64) return hipErrorInvalidValue;
+        }
+        const int clip = row_lo / std::max(1, L);
+        raw.push_back({it, (float)o + order_skew * (float)(order_group > 0 ? clip / order_group : 0), (int)raw.size()});
+      }
+  }
+  std::stable_sort(raw.begin(), raw.end(), [](const Raw& x, const Raw& y) { return x.rank < y.rank; });
+  // emit in rank order, an item only after all producer tiles of the counters it polls (a topological order by construction)
+  std::vector<int> emitted(n_counters, 0);
+  std::vector<char> done(raw.size(), 0);
+  std::vector<ChainItem> items;
+  items.reserve(raw.size());
+  size_t first_open = 0;
+  while (items.size() < raw.size()) {
+    bool progressed = false;
+    for (size_t i = first_open; i < raw.size(); ++i) {
+      if (done[i]) { if (i == first_open) ++first_open; continue; }
+      const ChainItem& it = raw[i].it;
+      bool ready = true;
+      for (int k = 0; k < it.dep_n && ready; ++k) ready = emitted[it.dep_lo + k] >= it.dep_target;
+      if (!ready) continue;
+      items.push_back(it);
+      ++emitted[it.sig];
+      done[i] = 1;
+      progressed = true;
+      break;                                                               // restart from the lowest rank still open
+    }
+    if (!progressed) return hipErrorInvalidValue;                           // a dependency cycle: cannot happen for a chain
+  }
+  ChainPlanImpl* p = new (std::nothrow) ChainPlanImpl();
+  if (!p) return hipErrorOutOfMemory;
+  p->n_items = (int)items.size();
+  p->n_ops = n_ops;
+  p->flops = b->flops; p->bytes = b->bytes;
+  p->state_bytes = ((size_t)(CHAIN_STATE_HDR + n_counters) * sizeof(unsigned) + 15) / 16 * 16;
+  std::vector<ChainOp> ops(n_ops);
+  for (int o = 0; o < n_ops; ++o) ops[o] = b->ops[o].op;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ops_dev), ops.size() * sizeof(ChainOp));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->items_dev), items.size() * sizeof(ChainItem));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->state_dev), p->state_bytes);
+  if (e == hipSuccess) e = hipMemcpy(p->ops_dev, ops.data(), ops.size() * sizeof(ChainOp), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->items_dev, items.data(), items.size() * sizeof(ChainItem), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(p->state_dev, 0, p->state_bytes);
+  int per_cu = 0, dev = 0, cus = 256;
+  p->wps = 4;
+  if (const char* g = dev_env("AVSEP_CHAIN_WPS")) p->wps = atoi(g) == 3 ? 3 : 4;       // developer sweep
+  if (e == hipSuccess)
+    e = p->wps == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain_kernel<3>), 256, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain_kernel<4>), 256, 0);
+  if (e == hipSuccess) e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) { chain_plan_free(p); return e; }
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > p->wps) per_cu = p->wps;
+  if (const char* g = dev_env("AVSEP_CHAIN_WGPC")) per_cu = std::max(1, atoi(g));      // developer sweep
+  p->grid = std::min(p->n_items, cus * per_cu);
+  *out = p;
+  return hipSuccess;
+}
+
+void chain_plan_free(ChainPlanImpl* p) {
+  if (!p) return;
+  if (p->ops_dev) (void)hipFree(p->ops_dev);
+  if (p->items_dev) (void)hipFree(p->items_dev);
+  if (p->state_dev) (void)hipFree(p->state_dev);
+  delete p;
+}
+
+double chain_plan_flops(const ChainPlanImpl* p) { return p->flops; }
+double chain_plan_bytes(const ChainPlanImpl* p) { return p->bytes; }
+int chain_plan_items(const ChainPlanImpl* p) { return p->n_items; }
+
+hipError_t launch_chain(const ChainPlanImpl* p, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(p->state_dev, 0, p->state_bytes, s);
+  if (e != hipSuccess) return e;
+  ChainArgs a{p->ops_dev, p->items_dev, p->n_items, p->state_dev};
+  if (p->wps == 3) hipLaunchKernelGGL(chain_kernel<3>, dim3((unsigned)p->grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(chain_kernel<4>, dim3((unsigned)p->grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// the error word of the last launch (0 = every wait was satisfied); synchronises the stream
+hipError_t chain_plan_error(const ChainPlanImpl* p, hipStream_t s, unsigned* word) {
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  return hipMemcpy(word, p->state_dev + 1, sizeof(unsigned), hipMemcpyDeviceToHost);
+}

@@ -158,6 +158,25 @@ int wgrad_tiles(int N, int K, int R);
 const char* gemm_instance_name(const GemmParams& p);
 bool gemm_ln_supported(int K);                          // can launch_gemm() fuse a LayerNorm over K columns?   // template instance launch_gemm() will pick
 
+// ---- dependency-driven persistent launch of a chain of small ops (chain.hip)
+struct AttnProblem;
+struct ChainBuilder;
+struct ChainPlanImpl;
+ChainBuilder* chain_builder_new();
+void chain_builder_free(ChainBuilder* b);
+// ops are added in execution order; `dep` = index (return value) of the op that produces this op's input rows, or -1 when they
+// come from an earlier launch; L = rows per clip of the sequence tensor.  -1 = the op cannot run as a chain tile.
+int chain_add_gemm(ChainBuilder* b, const GemmParams& p, int dep, int L);
+int chain_add_attention(ChainBuilder* b, const AttnProblem& a, int nhead, int dep);
+// device tables of the work list (hipMalloc + blocking copies: never call it while a stream capture is in progress)
+hipError_t chain_build(ChainBuilder* b, int order_group, float order_skew, ChainPlanImpl** out);
+void chain_plan_free(ChainPlanImpl* p);
+double chain_plan_flops(const ChainPlanImpl* p);
+double chain_plan_bytes(const ChainPlanImpl* p);
+int chain_plan_items(const ChainPlanImpl* p);
+hipError_t launch_chain(const ChainPlanImpl* p, hipStream_t s);                       // memset of the counters + ONE kernel
+hipError_t chain_plan_error(const ChainPlanImpl* p, hipStream_t s, unsigned* word);   // 0 = no wait timed out (synchronises s)
+
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int d, float eps,
                             hipStream_t s);
 // row statistics of nn.LayerNorm only: stats[2m] = mean, stats[2m+1] = 1/sqrt(biased var + eps), the values

@@ -74,6 +74,13 @@ def flops_per_clip(F, T, N, H, W, d, Le, Lf, S):
             + 2 * T * d * 2 * d + 2 * T * 2 * d * F * S)
 
 
+def metric_string(mk, dk, steps_in_flight):
+    """BASELINE.json's metric, spelled for the workload that ran (VERDICT r3: the cfg3 / cfg5 lines printed cfg2's)."""
+    dur, sr = dk["duration"], dk["sample_rate"] // 1000
+    return (f"separated clips/sec ({mk['num_speakers']}-spk, {dur:g}s@{sr}kHz, d={mk['d_model']}) forward, fp32" +
+            (f", throughput with {steps_in_flight} steps in flight" if steps_in_flight > 1 else ""))
+
+
 def shard_range(rank, world, batch):
     """Clip indices of this rank: shard r owns clips [r*batch, (r+1)*batch) of the synthetic stream."""
     return range(rank * batch, (rank + 1) * batch)
@@ -302,7 +309,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event leg (roofline = path only)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--mode", default="forward", choices=("forward", "train"),
                     help="forward = the headline metric; train = one DP training step per 'step' (row N1, not the headline)")
     ap.add_argument("--dropout", type=float, default=0.1, help="train mode only (reference default 0.1)")
@@ -316,6 +323,17 @@ def main():
                     help="also time the PCIe-inclusive streamed mode (distinct pinned host batches, double-buffered "
                          "H2D/D2H on side streams); reported as `stream` next to the resident-batch value")
     ap.add_argument("--stream-steps", type=int, default=200)
+    ap.add_argument("--schedule", type=int, default=0,
+                    help="launch schedule of the forward (include/avsep.h avsep_set_schedule): 0 = one launch per op, 1 = the "
+                         "encoder layers of each branch as one dependency-driven persistent launch")
+    ap.add_argument("--chain-group", type=int, default=8, help="schedule 1: clips per group of the work-list order")
+    ap.add_argument("--chain-skew", type=float, default=0.0, help="schedule 1: ops between consecutive clip groups (0 = op-major)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the `also` block (short cfg3 / cfg5 forward and cfg4 training lines behind the default cfg2 run; "
+                         "--no-cpu and --no-profile, the developer tools' flags, skip it too)")
+    ap.add_argument("--no-quality", action="store_true",
+                    help="skip the trained-weights quality pair of the cpu_baseline block (the reference's demo recipe on the "
+                         "HIP path and on the CPU port)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU-only check of the N>1 launch path (spawn, rendezvous, barrier, max-over-ranks, one JSON "
                          "line): no GPU work, gloo backend; used by tests/test_shards_gloo.py")
@@ -357,6 +375,8 @@ def main():
     mk, dk = wl["model"], wl["data"]
     torch.manual_seed(0)                       # same random-init weights on every rank (replicated model)
     model = av.AVSeparationTransformer(dropout=0.0, **mk).to(dev).eval()
+    if a.schedule:
+        model.set_schedule(a.schedule, a.chain_group, a.chain_skew)
     # R = --inflight independent steps are kept in flight: step i runs on stream i % R with batch / output / workspace
     # set i % R (R distinct resident batches per rank; a batch of 32 clips alone leaves the 256 CUs latency-bound, a second
     # one fills the bubbles -- what a serving loop does).  Every step is a complete forward of its own 32-clip batch.
@@ -465,9 +485,24 @@ def main():
             roofline["traffic_note"] = (f"profiles/pmc_hbm_traffic.json was measured on build {pmc_file.get('build_id')}, "
                                         f"the loaded library is {build_id}: traffic withheld (re-run tools/pmc_bench.sh)")
         elif hit:
-            roofline["traffic"] = round(hit["fetch_bytes_per_launch"] + hit["write_bytes_per_launch"])
-            roofline["traffic_unit"] = "HBM-side bytes per launch (PMC, profiles/pmc_hbm_traffic.json, same build id)"
-            roofline["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["calls"])
+            # ONE launch population for both figures: the PMC pass traces the eager TWO-stream
+            # forward, whose tail runs as two half-batch launches per site (cfg2: 18 launches of the dominant instance per
+            # forward, where the one-stream profile leg above has 13 full-batch ones).  The instance's algorithmic bytes
+            # per forward are the same either way (a split site moves the same A and C rows; its W is counted once), so
+            # both per-launch figures are per-forward totals over the PMC pass's launch count.
+            n_pmc = hit["calls_per_forward"]
+            alg_fwd = dom["bytes"] / prof_iters
+            traffic_launch = hit["fetch_bytes_per_launch"] + hit["write_bytes_per_launch"]
+            roofline["traffic"] = round(traffic_launch)
+            roofline["traffic_unit"] = ("HBM-side bytes per launch, averaged over the launches of the eager two-stream "
+                                        "forward (PMC, profiles/pmc_hbm_traffic.json, same build id)")
+            roofline["algorithmic_bytes_per_launch"] = round(alg_fwd / n_pmc)
+            roofline["traffic_population"] = {"launches_per_forward": round(n_pmc, 2),
+                                              "traffic_bytes_per_forward": round(traffic_launch * n_pmc),
+                                              "fetch_bytes_per_forward": round(hit["fetch_bytes_per_launch"] * n_pmc),
+                                              "write_bytes_per_forward": round(hit["write_bytes_per_launch"] * n_pmc),
+                                              "algorithmic_bytes_per_forward": round(alg_fwd),
+                                              "traffic_over_algorithmic": round(traffic_launch * n_pmc / alg_fwd, 3)}
     except (OSError, KeyError, ValueError):
         pass
 
@@ -481,14 +516,18 @@ def main():
     except (OSError, ValueError):
         pass
     if in_graph.get(dom["name"]):
-        # (no fraction is derived from it: inside the graph the tail runs as two half-batch launches per kernel, so an
-        # instance's launches there are not the launches the profile leg priced)
-        roofline["in_graph_avg_launch_us"] = round(in_graph[dom["name"]]["avg_us"], 3)
-        roofline["in_graph_launches_per_step"] = round(in_graph[dom["name"]]["calls_per_step"], 2)
+        # inside the replayed step the tail runs as two half-batch launches per site: the instance's flops per STEP are the
+        # profile leg's, its time per step is launches x average duration there -> the fraction it reaches beside the
+        # other kernels of the step
+        ig = in_graph[dom["name"]]
+        roofline["in_graph_avg_launch_us"] = round(ig["avg_us"], 3)
+        roofline["in_graph_launches_per_step"] = round(ig["calls_per_step"], 2)
+        ig_tf = dom["flops"] / prof_iters / (ig["calls_per_step"] * ig["avg_us"] * 1e-6) / 1e12
+        roofline["in_graph_achieved"] = round(ig_tf, 3)
+        roofline["in_graph_frac"] = round(ig_tf / FP32_MATRIX_PEAK_TFLOPS, 4)
 
     out = {
-        "metric": "separated clips/sec (2-spk, 1s@8kHz, d=256) forward, fp32" +
-                  (f", throughput with {R} steps in flight" if R > 1 else ""),
+        "metric": metric_string(mk, dk, R),
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -499,6 +538,8 @@ def main():
                    "launch": ("hipGraph replay" if graph else "eager") +
                              (f", {R} independent steps in flight (one stream + batch / output / workspace set each)" if R > 1
                               else ", one step after the other"),
+                   "schedule": ("one launch per op" if not a.schedule else
+                                f"chained encoder layers (group {a.chain_group}, skew {a.chain_skew:g})"),
                    "steps_in_flight": R, "slots_bit_equal_on_one_batch": slots_equal,
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                    "parallelism": f"replica x{world} (clip shards)"},
@@ -539,11 +580,136 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu:
         clean = torch.stack([it["clean_specs"] for it in items])
         out["cpu_baseline"] = cpu_baseline(model, mixed, lips, masks, sep, clean, mk, B, a.cpu_seconds)
+        if a.workload == "cfg2" and not a.no_quality:
+            out["cpu_baseline"]["quality"] = trained_quality(av, dev)
+    if rank == 0 and world == 1 and a.workload == "cfg2" and not (a.no_also or a.no_cpu or a.no_profile):
+        # the other BASELINE configs under the same clock: short lines, no CPU legs
+        del model, sets
+        torch.cuda.empty_cache()
+        t_also = time.perf_counter()
+        out["also"] = {w: also_forward(av, dev, w) for w in ("cfg3", "cfg5")}
+        out["also"]["cfg4_train"] = also_train(av, dev)
+        out["also"]["seconds"] = round(time.perf_counter() - t_also, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def also_forward(av, dev, name, steps=5, rounds=3, warmup=3):
+    """A short line for another BASELINE forward config inside the default run: the workload's own model and per-GPU batch,
+    SyntheticAVDataset clips, hipGraph replay, `rounds` rounds of EXACTLY `steps` steps with two steps in flight (median
+    round) and the same steps one at a time.  Both in-flight slots hold the same clips (dataset generation is host time)."""
+    wl = WORKLOADS[name]
+    B, mk, dk = wl["batch"], wl["model"], wl["data"]
+    torch.manual_seed(0)
+    model = av.AVSeparationTransformer(dropout=0.0, **mk).to(dev).eval()
+    ds = av.SyntheticAVDataset(num_samples=B, **dk)
+    its = [ds[i] for i in range(B)]
+    S = mk["num_speakers"]
+    sets = []
+    for _ in range(2):
+        mx = torch.stack([it["mixed_spec"] for it in its]).to(dev).contiguous()
+        lp = torch.stack([it["lip_frames"] for it in its]).to(dev).contiguous()
+        _, F, T = mx.shape
+        sets.append(dict(mixed=mx, lips=lp, masks=torch.empty(B, T, S, F, device=dev), sep=torch.empty(B, T, S, F, device=dev),
+                         stream=torch.cuda.Stream(device=dev)))
+    _, N, H, W = sets[0]["lips"].shape
+
+    def run_steps(n, nsets):
+        for i in range(n):
+            st = sets[i % nsets]
+            with torch.cuda.stream(st["stream"]):
+                model.run_static(st["mixed"], st["lips"], st["masks"], st["sep"], graph=True, slot=i % nsets)
+
+    with torch.no_grad():
+        run_steps(max(2, warmup), 2)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(sets[0]["masks"], sets[1]["masks"]))          # two contexts, same clips: same bits
+        worst, _ = timed_rounds(None, dev, rounds, lambda: run_steps(steps, 2))
+        run_steps(2, 1)
+        single, _ = timed_rounds(None, dev, rounds, lambda: run_steps(steps, 1))
+    gflop = flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
+    el, el1 = median(worst), median(single)
+    value = B * steps / el
+    out = {"metric": metric_string(mk, dk, 2), "value": round(value, 2), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 4),
+           "steps": steps, "rounds": rounds, "batch_per_gpu": B, "gflop_per_clip": round(gflop, 4),
+           "path_frac": round(value * gflop / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
+           "one_step_at_a_time": {"value": round(B * steps / el1, 2), "ms_per_step": round(el1 / steps * 1e3, 4)},
+           "slots_bit_equal": same, "masks_in_unit_interval": bool(float(sets[0]["masks"].min()) >= 0.0 and
+                                                                   float(sets[0]["masks"].max()) <= 1.0)}
+    del model, sets
+    torch.cuda.empty_cache()
+    return out
+
+
+def also_train(av, dev, steps=5, rounds=3, warmup=6):
+    """A short line for BASELINE configs[3]'s training step inside the default run: the loop body of `--mode train`
+    (zero_grad, train-mode forward with dropout 0.1, SeparationLoss, backward, clip, fused Adam) on one resident 16-clip
+    batch, single rank."""
+    from av_separation.losses import SeparationLoss
+    wl = WORKLOADS["cfg4"]
+    B, mk, dk = wl["batch"], wl["model"], wl["data"]
+    torch.manual_seed(0)
+    model = av.AVSeparationTransformer(dropout=0.1, **mk).to(dev).train()
+    ds = av.SyntheticAVDataset(num_samples=B, **dk)
+    its = [ds[i] for i in range(B)]
+    mixed = torch.stack([it["mixed_spec"] for it in its]).to(dev).contiguous()
+    lips = torch.stack([it["lip_frames"] for it in its]).to(dev).contiguous()
+    targets = torch.stack([it["clean_specs"] for it in its]).to(dev).contiguous()
+    _, F, T = mixed.shape
+    _, N, H, W = lips.shape
+    crit = SeparationLoss(0.5)
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4, fused=True)
+    losses = []
+
+    def step():
+        opt.zero_grad()
+        sep, _ = model(mixed, lips)
+        loss = crit(sep, targets)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0, foreach=True)
+        opt.step()
+        losses.append(loss.detach())
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    worst, _ = timed_rounds(None, dev, rounds, lambda: [step() for _ in range(steps)])
+    el = median(worst)
+    gflop = 3 * flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"],
+                               mk["num_speakers"]) / 1e9
+    value = B * steps / el
+    out = {"metric": "training clips/sec (forward+backward+Adam step), fp32", "value": round(value, 2), "unit": "clips/s",
+           "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "rounds": rounds, "batch_per_gpu": B,
+           "gflop_per_clip": round(gflop, 3), "frac": round(value * gflop / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
+           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)]}
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def trained_quality(av, dev):
+    """The quality half of BASELINE.json's metric on TRAINED weights: the reference's demo recipe
+    (tools/quality_recipe.py; /root/reference/demo.py:116-198) from the same initial weights and batch order on the HIP path
+    and on the CPU port of the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import quality_recipe as q
+    order = q.batch_order(q.DATA["num_samples"], seed=7)
+    items = q.make_items(av, order)
+    g, state0 = q.run_gpu(av, dev, items, order)
+    c = q.run_cpu_port(state0, items, order)
+    r3 = lambda x: round(x, 3)  # noqa: E731
+    return {"recipe": "reference demo.py:116-198: d_model 128, 2+2 layers, dropout 0.1, 63 Adam steps (batch 8, lr 3e-4, "
+                      "SeparationLoss(0.5), clip 1.0), SNR of the first 20 items, seeded batch order, same initial weights; "
+                      "README.md:61-65: input 0.01 / untrained 3.20 / trained 37.24 / improvement +37.23 dB",
+            "input_snr_db": r3(g["in_snr"]),
+            "gpu": {"untrained_out_snr_db": r3(g["out_snr_untrained"]), "trained_out_snr_db": r3(g["out_snr"]),
+                    "snr_improvement_db": r3(g["improvement"]), "train_seconds": round(g["train_seconds"], 2)},
+            "cpu_port": {"untrained_out_snr_db": r3(c["out_snr_untrained"]), "trained_out_snr_db": r3(c["out_snr"]),
+                         "snr_improvement_db": r3(c["improvement"]), "train_seconds": round(c["train_seconds"], 2)},
+            "trained_out_snr_gpu_minus_cpu_db": r3(g["out_snr"] - c["out_snr"])}
 
 
 def train_main(a, av, dev, dist, rank, world):
@@ -745,7 +911,8 @@ def cpu_baseline(model, mixed, lips, masks_gpu, sep_gpu, clean, mk, B, budget_s)
     got_sep = sep_gpu.permute(0, 2, 3, 1).cpu()
     quality = {"si_snr_i_db_gpu": round(si_snr_improvement(got_sep, mx, clean), 4),
                "si_snr_i_db_cpu": round(si_snr_improvement(ref_sep, mx, clean), 4),
-               "weights": "random init (torch.manual_seed(0)): the pair shows parity of the metric, not separation quality"}
+               "weights": "random init (torch.manual_seed(0)): the pair shows parity of the metric on the bench batch; separation "
+                          "quality on TRAINED weights is `quality` below"}
     return {"value": round(B / med, 2), "unit": "clips/s", "cores": threads, "threads": threads, **host_cpu_info(),
             "kind": "port",
             "sample": f"{len(times)} forwards of the same {B}-clip batch, median {med * 1e3:.1f} ms "

@@ -111,6 +111,20 @@ int avsep_set_debug_taps(avsep_ctx* ctx, int on);
 int64_t avsep_read_tap(avsep_ctx* ctx, const char* name, float* dst, int64_t max_floats, void* workspace, int B,
                        int T, int N, int H, int W, void* stream);
 
+/* Launch schedule of the eval forward (round 4).  0 (default): one launch per op, two streams -- the path every golden test
+ * pins.  1: the pre-norm encoder layers of each branch (nn.TransformerEncoder of AudioEncoder / VisualEncoder,
+ * /root/reference/src/av_separation/model.py:48-52,59 and 97-101,111) run as ONE dependency-driven persistent launch per
+ * branch (csrc/chain.hip): tiles of the same kernels' code, started as soon as the producer tiles of THEIR rows / clip have
+ * finished instead of after a device-wide launch boundary; outputs are bit-identical to schedule 0.  `group` / `skew` order
+ * the work list: clip groups of `group` clips run `skew` ops apart (skew 0 = op-major).  Applies to models whose layers take
+ * the LayerNorm-in-the-epilogue GEMM and the short-sequence attention (d_model <= 256, head dim 64, 49..64 positions);
+ * other shapes keep schedule 0 silently.  Drops the context's captured graphs.  Not an environment switch: the product
+ * library reads none. */
+int avsep_set_schedule(avsep_ctx* ctx, int schedule, int group, float skew);
+/* After a forward under schedule 1: waits for `stream` and returns AVSEP_OK when every dependency wait of the chained launches
+ * was satisfied, AVSEP_EINTERNAL (with avsep_last_error()) when a bounded spin gave up (outputs are then invalid). */
+int avsep_chain_status(avsep_ctx* ctx, void* stream);
+
 /* Live per-kernel profile: between avsep_profile_begin() and avsep_profile_end() every kernel the EAGER
  * entry points launch is issued 20x back to back between one pair of HIP events on the stream it runs on
  * (an event record costs microseconds here, a kernel may take less) and its MEAN duration is kept; outputs

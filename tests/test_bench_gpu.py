@@ -46,6 +46,20 @@ def test_bench_single_gpu_contract_line():
     assert tm["rounds"] >= 9 and len(tm["ms_per_step_rounds"]) == tm["rounds"] and tm["steps_per_round"] == 20
     assert tm["ms_per_step_min"] <= out["ms_per_step"] <= tm["ms_per_step_max"]
     assert out["config"]["slots_bit_equal_on_one_batch"] is True and "in flight" in out["metric"]
+    assert "2-spk, 1s@8kHz, d=256" in out["metric"]
+    # the other BASELINE configs under the same clock and the trained-weights quality pair (item 5)
+    al = out["also"]
+    assert "2s@16kHz, d=512" in al["cfg3"]["metric"] and "4s@16kHz, d=512" in al["cfg5"]["metric"]
+    for w, b in (("cfg3", 64), ("cfg5", 32)):
+        assert al[w]["batch_per_gpu"] == b and al[w]["value"] > 0 and al[w]["slots_bit_equal"] and al[w]["masks_in_unit_interval"]
+        assert 0.3 < al[w]["path_frac"] < 1.0
+    assert al["cfg4_train"]["batch_per_gpu"] == 16 and al["cfg4_train"]["value"] > 0 and al["seconds"] < 90
+    ql = cb["quality"]
+    assert ql["gpu"]["snr_improvement_db"] >= 35.0 and abs(ql["trained_out_snr_gpu_minus_cpu_db"]) < 1.0
+    if rf["traffic"] is not None:
+        tp = rf["traffic_population"]
+        assert abs(tp["algorithmic_bytes_per_forward"] / tp["launches_per_forward"] - rf["algorithmic_bytes_per_launch"]) < 2
+        assert abs(tp["traffic_bytes_per_forward"] / tp["launches_per_forward"] - rf["traffic"]) < 2
 
 
 @pytest.mark.parametrize("mode,launcher", [("forward", "self"), ("forward", "torchrun"), ("train", "self")])
