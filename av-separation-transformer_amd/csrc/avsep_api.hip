@@ -1079,6 +1079,20 @@ int avsep_chain_status(avsep_ctx* c, void* stream) try {
   return on_exception();
 }
 
+// developer aid: the first n state words (ticket head, error word, 2 unused, counters...) of chained plan `idx`, copied on a
+// stream of its own while the launch may still be running
+int avsep_chain_peek(avsep_ctx* c, int idx, unsigned* out, int n) try {
+  if (!c || idx < 0 || idx >= (int)c->chains.size() || !out || n <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  hipStream_t s = nullptr;
+  HCK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  hipError_t e = chain_plan_peek(c->chains[idx].plan, s, out, n);
+  (void)hipStreamDestroy(s);
+  HCK(e);
+  return (int)c->chains.size();
+} catch (...) {
+  return on_exception();
+}
+
 int avsep_profile_begin(avsep_ctx* c) try {
   if (!c) return fail(AVSEP_EINVAL, "null context");
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

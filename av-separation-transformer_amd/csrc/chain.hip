@@ -58,9 +58,11 @@ struct ChainArgs {
   const ChainItem* items;
   int n_items;
   unsigned* state;            // [0] ticket head, [1] error word, [2..3] unused, [4..] counters
+  unsigned long long* dbg;    // developer diagnostics (AVSEP_CHAIN_DBG): 4 wall-clock stamps per ticket, else null
+  int backoff;                // s_sleep argument of the dependency poll's back-off
 };
 
-enum { CHAIN_STATE_HDR = 4, CHAIN_SPIN_LIMIT = 2000000 };
+enum { CHAIN_STATE_HDR = 4, CHAIN_SPIN_LIMIT = 40000 };
 
 template <typename T>
 __device__ __forceinline__ T uni(T v) {       // the value is wave-uniform: move it to SGPRs
@@ -81,20 +83,28 @@ template <int WPS>
 __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8192];     // 32 KB: the 32x32x64 plain tile; the 32x64x32 tile takes 24 KB
   __shared__ int s_ticket;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: branches on it are scalar branches
   unsigned* const head = a.state;
   unsigned* const err = a.state + 1;
   unsigned* const cnt = a.state + CHAIN_STATE_HDR;
-  for (;;) {
-    if (tid == 0) s_ticket = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int t = uni(s_ticket);
-    if (t >= a.n_items) break;
+  // Control flow note: NO divergent branch may straddle the loop's back edge.  The first version fetched the ticket in an
+  // `if (tid == 0)` at the loop top and signalled in another at the bottom; hipcc merged the two into one divergent region around
+  // the back edge (lane 0 parked in an outer loop while lanes 1-63 of its wave went round the inner one): the wave re-entered the
+  // barrier without lane 0, re-read the OLD ticket and ran the same tile forever.  Now lane 0's work (signal + next ticket) sits
+  // in straight-line code between two barriers, under a scalar `wave == 0` branch, and the loop condition is an SGPR compare.
+  if (wave == 0) {
+    if (lane == 0) s_ticket = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  int t = uni(s_ticket);
+  while (t < a.n_items) {
     const ChainItem* ip = a.items + t;
     const int it_op = uni(ip->op), it_m0 = uni(ip->m0), it_n0 = uni(ip->n0);
     const int dep_lo = uni(ip->dep_lo), dep_n = uni(ip->dep_n), dep_target = uni(ip->dep_target), sig = uni(ip->sig);
     const ChainOp* op = a.ops + it_op;
     const int kind = uni(op->kind);
+    if (a.dbg && tid == 0) a.dbg[4 * (size_t)t] = __builtin_amdgcn_s_memrealtime();
     if (dep_n > 0) {                                                    // block-uniform
       if (wave == 0) {
         const unsigned* w = cnt + dep_lo + min(lane, dep_n - 1);
@@ -105,12 +115,18 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
             if (lane == 0) __hip_atomic_store(err, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          // back off: every poll is a load that goes past L1 / L2 to the counter's home, and hundreds of waiting workgroups
+          // polling a handful of words slow down the very adds they wait for (MI355X_MICROARCH.md, polling-cost)
+          if (a.backoff <= 2) __builtin_amdgcn_s_sleep(2);
+          else if (a.backoff <= 16) __builtin_amdgcn_s_sleep(16);
+          else if (a.backoff <= 48) __builtin_amdgcn_s_sleep(48);
+          else __builtin_amdgcn_s_sleep(127);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // no instruction: keeps the tile's loads below the poll
       __syncthreads();
     }
+    if (a.dbg && tid == 0) a.dbg[4 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
     if (kind == CH_ATTN) {
       const int Lq = uni(op->Lq), Lk = uni(op->Lk), ldq = uni(op->ldq), ldk = uni(op->ldk), ldv = uni(op->ldv), ldo = uni(op->ldo);
       const int nqt = (Lq + 15) >> 4;
@@ -150,10 +166,20 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
         gemm_tile<32, 32, 64, AMODE_PLAIN, false, 0, true>(p, it_m0, it_n0, lds);
       }
     }
-    // publish: every storing wave drains its write-through stores, the workgroup meets, ONE lane signals
+    // publish: every storing wave drains its write-through stores, the workgroup meets, ONE lane signals -- and draws the
+    // workgroup's next ticket
+    if (a.dbg && tid == 0) a.dbg[4 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(cnt + sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.dbg && tid == 0) a.dbg[4 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
+    if (wave == 0) {
+      if (lane == 0) {
+        __hip_atomic_fetch_add(cnt + sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ticket = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    t = uni(s_ticket);
   }
 }
 
@@ -165,6 +191,10 @@ struct ChainPlanImpl {
   ChainItem* items_dev = nullptr;
   unsigned* state_dev = nullptr;
   int n_items = 0, n_ops = 0, grid = 0, wps = 4;
+  unsigned long long* dbg_dev = nullptr;  // AVSEP_CHAIN_DBG (developer build): stamps per ticket
+  int backoff = 48;
+  std::vector<ChainItem> items_host;      // diagnostics (chain_plan_error)
+  std::vector<int> op_kind_host;
   size_t state_bytes = 0;
   double flops = 0.0, bytes = 0.0;
 };
@@ -304,12 +334,19 @@ hipError_t chain_build(ChainBuilder* b, int order_group, float order_skew, Chain
   p->state_bytes = ((size_t)(CHAIN_STATE_HDR + n_counters) * sizeof(unsigned) + 15) / 16 * 16;
   std::vector<ChainOp> ops(n_ops);
   for (int o = 0; o < n_ops; ++o) ops[o] = b->ops[o].op;
+  p->items_host = items;
+  for (int o = 0; o < n_ops; ++o) p->op_kind_host.push_back(b->ops[o].op.kind);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ops_dev), ops.size() * sizeof(ChainOp));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->items_dev), items.size() * sizeof(ChainItem));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->state_dev), p->state_bytes);
   if (e == hipSuccess) e = hipMemcpy(p->ops_dev, ops.data(), ops.size() * sizeof(ChainOp), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->items_dev, items.data(), items.size() * sizeof(ChainItem), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(p->state_dev, 0, p->state_bytes);
+  if (e == hipSuccess && dev_env("AVSEP_CHAIN_DBG")) {
+    e = hipMalloc(reinterpret_cast<void**>(&p->dbg_dev), items.size() * 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(p->dbg_dev, 0, items.size() * 4 * sizeof(unsigned long long));
+  }
+  if (const char* g = dev_env("AVSEP_CHAIN_BACKOFF")) p->backoff = atoi(g);                // developer sweep
   int per_cu = 0, dev = 0, cus = 256;
   p->wps = 4;
   if (const char* g = dev_env("AVSEP_CHAIN_WPS")) p->wps = atoi(g) == 3 ? 3 : 4;       // developer sweep
@@ -332,6 +369,7 @@ void chain_plan_free(ChainPlanImpl* p) {
   if (p->ops_dev) (void)hipFree(p->ops_dev);
   if (p->items_dev) (void)hipFree(p->items_dev);
   if (p->state_dev) (void)hipFree(p->state_dev);
+  if (p->dbg_dev) (void)hipFree(p->dbg_dev);
   delete p;
 }
 
@@ -342,7 +380,7 @@ int chain_plan_items(const ChainPlanImpl* p) { return p->n_items; }
 hipError_t launch_chain(const ChainPlanImpl* p, hipStream_t s) {
   hipError_t e = hipMemsetAsync(p->state_dev, 0, p->state_bytes, s);
   if (e != hipSuccess) return e;
-  ChainArgs a{p->ops_dev, p->items_dev, p->n_items, p->state_dev};
+  ChainArgs a{p->ops_dev, p->items_dev, p->n_items, p->state_dev, p->dbg_dev, p->backoff};
   if (p->wps == 3) hipLaunchKernelGGL(chain_kernel<3>, dim3((unsigned)p->grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(chain_kernel<4>, dim3((unsigned)p->grid), dim3(256), 0, s, a);
   return hipGetLastError();
@@ -352,5 +390,48 @@ hipError_t launch_chain(const ChainPlanImpl* p, hipStream_t s) {
 hipError_t chain_plan_error(const ChainPlanImpl* p, hipStream_t s, unsigned* word) {
   hipError_t e = hipStreamSynchronize(s);
   if (e != hipSuccess) return e;
-  return hipMemcpy(word, p->state_dev + 1, sizeof(unsigned), hipMemcpyDeviceToHost);
+  std::vector<unsigned> st(p->state_bytes / sizeof(unsigned));
+  e = hipMemcpy(st.data(), p->state_dev, p->state_bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return e;
+  *word = st[1];
+  if (p->dbg_dev) {      // developer diagnostics: where a tile's life goes, per op (100 MHz wall clock)
+    std::vector<unsigned long long> d((size_t)p->n_items * 4);
+    if (hipMemcpy(d.data(), p->dbg_dev, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+      unsigned long long t0 = ~0ULL, t1 = 0;
+      for (int i = 0; i < p->n_items; ++i) { t0 = std::min(t0, d[4 * (size_t)i]); t1 = std::max(t1, d[4 * (size_t)i + 3]); }
+      fprintf(stderr, "[chain dbg] %d items, %d ops, grid %d (%d per CU cap), back-off %d: launch span %.1f us\n", p->n_items, p->n_ops,
+              p->grid, p->wps, p->backoff, (double)(t1 - t0) / 100.0);
+      fprintf(stderr, "[chain dbg]  op kind tiles | first start .. last done (us) | mean wait  tile  drain+barrier (us) | max wait\n");
+      for (int o = 0; o < p->n_ops; ++o) {
+        double w = 0, tl = 0, pb = 0, wmax = 0; int n = 0; unsigned long long a0 = ~0ULL, a1 = 0;
+        for (int i = 0; i < p->n_items; ++i) {
+          if (p->items_host[i].op != o) continue;
+          const unsigned long long* q = &d[4 * (size_t)i];
+          w += (double)(q[1] - q[0]); tl += (double)(q[2] - q[1]); pb += (double)(q[3] - q[2]); ++n;
+          wmax = std::max(wmax, (double)(q[1] - q[0]));
+          a0 = std::min(a0, q[0]); a1 = std::max(a1, q[3]);
+        }
+        if (n) fprintf(stderr, "[chain dbg]  %2d  %d  %5d | %7.1f .. %7.1f | %6.2f %6.2f %6.2f | %6.1f\n", o, p->op_kind_host[o], n,
+                       (double)(a0 - t0) / 100.0, (double)(a1 - t0) / 100.0, w / n / 100.0, tl / n / 100.0, pb / n / 100.0, wmax / 100.0);
+      }
+    }
+  }
+  if (st[1]) {                              // a wait gave up: say which tile and what its counters read now
+    const int t = (int)st[1] - 1;
+    if (t >= 0 && t < p->n_items) {
+      const ChainItem& it = p->items_host[t];
+      fprintf(stderr, "[chain] ticket %d of %d (head now %u, grid %d): op %d kind %d tile (%d, %d) waits for counters [%d, %d) >= %d; they read",
+              t, p->n_items, st[0], p->grid, it.op, p->op_kind_host[it.op], it.m0, it.n0, it.dep_lo, it.dep_lo + it.dep_n, it.dep_target);
+      for (int k = 0; k < it.dep_n; ++k) fprintf(stderr, " %u", st[CHAIN_STATE_HDR + it.dep_lo + k]);
+      fprintf(stderr, "\n");
+    }
+  }
+  return hipSuccess;
+}
+
+hipError_t chain_plan_peek(const ChainPlanImpl* p, hipStream_t s, unsigned* out, int n) {
+  const size_t bytes = std::min((size_t)n * sizeof(unsigned), p->state_bytes);
+  hipError_t e = hipMemcpyAsync(out, p->state_dev, bytes, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
 }

@@ -124,6 +124,9 @@ int avsep_set_schedule(avsep_ctx* ctx, int schedule, int group, float skew);
 /* After a forward under schedule 1: waits for `stream` and returns AVSEP_OK when every dependency wait of the chained launches
  * was satisfied, AVSEP_EINTERNAL (with avsep_last_error()) when a bounded spin gave up (outputs are then invalid). */
 int avsep_chain_status(avsep_ctx* ctx, void* stream);
+/* developer aid: copies the first n state words (ticket head, error word, two unused, arrival counters ...) of chained plan
+ * `idx` on a stream of its own, also while the launch is running; returns the number of plans */
+int avsep_chain_peek(avsep_ctx* ctx, int idx, unsigned* out, int n);
 
 /* Live per-kernel profile: between avsep_profile_begin() and avsep_profile_end() every kernel the EAGER
  * entry points launch is issued 20x back to back between one pair of HIP events on the stream it runs on

@@ -226,6 +226,38 @@ def test_offset_residual_streams_against_float64_oracle(dev, offset):
     assert maxabs(sep.cpu().numpy(), rs) < MASK_TOL * max(1.0, float(np.abs(mixed).max()))
 
 
+@pytest.mark.parametrize("group,skew", [(8, 0.0), (4, 1.0), (1, 2.5), (16, 0.5)])
+def test_chained_encoder_layers_change_no_bit(dev, group, skew):
+    """Schedule 1 (include/avsep.h avsep_set_schedule; csrc/chain.hip): the encoder layers of each branch as ONE
+    dependency-driven persistent launch -- tiles of the stand-alone kernels' own code, started when the producer tiles of their
+    rows / clip have arrived, handed off through write-through stores and L1-bypassing loads.  For every work-list order the
+    outputs must equal the launch-per-op schedule's BIT FOR BIT, eagerly and under graph replay, at the full bench batch and at
+    a ragged one; and no dependency wait may have timed out."""
+    import av_separation as av
+    torch.manual_seed(3)
+    m = av.AVSeparationTransformer(dropout=0.0).to(dev).eval()
+    for B in (32, 5):
+        ds = av.SyntheticAVDataset(num_samples=B)
+        items = [ds[i] for i in range(B)]
+        mixed = torch.stack([x["mixed_spec"] for x in items]).to(dev)
+        lips = torch.stack([x["lip_frames"] for x in items]).to(dev)
+        with torch.no_grad():
+            m.set_schedule(0)
+            sep0, masks0 = m(mixed, lips)
+            m.set_schedule(1, group, skew)
+            for _ in range(3):                       # counters are re-zeroed by every launch
+                sep1, masks1 = m(mixed, lips)
+                m.chain_status()
+                assert torch.equal(masks1, masks0) and torch.equal(sep1, sep0)
+            m.enable_graph_replay(True)
+            for _ in range(3):
+                sg, mg = m(mixed, lips)
+                m.chain_status()
+                assert torch.equal(mg, masks0) and torch.equal(sg, sep0)
+            m.enable_graph_replay(False)
+            m.set_schedule(0)
+
+
 @pytest.mark.parametrize("wl", ["cfg3", "cfg5"])
 def test_full_batch_properties_big_configs(golden, dev, wl):
     """BASELINE configs[2] / [4] at their FULL per-GPU batch (64 / 32 clips, M = 16 k rows: the large-tile GEMM, the

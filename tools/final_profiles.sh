@@ -4,7 +4,7 @@
 # then the bench lines, rocprofv3 kernel stats of the same command, matrix-pipe PMC, the other workloads, the training step.
 # Two calls (a GPU call is limited to 20 minutes): `final_profiles.sh r03 a` = the PMC / in-graph passes; copy
 # gpurun_out/final/{pmc_hbm_traffic,graph_kernel_stats}.json into profiles/ and run `final_profiles.sh r03 b` = the bench lines.
-TAG=${1:-r03}; PART=${2:-ab}
+TAG=${1:-r04}; PART=${2:-ab}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
 unset AVSEP_LIB
@@ -25,6 +25,10 @@ python3 $R/tools/graph_stats.py $O/${TAG}_bench_cfg2_graph_only_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload cfg3 --no-cpu --no-profile --steps 10 --warmup 2 --rounds 1 > /dev/null 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv") $O/${TAG}_bench_cfg3_graph_only_kernel_stats.csv; rm -rf $O/kt
 python3 $R/tools/graph_stats.py $O/${TAG}_bench_cfg3_graph_only_kernel_stats.csv cfg3 25 $O/graph_kernel_stats.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --workload cfg5 --no-cpu --no-profile --steps 6 --warmup 2 --rounds 1 > /dev/null 2>&1
+cp $(find $O/kt -name "*kernel_stats.csv") $O/${TAG}_bench_cfg5_graph_only_kernel_stats.csv; rm -rf $O/kt
+# (replays: 2 warm-up + 6 of the two-in-flight leg, 2 + 6 of the one-at-a-time leg, one eager forward of the slot check = 17)
+python3 $R/tools/graph_stats.py $O/${TAG}_bench_cfg5_graph_only_kernel_stats.csv cfg5 17 $O/graph_kernel_stats.json
 cp $O/graph_kernel_stats.json $R/profiles/graph_kernel_stats.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu --no-profile --inflight 1 --steps 50 --rounds 1 > /dev/null 2>&1
 python3 $R/tools/trace_step.py $(find $O/kt -name "*kernel_trace.csv") > $O/${TAG}_step_timeline.txt 2>&1; rm -rf $O/kt
