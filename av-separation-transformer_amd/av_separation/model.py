@@ -299,8 +299,11 @@ class _Engine:
         return self.ws, need
 
     def set_schedule(self, schedule: int, group: int = 8, skew: float = 0.0):
+        if schedule and not hasattr(_native.load(), "avsep_set_schedule"):
+            raise RuntimeError("launch schedules 1 / 2 (chained encoder layers) exist in the developer build of the library only "
+                               "(AVSEP_LIB=dev): they were measured slower than the launch-per-op schedule")
         self.schedule = (int(schedule), int(group), float(skew))
-        if self.ctx is not None:
+        if self.ctx is not None and hasattr(_native.load(), "avsep_set_schedule"):
             _native.check(_native.load().avsep_set_schedule(self.ctx, *self.schedule[:2], C.c_float(self.schedule[2])),
                           "avsep_set_schedule")
 
@@ -534,8 +537,9 @@ class AVSeparationTransformer(_Tracked):
         return self
 
     def set_schedule(self, schedule: int = 0, group: int = 8, skew: float = 0.0):
-        """Launch schedule of the fused eval forward (include/avsep.h avsep_set_schedule): 0 = one launch per op (default), 1 =
-        the encoder layers of each branch as one dependency-driven persistent launch; same output bits either way."""
+        """Launch schedule of the fused eval forward (include/avsep.h avsep_set_schedule, DEVELOPER build of the library only):
+        0 = one launch per op (default), 1 / 2 = the encoder layers of each branch as one dependency-driven persistent launch
+        (one queue / XCD-local queues); same output bits either way, measured slower."""
         self._engine.set_schedule(schedule, group, skew)
         for eng in self.__dict__.get("_slot_engines", {}).values():
             eng.set_schedule(schedule, group, skew)

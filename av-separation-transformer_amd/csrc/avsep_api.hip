@@ -517,9 +517,10 @@ GemmParams linear_params(const float* A, int lda, const float* W, int K, const f
 // ---- schedule 1: all pre-norm encoder layers of one branch as ONE persistent, dependency-driven launch (chain.hip).
 // The ops and their operands are exactly those of encoder_layer() below (LayerNorm-epilogue QKV / FFN-1, short-sequence
 // attention, plain out-projection / FFN-2 with the residual in place), so the outputs are the launch-per-op path's bit for bit.
+#ifdef AVSEP_DEV
 bool chain_usable(const avsep_ctx* c, const std::vector<EncLayerW>& layers, int B, int L) {
   const int d = c->d, M = B * L;
-  if (c->schedule != 1 || c->keep_taps || layers.empty() || !c->use_lnx || c->lnx_all) return false;
+  if (c->schedule == 0 || c->keep_taps || layers.empty() || !c->use_lnx || c->lnx_all) return false;
   if (c->dh != 64 || L <= 48 || L > 64 || (d & 63)) return false;
   // the launch-per-op path takes the LayerNorm-epilogue form below 1024 64x64 tiles only (run_ln_linear): same rule, same bits
   if ((long)((M + 63) / 64) * ((4 * d + 63) / 64) >= 1024) return false;
@@ -559,13 +560,15 @@ int get_chain(avsep_ctx* c, const std::vector<EncLayerW>& layers, float* x, floa
     ok = ok && o_qkv >= 0 && o_att >= 0 && o_out >= 0 && o_f1 >= 0 && prev >= 0;
   }
   ChainPlanImpl* plan = nullptr;
-  hipError_t e = ok ? chain_build(b, c->chain_group, c->chain_skew, &plan) : hipErrorInvalidValue;
+  hipError_t e = ok ? chain_build(b, c->schedule == 2 ? 1 : 0, c->chain_group, c->chain_skew, &plan) : hipErrorInvalidValue;
   chain_builder_free(b);
   if (e != hipSuccess) return fail_hip(e, "chain_build (encoder layers)");
   c->chains.push_back({x, B, L, (const void*)layers.data(), plan});
   *out = plan;
   return AVSEP_OK;
 }
+
+#endif  // AVSEP_DEV
 
 int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
                   int Lseq, hipStream_t s);
@@ -578,12 +581,14 @@ int encoder_layers(avsep_ctx* c, const std::vector<EncLayerW>& layers, const Wor
   float* qkv = audio ? w.qkv : w.v_qkv;
   float* att = audio ? w.att : w.v_att;
   float* ffn = audio ? w.ffn : w.v_ffn;
+#ifdef AVSEP_DEV
   if (chain_usable(c, layers, B, L)) {
     ChainPlanImpl* plan = nullptr;
     RCK(get_chain(c, layers, x, qkv, att, ffn, B, L, &plan));
     return profiled(c, audio ? "chain_kernel (audio encoder layers)" : "chain_kernel (visual encoder layers)",
                     chain_plan_flops(plan), chain_plan_bytes(plan), s, [&] { return launch_chain(plan, s); });
   }
+#endif
   for (size_t i = 0; i < layers.size(); ++i) {
     RCK(encoder_layer(c, layers[i], x, ln, qkv, att, ffn, B, L, s));
     RCK(record_tap(c, w, ((audio ? "a_enc" : "v_enc") + std::to_string(i)).c_str(), x, (size_t)B * L * c->d, s));
@@ -1036,7 +1041,9 @@ void avsep_destroy(avsep_ctx* c) {
     (void)hipStreamDestroy(g.side);
   }
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+#ifdef AVSEP_DEV
   for (auto& e : c->chains) chain_plan_free(e.plan);
+#endif
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_vdone) (void)hipEventDestroy(c->ev_vdone);
   if (c->ev_adone) (void)hipEventDestroy(c->ev_adone);
@@ -1047,9 +1054,11 @@ void avsep_destroy(avsep_ctx* c) {
   delete c;
 }
 
+#ifdef AVSEP_DEV
 int avsep_set_schedule(avsep_ctx* c, int schedule, int group, float skew) try {
   if (!c) return fail(AVSEP_EINVAL, "null context");
-  if (schedule < 0 || schedule > 1) return fail(AVSEP_EINVAL, "schedule: 0 = one launch per op, 1 = chained encoder layers");
+  if (schedule < 0 || schedule > 2)
+    return fail(AVSEP_EINVAL, "schedule: 0 = one launch per op, 1 = chained encoder layers (one queue), 2 = chained, XCD-local queues");
   if (group < 0 || !(skew >= 0.0f) || skew > 64.0f) return fail(AVSEP_EINVAL, "bad work-list order");
   DeviceScope guard(c->device);
   // plans and captured graphs of the previous schedule may be in flight: drain, then drop them
@@ -1092,6 +1101,7 @@ int avsep_chain_peek(avsep_ctx* c, int idx, unsigned* out, int n) try {
 } catch (...) {
   return on_exception();
 }
+#endif  // AVSEP_DEV
 
 int avsep_profile_begin(avsep_ctx* c) try {
   if (!c) return fail(AVSEP_EINVAL, "null context");
@@ -1315,7 +1325,8 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
     if (e != hipSuccess) { (void)hipStreamDestroy(g.cap); return fail_hip(e, "hipStreamCreate(capture side stream)"); }
     auto drop_streams = [&] { (void)hipStreamDestroy(g.cap); (void)hipStreamDestroy(g.side); };
     hipGraph_t graph = nullptr;
-    if (c->schedule == 1) {      // the chain plans allocate device tables: build them BEFORE the capture starts
+#ifdef AVSEP_DEV
+    if (c->schedule != 0) {      // the chain plans allocate device tables: build them BEFORE the capture starts
       Workspace w;
       if (ws_bytes >= carve(c, &w, reinterpret_cast<float*>(ws), B, T, N, H, W) * sizeof(float)) {
         ChainPlanImpl* plan = nullptr;
@@ -1325,6 +1336,7 @@ int avsep_forward_graph(avsep_ctx* c, const float* mixed, const float* lips, flo
         if (r != AVSEP_OK) { drop_streams(); return r; }
       }
     }
+#endif
     e = hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { drop_streams(); return fail_hip(e, "hipStreamBeginCapture"); }
     hipStream_t ctx_side = c->side;

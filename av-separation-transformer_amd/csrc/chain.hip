@@ -22,8 +22,20 @@
 //   * tickets come from one agent-scope atomic counter; the list order is a topological order, so a workgroup only ever waits for
 //     tiles with LOWER tickets, all of which have been claimed by running workgroups: no co-residency requirement, no deadlock.
 //     Every spin is bounded; a timeout sets an error word and the grid still drains.
-//   * counters, the ticket word and the error word are zeroed by a memset node in front of the launch (replayed with it).
+//   * counters, the ticket words and the error word are zeroed by a memset node in front of the launch (replayed with it).
+//
+// Two hand-off forms (avsep_set_schedule 1 / 2; both bit-identical to the launch-per-op path):
+//   1  ONE work queue, placement-independent: write-through (sc1) stores as above.  Measured (profiles/r04_chain_phase_stamps_sc1.txt):
+//      an sc1 store DROPS its line from the XCD's L2, so every A-operand load of every consumer tile -- 12 column tiles re-read
+//      each QKV row block -- goes to memory: tiles take 15-30 us where the stand-alone kernels' live 8.
+//   2  XCD-LOCAL queues: the batch is cut into (up to) 8 groups of clips, group g's tiles (group-aligned row tiling, so no tile
+//      straddles two groups) sit in queue g, and a workgroup pulls ONLY from the queue of the XCD it runs on, which it reads from
+//      the hardware (s_getreg HW_REG_XCC_ID) -- not from its block index.  Producer and consumer of every hand-off therefore share
+//      one L2: activations are stored PLAIN (the line stays in that L2), drained, signalled; consumers read them with L1-bypassing
+//      sc1 loads, which that L2 serves.  Correct for any dispatch order; if the runtime gave an XCD no workgroup its queue would
+//      not drain, which the launch's status word reports (chain_plan_error) instead of hanging.
 #include "kernels.h"
+#ifdef AVSEP_DEV   // measured slower than the launch-per-op schedule: developer build only, like every rejected instance
 #include "gemm_tile.h"
 #include "attn_tile.h"
 
@@ -50,19 +62,19 @@ struct ChainItem {            // device table, one per ticket
   int op, m0, n0;             // GEMM: tile origin; attention: m0 = clip, n0 = head
   int dep_lo, dep_n, dep_target;   // counters [dep_lo, dep_lo + dep_n) must each have reached dep_target (dep_n = 0: no wait)
   int sig;                    // counter this tile adds 1 to when its stores have drained
-  int pad;
+  int mend;                   // GEMM: row bound of the tile (end of its clip group; rows at or beyond it are not computed)
 };
 
 struct ChainArgs {
   const ChainOp* ops;
-  const ChainItem* items;
-  int n_items;
-  unsigned* state;            // [0] ticket head, [1] error word, [2..3] unused, [4..] counters
+  const ChainItem* items;     // queue q = items [qstart[q], qstart[q + 1])
+  const int* qstart;          // 9 entries (device)
+  unsigned* state;            // ticket head of queue q at word 16 q, error word at 128, counters from CHAIN_STATE_HDR
   unsigned long long* dbg;    // developer diagnostics (AVSEP_CHAIN_DBG): 4 wall-clock stamps per ticket, else null
   int backoff;                // s_sleep argument of the dependency poll's back-off
 };
 
-enum { CHAIN_STATE_HDR = 4, CHAIN_SPIN_LIMIT = 40000 };
+enum { CHAIN_STATE_HDR = 144, CHAIN_ERR_WORD = 128, CHAIN_SPIN_LIMIT = 40000 };
 
 template <typename T>
 __device__ __forceinline__ T uni(T v) {       // the value is wave-uniform: move it to SGPRs
@@ -79,14 +91,18 @@ __device__ __forceinline__ T uni(T v) {       // the value is wave-uniform: move
 
 // WPS = workgroups per CU the register budget is cut for: 4 (128 VGPRs: the persistent loop keeps lane constants of three tile
 // kinds alive and spills ~25 of them, a few reloads inside the K loops) or 3 (168 VGPRs, no spill)
-template <int WPS>
+template <int WPS, int XL>
 __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[8192];     // 32 KB: the 32x32x64 plain tile; the 32x64x32 tile takes 24 KB
   __shared__ int s_ticket;
+  constexpr int COH = XL ? 2 : 1;                              // XL: plain stores (same-XCD consumers), else write-through stores
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform: branches on it are scalar branches
-  unsigned* const head = a.state;
-  unsigned* const err = a.state + 1;
+  // XL: the queue of the XCD this workgroup RUNS on (hardware register, bits 3:0), never a guess from the block index
+  const int q = XL ? (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7u) : 0;
+  const int q_lo = uni(a.qstart[q]), q_hi = uni(a.qstart[q + 1]);
+  unsigned* const head = a.state + 16 * q;
+  unsigned* const err = a.state + CHAIN_ERR_WORD;
   unsigned* const cnt = a.state + CHAIN_STATE_HDR;
   // Control flow note: NO divergent branch may straddle the loop's back edge.  The first version fetched the ticket in an
   // `if (tid == 0)` at the loop top and signalled in another at the bottom; hipcc merged the two into one divergent region around
@@ -94,14 +110,15 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
   // barrier without lane 0, re-read the OLD ticket and ran the same tile forever.  Now lane 0's work (signal + next ticket) sits
   // in straight-line code between two barriers, under a scalar `wave == 0` branch, and the loop condition is an SGPR compare.
   if (wave == 0) {
-    if (lane == 0) s_ticket = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) s_ticket = q_lo + (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   int t = uni(s_ticket);
-  while (t < a.n_items) {
+  while (t < q_hi) {
     const ChainItem* ip = a.items + t;
     const int it_op = uni(ip->op), it_m0 = uni(ip->m0), it_n0 = uni(ip->n0);
     const int dep_lo = uni(ip->dep_lo), dep_n = uni(ip->dep_n), dep_target = uni(ip->dep_target), sig = uni(ip->sig);
+    const int mend = uni(ip->mend);
     const ChainOp* op = a.ops + it_op;
     const int kind = uni(op->kind);
     if (a.dbg && tid == 0) a.dbg[4 * (size_t)t] = __builtin_amdgcn_s_memrealtime();
@@ -145,14 +162,17 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
         if (qo < Lq) {
           const __amdgpu_buffer_rsrc_t ro = coh_rsrc(ob);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            coh_store16(ro, (qo * ldo + 4 * (4 * g + r)) * 4, f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv});
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 ov = f32x4{acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
+            if (COH == 1) coh_store16(ro, (qo * ldo + 4 * (4 * g + r)) * 4, ov);
+            else *reinterpret_cast<f32x4*>(ob + (size_t)qo * ldo + 4 * (4 * g + r)) = ov;
+          }
         }
       }
     } else {
       GemmParams p{};
       p.A = uni(op->A); p.W = uni(op->W); p.bias = uni(op->bias); p.C = uni(op->C);
-      p.M = uni(op->M); p.N = uni(op->N); p.K = uni(op->K);
+      p.M = mend; p.N = uni(op->N); p.K = uni(op->K);
       p.lda = uni(op->lda); p.ldw = p.K; p.ldc = uni(op->ldc);
       p.act = uni(op->act);
       p.R = uni(op->R); p.ldr = uni(op->ldr);
@@ -160,10 +180,10 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
       if (kind == CH_GEMM_LNX) {
         p.amode = AMODE_LNX;
         p.lnx_c1 = uni(op->c1); p.lnx_c2 = uni(op->c2);
-        gemm_tile<32, 64, 32, AMODE_LNX, false, 0, true>(p, it_m0, it_n0, lds);
+        gemm_tile<32, 64, 32, AMODE_LNX, false, 0, COH>(p, it_m0, it_n0, lds);
       } else {
         p.amode = AMODE_PLAIN;
-        gemm_tile<32, 32, 64, AMODE_PLAIN, false, 0, true>(p, it_m0, it_n0, lds);
+        gemm_tile<32, 32, 64, AMODE_PLAIN, false, 0, COH>(p, it_m0, it_n0, lds);
       }
     }
     // publish: every storing wave drains its write-through stores, the workgroup meets, ONE lane signals -- and draws the
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const ChainArgs a) {
     if (wave == 0) {
       if (lane == 0) {
         __hip_atomic_fetch_add(cnt + sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ticket = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ticket = q_lo + (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();
@@ -190,7 +210,9 @@ struct ChainPlanImpl {
   ChainOp* ops_dev = nullptr;
   ChainItem* items_dev = nullptr;
   unsigned* state_dev = nullptr;
-  int n_items = 0, n_ops = 0, grid = 0, wps = 4;
+  int* qstart_dev = nullptr;
+  int n_items = 0, n_ops = 0, grid = 0, wps = 4, xcd_local = 0;
+  std::vector<int> qstart_host;
   unsigned long long* dbg_dev = nullptr;  // AVSEP_CHAIN_DBG (developer build): stamps per ticket
   int backoff = 48;
   std::vector<ChainItem> items_host;      // diagnostics (chain_plan_error)
@@ -213,6 +235,15 @@ struct HostOp {
 }  // namespace
 
 void chain_plan_free(ChainPlanImpl* p);
+
+template <typename F>
+static hipError_t chain_dispatch(const ChainPlanImpl* p, F&& f) {      // the kernel instance of a plan
+  if (p->xcd_local) return p->wps == 3 ? f(chain_kernel<3, 1>) : f(chain_kernel<4, 1>);
+  return p->wps == 3 ? f(chain_kernel<3, 0>) : f(chain_kernel<4, 0>);
+}
+static hipError_t chain_occupancy(const ChainPlanImpl* p, int* per_cu) {
+  return chain_dispatch(p, [&](auto kern) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, reinterpret_cast<const void*>(kern), 256, 0); });
+}
 
 struct ChainBuilder {
   std::vector<HostOp> ops;
@@ -267,80 +298,117 @@ int chain_add_attention(ChainBuilder* b, const AttnProblem& a, int nhead, int de
   return (int)b->ops.size() - 1;
 }
 
-// Work list: one item per tile, in a topological order that follows `skew`: items are ranked by (op index + skew x clip group)
-// and emitted in rank order as soon as every producer tile they wait for has been emitted.  skew = 0: op-major (all tiles of an
-// op, then the next op's -- the launch-per-op order without the launch boundaries); skew > 0: groups of `group` clips run
-// `skew` ops apart, so that tiles of different ops (different phases: latency-bound attention, MFMA-bound FFN) share the CUs.
-hipError_t chain_build(ChainBuilder* b, int order_group, float order_skew, ChainPlanImpl** out) {
+// Work list: one item per tile.  The batch is cut into `NG` groups of G clips (xcd_local: up to 8 groups, one queue each; else
+// one group = one queue) and every GEMM is tiled in 32-row blocks that START at its group's first row, so no tile straddles two
+// groups; a tile's row bound is the end of its group.  Inside a queue the items follow a topological order steered by `skew`:
+// ranked by (op index + skew x sub-group of `order_group` clips) and emitted in rank order as soon as every producer tile they
+// wait for has been emitted.  skew = 0: op-major (the launch-per-op order without the launch boundaries); skew > 0: sub-groups
+// run `skew` ops apart, so that tiles of different ops (latency-bound attention, MFMA-bound FFN) share the CUs.
+hipError_t chain_build(ChainBuilder* b, int xcd_local, int order_group, float order_skew, ChainPlanImpl** out) {
   *out = nullptr;
   const int n_ops = (int)b->ops.size();
   if (n_ops == 0) return hipErrorInvalidValue;
+  const int L = b->ops[0].rows_per_clip, M = b->ops[0].op.M;
+  if (L <= 0 || M % L) return hipErrorInvalidValue;
+  const int B = M / L;
+  for (auto& h : b->ops)
+    if (h.rows_per_clip != L || h.op.M != M) return hipErrorInvalidValue;      // one sequence geometry per chain
+  const int G = xcd_local ? (B + 7) / 8 : B;                                    // clips per group
+  const int NG = (B + G - 1) / G;
+  const int tpg = (G * L + 31) / 32;                                            // row tiles per group
   int n_counters = 0;
-  for (auto& h : b->ops) { h.first_counter = n_counters; n_counters += h.units; }
-  struct Raw { ChainItem it; float rank; int idx; };
+  for (auto& h : b->ops) {
+    h.units = h.op.kind == CH_ATTN ? B : NG * tpg;
+    h.first_counter = n_counters;
+    n_counters += h.units;
+  }
+  struct Raw { ChainItem it; float rank; int queue; };
   std::vector<Raw> raw;
   for (int o = 0; o < n_ops; ++o) {
     const HostOp& h = b->ops[o];
-    const int L = h.rows_per_clip;
-    for (int u = 0; u < h.units; ++u)
+    for (int u = 0; u < h.units; ++u) {
+      int g, row_lo, row_hi, gbase, gend;
+      if (h.op.kind == CH_ATTN) { g = u / G; row_lo = u * L; row_hi = u * L + L - 1; }
+      else { g = u / tpg; row_lo = g * G * L + 32 * (u - g * tpg); row_hi = 0; }
+      gbase = g * G * L;
+      gend = std::min(gbase + G * L, M);
+      if (h.op.kind != CH_ATTN) {
+        if (row_lo >= gend) continue;                                           // a short last group: no such tile
+        row_hi = std::min(row_lo + 31, gend - 1);
+      }
       for (int t = 0; t < h.tiles_per_unit; ++t) {
         ChainItem it{};
         it.op = o;
-        int row_lo, row_hi;                                               // rows of the sequence tensor this tile reads / writes
-        if (h.op.kind == CH_ATTN) { it.m0 = u; it.n0 = t; row_lo = u * L; row_hi = u * L + L - 1; }
-        else { it.m0 = 32 * u; it.n0 = (h.op.kind == CH_GEMM_LNX ? 64 : 32) * t; row_lo = 32 * u; row_hi = std::min(32 * u + 31, h.op.M - 1); }
+        if (h.op.kind == CH_ATTN) { it.m0 = u; it.n0 = t; }
+        else { it.m0 = row_lo; it.n0 = (h.op.kind == CH_GEMM_LNX ? 64 : 32) * t; it.mend = gend; }
         it.sig = h.first_counter + u;
         if (h.dep >= 0) {
           const HostOp& pr = b->ops[h.dep];
           int lo, hi;
-          if (pr.op.kind == CH_ATTN) { lo = row_lo / pr.rows_per_clip; hi = row_hi / pr.rows_per_clip; }
-          else { lo = row_lo / 32; hi = row_hi / 32; }
-          if (hi >= pr.units) hi = pr.units - 1;
+          if (pr.op.kind == CH_ATTN) { lo = row_lo / L; hi = row_hi / L; }
+          else { lo = g * tpg + (row_lo - gbase) / 32; hi = g * tpg + (row_hi - gbase) / 32; }
           it.dep_lo = pr.first_counter + lo; it.dep_n = hi - lo + 1; it.dep_target = pr.tiles_per_unit;
           if (it.dep_n > 64) return hipErrorInvalidValue;
         }
-        const int clip = row_lo / std::max(1, L);
-        raw.push_back({it, (float)o + order_skew * (float)(order_group > 0 ? clip / order_group : 0), (int)raw.size()});
+        const int sub = order_group > 0 ? (row_lo / L - g * G) / order_group : 0;
+        raw.push_back({it, (float)o + order_skew * (float)sub, xcd_local ? g : 0});
       }
+    }
   }
-  std::stable_sort(raw.begin(), raw.end(), [](const Raw& x, const Raw& y) { return x.rank < y.rank; });
-  // emit in rank order, an item only after all producer tiles of the counters it polls (a topological order by construction)
+  std::stable_sort(raw.begin(), raw.end(), [](const Raw& x, const Raw& y) { return x.queue != y.queue ? x.queue < y.queue : x.rank < y.rank; });
+  // emit in (queue, rank) order, an item only after all producer tiles of the counters it polls: a topological order inside
+  // every queue by construction (all producers of an item are in its own queue: tiles never straddle groups)
   std::vector<int> emitted(n_counters, 0);
   std::vector<char> done(raw.size(), 0);
   std::vector<ChainItem> items;
+  std::vector<int> qstart(9, 0);
   items.reserve(raw.size());
-  size_t first_open = 0;
-  while (items.size() < raw.size()) {
-    bool progressed = false;
-    for (size_t i = first_open; i < raw.size(); ++i) {
-      if (done[i]) { if (i == first_open) ++first_open; continue; }
-      const ChainItem& it = raw[i].it;
-      bool ready = true;
-      for (int k = 0; k < it.dep_n && ready; ++k) ready = emitted[it.dep_lo + k] >= it.dep_target;
-      if (!ready) continue;
-      items.push_back(it);
-      ++emitted[it.sig];
-      done[i] = 1;
-      progressed = true;
-      break;                                                               // restart from the lowest rank still open
+  size_t range_lo = 0;
+  for (int qq = 0; qq < 8; ++qq) {
+    size_t range_hi = range_lo;
+    while (range_hi < raw.size() && raw[range_hi].queue == qq) ++range_hi;
+    qstart[qq] = (int)items.size();
+    size_t first_open = range_lo, left = range_hi - range_lo;
+    while (left > 0) {
+      bool progressed = false;
+      for (size_t i = first_open; i < range_hi; ++i) {
+        if (done[i]) { if (i == first_open) ++first_open; continue; }
+        const ChainItem& it = raw[i].it;
+        bool ready = true;
+        for (int k = 0; k < it.dep_n && ready; ++k) ready = emitted[it.dep_lo + k] >= it.dep_target;
+        if (!ready) continue;
+        items.push_back(it);
+        ++emitted[it.sig];
+        done[i] = 1;
+        --left;
+        progressed = true;
+        break;                                                             // restart from the lowest rank still open
+      }
+      if (!progressed) return hipErrorInvalidValue;                         // a dependency cycle: cannot happen for a chain
     }
-    if (!progressed) return hipErrorInvalidValue;                           // a dependency cycle: cannot happen for a chain
+    range_lo = range_hi;
   }
+  qstart[8] = (int)items.size();
+  if (items.size() != raw.size()) return hipErrorInvalidValue;
   ChainPlanImpl* p = new (std::nothrow) ChainPlanImpl();
   if (!p) return hipErrorOutOfMemory;
   p->n_items = (int)items.size();
   p->n_ops = n_ops;
+  p->xcd_local = xcd_local ? 1 : 0;
   p->flops = b->flops; p->bytes = b->bytes;
   p->state_bytes = ((size_t)(CHAIN_STATE_HDR + n_counters) * sizeof(unsigned) + 15) / 16 * 16;
   std::vector<ChainOp> ops(n_ops);
   for (int o = 0; o < n_ops; ++o) ops[o] = b->ops[o].op;
   p->items_host = items;
+  p->qstart_host = qstart;
   for (int o = 0; o < n_ops; ++o) p->op_kind_host.push_back(b->ops[o].op.kind);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ops_dev), ops.size() * sizeof(ChainOp));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->items_dev), items.size() * sizeof(ChainItem));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->qstart_dev), 16 * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->state_dev), p->state_bytes);
   if (e == hipSuccess) e = hipMemcpy(p->ops_dev, ops.data(), ops.size() * sizeof(ChainOp), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(p->items_dev, items.data(), items.size() * sizeof(ChainItem), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->qstart_dev, qstart.data(), 9 * sizeof(int), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(p->state_dev, 0, p->state_bytes);
   if (e == hipSuccess && dev_env("AVSEP_CHAIN_DBG")) {
     e = hipMalloc(reinterpret_cast<void**>(&p->dbg_dev), items.size() * 4 * sizeof(unsigned long long));
@@ -350,16 +418,15 @@ hipError_t chain_build(ChainBuilder* b, int order_group, float order_skew, Chain
   int per_cu = 0, dev = 0, cus = 256;
   p->wps = 4;
   if (const char* g = dev_env("AVSEP_CHAIN_WPS")) p->wps = atoi(g) == 3 ? 3 : 4;       // developer sweep
-  if (e == hipSuccess)
-    e = p->wps == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain_kernel<3>), 256, 0)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(chain_kernel<4>), 256, 0);
+  if (e == hipSuccess) e = chain_occupancy(p, &per_cu);
   if (e == hipSuccess) e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e != hipSuccess) { chain_plan_free(p); return e; }
   if (per_cu < 1) per_cu = 1;
   if (per_cu > p->wps) per_cu = p->wps;
   if (const char* g = dev_env("AVSEP_CHAIN_WGPC")) per_cu = std::max(1, atoi(g));      // developer sweep
-  p->grid = std::min(p->n_items, cus * per_cu);
+  // (XCD-local: every XCD needs its share of workgroups even when the list is short, so the grid is not cut to the item count)
+  p->grid = xcd_local ? cus * per_cu : std::min(p->n_items, cus * per_cu);
   *out = p;
   return hipSuccess;
 }
@@ -369,6 +436,7 @@ void chain_plan_free(ChainPlanImpl* p) {
   if (p->ops_dev) (void)hipFree(p->ops_dev);
   if (p->items_dev) (void)hipFree(p->items_dev);
   if (p->state_dev) (void)hipFree(p->state_dev);
+  if (p->qstart_dev) (void)hipFree(p->qstart_dev);
   if (p->dbg_dev) (void)hipFree(p->dbg_dev);
   delete p;
 }
@@ -380,10 +448,11 @@ int chain_plan_items(const ChainPlanImpl* p) { return p->n_items; }
 hipError_t launch_chain(const ChainPlanImpl* p, hipStream_t s) {
   hipError_t e = hipMemsetAsync(p->state_dev, 0, p->state_bytes, s);
   if (e != hipSuccess) return e;
-  ChainArgs a{p->ops_dev, p->items_dev, p->n_items, p->state_dev, p->dbg_dev, p->backoff};
-  if (p->wps == 3) hipLaunchKernelGGL(chain_kernel<3>, dim3((unsigned)p->grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(chain_kernel<4>, dim3((unsigned)p->grid), dim3(256), 0, s, a);
-  return hipGetLastError();
+  ChainArgs a{p->ops_dev, p->items_dev, p->qstart_dev, p->state_dev, p->dbg_dev, p->backoff};
+  return chain_dispatch(p, [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+  });
 }
 
 // the error word of the last launch (0 = every wait was satisfied); synchronises the stream
@@ -393,7 +462,12 @@ hipError_t chain_plan_error(const ChainPlanImpl* p, hipStream_t s, unsigned* wor
   std::vector<unsigned> st(p->state_bytes / sizeof(unsigned));
   e = hipMemcpy(st.data(), p->state_dev, p->state_bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return e;
-  *word = st[1];
+  *word = st[CHAIN_ERR_WORD];
+  for (int q = 0; q < 8 && !*word; ++q)                                   // a queue no workgroup drained (XCD-local: an XCD without one)
+    if ((int)st[16 * q] < p->qstart_host[q + 1] - p->qstart_host[q]) {
+      *word = 0x80000000u | (unsigned)q;
+      fprintf(stderr, "[chain] queue %d was not drained: %u of %d tickets drawn\n", q, st[16 * q], p->qstart_host[q + 1] - p->qstart_host[q]);
+    }
   if (p->dbg_dev) {      // developer diagnostics: where a tile's life goes, per op (100 MHz wall clock)
     std::vector<unsigned long long> d((size_t)p->n_items * 4);
     if (hipMemcpy(d.data(), p->dbg_dev, d.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -416,8 +490,8 @@ hipError_t chain_plan_error(const ChainPlanImpl* p, hipStream_t s, unsigned* wor
       }
     }
   }
-  if (st[1]) {                              // a wait gave up: say which tile and what its counters read now
-    const int t = (int)st[1] - 1;
+  if (st[CHAIN_ERR_WORD]) {                 // a wait gave up: say which tile and what its counters read now
+    const int t = (int)st[CHAIN_ERR_WORD] - 1;
     if (t >= 0 && t < p->n_items) {
       const ChainItem& it = p->items_host[t];
       fprintf(stderr, "[chain] ticket %d of %d (head now %u, grid %d): op %d kind %d tile (%d, %d) waits for counters [%d, %d) >= %d; they read",
@@ -435,3 +509,4 @@ hipError_t chain_plan_peek(const ChainPlanImpl* p, hipStream_t s, unsigned* out,
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(s);
 }
+#endif  // AVSEP_DEV

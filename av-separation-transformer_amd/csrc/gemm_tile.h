@@ -11,7 +11,10 @@ namespace {
 // and L1-bypassing loads (buffer_* ... sc1, aux = 16).  A CU's vector L1 is never refreshed by another CU's stores and the XCDs'
 // L2s are not coherent with each other (MI355X_MICROARCH.md, inter-workgroup visibility): a handed-off byte is stored sc1,
 // drained (s_waitcnt vmcnt(0)) before its producer signals, and EVERY load of it is an sc1 load -- then no release / acquire
-// fence is needed (cdna_hip_programming.md Guideline 16, R1).  COH = false everywhere else: plain loads and stores.
+// fence is needed (cdna_hip_programming.md Guideline 16, R1).  COH = 1: both.  COH = 2: sc1 loads, PLAIN stores -- for producer and
+// consumer workgroups that are known to sit on the SAME XCD (chain.hip's XCD-local queues): a plain store keeps its line in that
+// XCD's L2, the one coherence point of its CUs, where the consumer's L1-bypassing load finds it (an sc1 store DROPS the line from
+// L2, and every later load of it pays the trip to memory).  COH = 0 everywhere else: plain loads and stores.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t coh_rsrc(const void* base) {          // base must be wave-uniform
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -113,7 +116,7 @@ __device__ __forceinline__ bool epilogue_is_fast(const GemmParams& p) {      // 
 // fetched the C tile itself as a stand-in to keep one code path: 32 KB per 128x64 tile of never-used, HBM-cold reads
 // that the stores then waited behind -- the QKV / FFN-1 / decoder GEMMs, 70 % of the large configs' flops, have no
 // residual.  profiles/r02_ab_epilogue_no_residual_fetch.txt)
-template <int WBM, int WBN, bool HAS_R, bool COH = false>
+template <int WBM, int WBN, bool HAS_R, int COH = 0>
 __device__ __forceinline__ void epilogue_load(const GemmParams& p, EpiOperands<WBM, WBN>& o, int mbase, int nbase, int fr,
                                               int fq) {
   const bool has_b = p.bias != nullptr;                                     // block-uniform
@@ -134,7 +137,7 @@ __device__ __forceinline__ void epilogue_load(const GemmParams& p, EpiOperands<W
   }
 }
 
-template <int WBM, int WBN, int ACT, bool HAS_R, bool COH = false>
+template <int WBM, int WBN, int ACT, bool HAS_R, int COH = 0>
 __device__ __forceinline__ void epilogue_finish(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], EpiOperands<WBM, WBN>& o,
                                                 int mbase, int nbase, int fr, int fq) {
   const bool has_b = p.bias != nullptr;
@@ -162,13 +165,13 @@ __device__ __forceinline__ void epilogue_finish(const GemmParams& p, const f32x4
     for (int j = 0; j < WBN; ++j) {
       const int m = mbase + 16 * i + fr, n = nbase + 16 * j + 4 * fq;
       if (m < p.M && n < p.N) {
-        if (COH) coh_store16(coh_rsrc(p.C), (m * p.ldc + n) * 4, o.rv[i][j]);
+        if (COH == 1) coh_store16(coh_rsrc(p.C), (m * p.ldc + n) * 4, o.rv[i][j]);
         else *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = o.rv[i][j];
       }
     }
 }
 
-template <int WBM, int WBN, bool HAS_R, bool COH = false>
+template <int WBM, int WBN, bool HAS_R, int COH = 0>
 __device__ __forceinline__ void epilogue_finish_act(const GemmParams& p, const f32x4 (&acc)[WBM][WBN],
                                                     EpiOperands<WBM, WBN>& o, int mbase, int nbase, int fr, int fq) {
   switch (p.act) {                                // block-uniform: one straight-line expansion per activation
@@ -243,7 +246,7 @@ __device__ __forceinline__ void mask_epilogue(const GemmParams& p, const f32x4 (
 // profiles/r02_gemm_phase_stamps.txt) -- and with loads on some control-flow path behind the stores, hipcc also drains
 // the counter (s_waitcnt vmcnt(0)) after every pair of stores.  The fast path below is straight-line code: ALL loads
 // of the tile (bias, residual / positional rows), then the arithmetic, then nothing but stores.
-template <int WBM, int WBN, bool COH = false>
+template <int WBM, int WBN, int COH = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], int m0, int n0, int mw,
                                               int nw, int fr, int fq) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -334,7 +337,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (
 // Epilogue of the LayerNorm-in-the-epilogue GEMM (GemmParams::lnx_c1): y = act( rstd (acc - mean c1) + c2 ) with the tile's row
 // statistics in LDS (st[2r] = mean, st[2r+1] = rstd of tile row r).  N % 4 == 0 (checked by the launcher); straight line:
 // loads, arithmetic, stores.
-template <int WBM, int WBN, bool COH = false>
+template <int WBM, int WBN, int COH = 0>
 __device__ __forceinline__ void lnx_epilogue(const GemmParams& p, const f32x4 (&acc)[WBM][WBN], const float* st, int m0, int n0,
                                              int mw, int nw, int fr, int fq) {
   f32x4 c1v[WBN], c2v[WBN];
@@ -375,7 +378,7 @@ __device__ __forceinline__ void lnx_epilogue(const GemmParams& p, const f32x4 (&
     for (int j = 0; j < WBN; ++j) {
       const int m = m0 + mw + 16 * i + fr, n = n0 + nw + 16 * j + 4 * fq;
       if (m < p.M && n < p.N) {
-        if (COH) coh_store16(coh_rsrc(p.C), (m * p.ldc + n) * 4, out[i][j]);
+        if (COH == 1) coh_store16(coh_rsrc(p.C), (m * p.ldc + n) * 4, out[i][j]);
         else *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = out[i][j];
       }
     }
@@ -448,9 +451,9 @@ __device__ __forceinline__ void dbg_stamp(const GemmParams& p, int slot) {
 }
 
 // One BM x BN output tile at (m0, n0): the whole body of gemm_kernel, which wraps it one-to-one.  p.M bounds the rows (rows at
-// or beyond it are clamped for loads and skipped by the stores).  COH: coherent A / residual loads and C stores (top of this file;
+// or beyond it are clamped for loads and skipped by the stores).  COH (1 / 2): coherent A / residual loads and C stores (top of this file;
 // PLAIN / LNX operand modes, fast and LayerNorm epilogues only).
-template <int BM, int BN, int BK, int AMODE, bool PF = false, int RING = 0, bool COH = false>
+template <int BM, int BN, int BK, int AMODE, bool PF = false, int RING = 0, int COH = 0>
 __device__ __forceinline__ void gemm_tile(GemmParams& p, const int m0, const int n0, float* lds) {
   static_assert(!COH || AMODE == AMODE_PLAIN || AMODE == AMODE_LNX, "coherent tiles: plain or LayerNorm-epilogue A operand");
   constexpr int SLOTS = BK / 4;            // 16-byte slots per LDS row
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(256, RING ? 4 : AMODE == AMODE_LNX ? ((BM + BN) * B
   select_pair(p, tile);
   const int bm = p.nbn_magic ? (int)__umulhi((unsigned)tile, p.nbn_magic) : tile / nbn;   // uniform: s_mul_hi_u32
   const int bn = tile - bm * nbn;
-  gemm_tile<BM, BN, BK, AMODE, PF, RING, false>(p, bm * BM, bn * BN, lds);
+  gemm_tile<BM, BN, BK, AMODE, PF, RING, 0>(p, bm * BM, bn * BN, lds);
 }
 
 

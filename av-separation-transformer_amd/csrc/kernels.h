@@ -169,7 +169,7 @@ void chain_builder_free(ChainBuilder* b);
 int chain_add_gemm(ChainBuilder* b, const GemmParams& p, int dep, int L);
 int chain_add_attention(ChainBuilder* b, const AttnProblem& a, int nhead, int dep);
 // device tables of the work list (hipMalloc + blocking copies: never call it while a stream capture is in progress)
-hipError_t chain_build(ChainBuilder* b, int order_group, float order_skew, ChainPlanImpl** out);
+hipError_t chain_build(ChainBuilder* b, int xcd_local, int order_group, float order_skew, ChainPlanImpl** out);
 void chain_plan_free(ChainPlanImpl* p);
 double chain_plan_flops(const ChainPlanImpl* p);
 double chain_plan_bytes(const ChainPlanImpl* p);

@@ -111,23 +111,6 @@ int avsep_set_debug_taps(avsep_ctx* ctx, int on);
 int64_t avsep_read_tap(avsep_ctx* ctx, const char* name, float* dst, int64_t max_floats, void* workspace, int B,
                        int T, int N, int H, int W, void* stream);
 
-/* Launch schedule of the eval forward (round 4).  0 (default): one launch per op, two streams -- the path every golden test
- * pins.  1: the pre-norm encoder layers of each branch (nn.TransformerEncoder of AudioEncoder / VisualEncoder,
- * /root/reference/src/av_separation/model.py:48-52,59 and 97-101,111) run as ONE dependency-driven persistent launch per
- * branch (csrc/chain.hip): tiles of the same kernels' code, started as soon as the producer tiles of THEIR rows / clip have
- * finished instead of after a device-wide launch boundary; outputs are bit-identical to schedule 0.  `group` / `skew` order
- * the work list: clip groups of `group` clips run `skew` ops apart (skew 0 = op-major).  Applies to models whose layers take
- * the LayerNorm-in-the-epilogue GEMM and the short-sequence attention (d_model <= 256, head dim 64, 49..64 positions);
- * other shapes keep schedule 0 silently.  Drops the context's captured graphs.  Not an environment switch: the product
- * library reads none. */
-int avsep_set_schedule(avsep_ctx* ctx, int schedule, int group, float skew);
-/* After a forward under schedule 1: waits for `stream` and returns AVSEP_OK when every dependency wait of the chained launches
- * was satisfied, AVSEP_EINTERNAL (with avsep_last_error()) when a bounded spin gave up (outputs are then invalid). */
-int avsep_chain_status(avsep_ctx* ctx, void* stream);
-/* developer aid: copies the first n state words (ticket head, error word, two unused, arrival counters ...) of chained plan
- * `idx` on a stream of its own, also while the launch is running; returns the number of plans */
-int avsep_chain_peek(avsep_ctx* ctx, int idx, unsigned* out, int n);
-
 /* Live per-kernel profile: between avsep_profile_begin() and avsep_profile_end() every kernel the EAGER
  * entry points launch is issued 20x back to back between one pair of HIP events on the stream it runs on
  * (an event record costs microseconds here, a kernel may take less) and its MEAN duration is kept; outputs
@@ -180,6 +163,25 @@ int avsep_op_attention_proj(const float* q, int ldq, const float* k, int ldk, co
  * tested against bit for bit. */
 int avsep_op_mask_head(const float* x, const float* w, const float* bias, const float* xt, float* masks, float* sep, int M,
                        int N, int K, int F, int ldx, int act, int general, void* stream);
+/* DEVELOPER BUILD ONLY (measured slower than the launch-per-op schedule: DESIGN.md (d), profiles/r04_chain_*).  Launch schedule of
+ * the eval forward (round 4).  0 (default, the only one of the product library): one launch per op, two streams.  1: the pre-norm encoder layers of each branch (nn.TransformerEncoder of AudioEncoder / VisualEncoder,
+ * /root/reference/src/av_separation/model.py:48-52,59 and 97-101,111) run as ONE dependency-driven persistent launch per
+ * branch (csrc/chain.hip): tiles of the same kernels' code, started as soon as the producer tiles of THEIR rows / clip have
+ * finished instead of after a device-wide launch boundary; outputs are bit-identical to schedule 0.  Schedule 1 keeps ONE work
+ * queue and hands tiles over with write-through stores (any workgroup may run any tile); schedule 2 keeps one queue per XCD
+ * (clip groups; a workgroup reads the XCD it runs on from the hardware) and hands over through that XCD's L2 with plain stores.
+ * `group` / `skew` order a queue: sub-groups of `group` clips run `skew` ops apart (skew 0 = op-major).  Applies to models whose
+ * layers take the LayerNorm-in-the-epilogue GEMM and the short-sequence attention (d_model <= 256, head dim 64, 49..64
+ * positions); other shapes keep schedule 0 silently.  Drops the context's captured graphs.  Not an environment switch: the
+ * product library reads none. */
+int avsep_set_schedule(avsep_ctx* ctx, int schedule, int group, float skew);
+/* After a forward under schedule 1: waits for `stream` and returns AVSEP_OK when every dependency wait of the chained launches
+ * was satisfied, AVSEP_EINTERNAL (with avsep_last_error()) when a bounded spin gave up (outputs are then invalid). */
+int avsep_chain_status(avsep_ctx* ctx, void* stream);
+/* developer aid: copies the first n state words (ticket head, error word, two unused, arrival counters ...) of chained plan
+ * `idx` on a stream of its own, also while the launch is running; returns the number of plans */
+int avsep_chain_peek(avsep_ctx* ctx, int idx, unsigned* out, int n);
+
 #endif  /* AVSEP_DEV */
 int avsep_op_interp_linear(const float* x, float* y, int B, int N, int T, int d, void* stream);
 #ifdef AVSEP_DEV

@@ -226,36 +226,29 @@ def test_offset_residual_streams_against_float64_oracle(dev, offset):
     assert maxabs(sep.cpu().numpy(), rs) < MASK_TOL * max(1.0, float(np.abs(mixed).max()))
 
 
-@pytest.mark.parametrize("group,skew", [(8, 0.0), (4, 1.0), (1, 2.5), (16, 0.5)])
-def test_chained_encoder_layers_change_no_bit(dev, group, skew):
-    """Schedule 1 (include/avsep.h avsep_set_schedule; csrc/chain.hip): the encoder layers of each branch as ONE
-    dependency-driven persistent launch -- tiles of the stand-alone kernels' own code, started when the producer tiles of their
-    rows / clip have arrived, handed off through write-through stores and L1-bypassing loads.  For every work-list order the
-    outputs must equal the launch-per-op schedule's BIT FOR BIT, eagerly and under graph replay, at the full bench batch and at
-    a ragged one; and no dependency wait may have timed out."""
+def test_chained_encoder_layers_change_no_bit():
+    """Schedules 1 / 2 (include/avsep.h avsep_set_schedule, developer build; csrc/chain.hip): the encoder layers of each branch as
+    ONE dependency-driven persistent launch -- tiles of the stand-alone kernels' own code, started when the producer tiles of their
+    rows / clip have arrived (1: one queue, write-through hand-offs; 2: one queue per XCD, hand-offs through that XCD's L2).
+    Measured slower than the launch-per-op schedule, so the product library does not carry them; the experiment
+    stays reproducible: for every work-list order the outputs must equal schedule 0's BIT FOR BIT, eagerly and under graph
+    replay, at the full bench batch and at ragged ones, with no dependency wait timed out (tools/chain_check.py on the
+    developer library, in a process of its own because the library of a process is chosen at import)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, AVSEP_LIB="dev")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "chain_check.py")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "CHAIN_CHECK_OK 18 cases" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_product_library_has_no_chained_schedule(dev):
     import av_separation as av
-    torch.manual_seed(3)
-    m = av.AVSeparationTransformer(dropout=0.0).to(dev).eval()
-    for B in (32, 5):
-        ds = av.SyntheticAVDataset(num_samples=B)
-        items = [ds[i] for i in range(B)]
-        mixed = torch.stack([x["mixed_spec"] for x in items]).to(dev)
-        lips = torch.stack([x["lip_frames"] for x in items]).to(dev)
-        with torch.no_grad():
-            m.set_schedule(0)
-            sep0, masks0 = m(mixed, lips)
-            m.set_schedule(1, group, skew)
-            for _ in range(3):                       # counters are re-zeroed by every launch
-                sep1, masks1 = m(mixed, lips)
-                m.chain_status()
-                assert torch.equal(masks1, masks0) and torch.equal(sep1, sep0)
-            m.enable_graph_replay(True)
-            for _ in range(3):
-                sg, mg = m(mixed, lips)
-                m.chain_status()
-                assert torch.equal(mg, masks0) and torch.equal(sg, sep0)
-            m.enable_graph_replay(False)
-            m.set_schedule(0)
+    m = av.AVSeparationTransformer(64, 64, 1, 1, 1, 2)
+    with pytest.raises(RuntimeError, match="developer build"):
+        m.set_schedule(1)
 
 
 @pytest.mark.parametrize("wl", ["cfg3", "cfg5"])

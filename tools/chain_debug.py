@@ -12,6 +12,7 @@ faulthandler.dump_traceback_later(40, exit=False)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 group = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 skew = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+sched = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device("cuda:0")
 torch.manual_seed(3)
 m = av.AVSeparationTransformer(dropout=0.0).to(dev).eval()
@@ -37,7 +38,7 @@ with torch.no_grad():
     sep0, masks0 = m(mixed, lips)
     torch.cuda.synchronize()
     print("schedule 0 forward done", flush=True)
-    m.set_schedule(1, group, skew)
+    m.set_schedule(sched, group, skew)
     print("set_schedule done", flush=True)
     threading.Thread(target=watchdog, daemon=True).start()
     for i in range(3):
