@@ -638,7 +638,10 @@ def also_forward(av, dev, name, steps=5, rounds=3, warmup=3):
            "path_frac": round(value * gflop / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
            "one_step_at_a_time": {"value": round(B * steps / el1, 2), "ms_per_step": round(el1 / steps * 1e3, 4)},
            "slots_bit_equal": same, "masks_in_unit_interval": bool(float(sets[0]["masks"].min()) >= 0.0 and
-                                                                   float(sets[0]["masks"].max()) <= 1.0)}
+                                                                   float(sets[0]["masks"].max()) <= 1.0),
+           "note": "short line inside the default run: the workload's own model and per-GPU batch, hipGraph replay, both in-flight "
+                   "slots hold the same SyntheticAVDataset clips (own buffers, own native context each); the full-length figures "
+                   "are `bench.py --workload " + name + "`"}
     del model, sets
     torch.cuda.empty_cache()
     return out
