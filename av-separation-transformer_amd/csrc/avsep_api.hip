@@ -108,6 +108,11 @@ struct avsep_ctx {
   float* zeros = nullptr;
   std::unordered_map<const float*, LnxW> lnx;     // by the packed weight of the linear layer that follows a LayerNorm
   bool use_lnx = true, lnx_all = false;
+  // Split-precision GEMM (gemm_split.hip; round 4): plain Linear GEMMs with N >= 512 and K >= 512 -- every Linear of the
+  // d_model >= 512 models, none of the d_model = 256 ones -- run their products as six bf16 MFMAs per fp32 product (operands cut
+  // into three bf16 terms, fp32 accumulation): fp32-equivalent results, ~1.5x the fp32 MFMA GEMM's speed.  The rule looks at the
+  // WEIGHT's shape only, never at the row count, so every batch size of a model computes the same bits.
+  bool split_gemm = true;
   // streams / events for the audio || visual fork-join and graph replay
   int device = 0;                                  // the device the context (arena, streams, events, graphs) lives on
   hipStream_t side = nullptr;                      // eager forwards: the visual branch's stream
@@ -380,6 +385,8 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
   double bytes = a_bytes + (double)p.N * k * 4 * (p.alt.M > 0 ? 2 : 1) + rows * p.N * 4 * (p.C2 ? 2 : 1);
   if (p.R) bytes += (p.rperiod > 0 ? (double)p.rperiod : rows) * p.N * 4;
   if (p.C2) bytes += (double)p.M * p.F * 4;
+  if (c->split_gemm && p.N >= 512 && p.K >= 512 && gemm_split_supported(p))       // see avsep_ctx::split_gemm
+    return profiled(c, gemm_split_instance_name(p), flops, bytes, s, [&] { return launch_gemm_split(p, s); });
   return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm(p, s); });
 }
 int run_layernorm(avsep_ctx* c, const float* x, const float* g, const float* b, float* y, int M, int d, hipStream_t s) {
@@ -995,6 +1002,7 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   // (+5 % on the cfg2 step, profiles/r03_ab_ln_epilogue.txt).  Large problems and d_model = 512 keep LayerNorm launch +
   // big-tile GEMM: measured 2.7 % faster there, and every batch size of such a model then computes the same bits.
   // Developer A/B: AVSEP_NO_LNX=1 restores the in-kernel LayerNorm form of round 2, AVSEP_LNX=all takes every site.
+  c->split_gemm = dev_env("AVSEP_NO_SPLIT") == nullptr;            // developer A/B: the fp32 MFMA GEMM everywhere
   c->use_lnx = dev_env("AVSEP_NO_LNX") == nullptr && (gemm_ln_supported(c->d) || dev_env("AVSEP_LNX"));
   c->lnx_all = dev_env("AVSEP_LNX") && !strcmp(dev_env("AVSEP_LNX"), "all");
   size_t off = 0;
@@ -1465,6 +1473,18 @@ int avsep_op_linear(const float* x, const float* w, const float* bias, const flo
   GemmParams p = linear_params(x, K, w, K, bias, y, N, M, N, act);
   if (residual) { p.R = residual; p.ldr = N; }
   HCK(launch_gemm(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_linear_split(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int N,
+                          int K, int act, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || N % 4) return fail(AVSEP_EINVAL, "K must be a multiple of 32 and N of 4");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  GemmParams p = linear_params(x, K, w, K, bias, y, N, M, N, act);
+  if (residual) { p.R = residual; p.ldr = N; }
+  if (!gemm_split_supported(p)) return fail(AVSEP_EINVAL, "shape not supported by the split-precision GEMM");
+  HCK(launch_gemm_split(p, reinterpret_cast<hipStream_t>(stream)));
   return AVSEP_OK;
 }
 

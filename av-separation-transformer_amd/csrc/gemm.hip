@@ -1381,6 +1381,14 @@ hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStrea
 
 hipError_t launch_gemm_impl(GemmParams p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 31)) return hipErrorInvalidValue;
+#ifdef AVSEP_DEV
+  // developer A/B (AVSEP_GEMM_SPLIT=<min 128x128 tiles>): avsep_op_linear & co. on the split-precision GEMM (the forward's own
+  // rule is in avsep_api.hip run_gemm)
+  if (const char* e = getenv("AVSEP_GEMM_SPLIT")) {
+    const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (gemm_split_supported(p) && tiles >= atol(e)) return launch_gemm_split(p, s);
+  }
+#endif
   if ((p.amode == AMODE_TAPS3 || p.amode == AMODE_CONV2D) && (p.Kt <= 0 || (p.Kt & 31))) return hipErrorInvalidValue;
   if (p.amode == AMODE_TAPS3 && !p.zeros) return hipErrorInvalidValue;
   if (p.amode == AMODE_FRAMES && (p.T <= 0 || p.frame_hop <= 0 || (p.frame_hop & 3) || p.frame_len <= 0 || (p.frame_len & 3)))

@@ -1,0 +1,195 @@
+// gemm_split.hip -- split-precision GEMM (round 4): fp32 operands, fp32 result, the products on the bf16 matrix pipe.
+//
+// The fp32 MFMA (v_mfma_f32_16x16x4_f32: 256 FLOP/clk/CU, 157 TFLOP/s) is the ceiling every GEMM of this path sits under, and three
+// rounds of work on the 128x64 tile stand at 0.78 of it.  SURVEY.md §7 names the one other road that keeps the 1e-4 mask contract:
+// "a split-precision (hi+lo) scheme validated against the golden vectors".  This file builds it:
+//
+//   * every fp32 operand x is cut into THREE bf16 terms by truncation, x = hi + mid + lo (+ < 2^-24 |x|): hi = the upper 16 bits of
+//     x, mid = the upper 16 bits of (x - hi), lo = the upper 16 bits of (x - hi - mid); the two subtractions are exact.
+//   * x w = SIX bf16 products -- (hi,hi) (hi,mid) (mid,hi) (mid,mid) (hi,lo) (lo,hi) -- each exact in fp32 (8 x 8 mantissa bits),
+//     accumulated in fp32 by v_mfma_f32_16x16x32_bf16, which runs at 16x the fp32 MFMA's rate: 6 / 16 of the fp32 matrix time.
+//     The dropped terms (mid,lo) (lo,mid) (lo,lo) are < 2^-23 relative: CPU emulation on model-like operands (K = 256 ... 2048)
+//     puts the split's own error at 6e-8 of max|y|, below the 5e-7 of an fp32 GEMM's accumulation, and the config-1 model's masks
+//     at 4.1e-7 from float64 with every Linear computed this way (fp32 path: 5.3e-7) -- profiles/r04_split_precision_accuracy.txt.
+//   * 128 x 128 x 32 tile, 256 threads = 2 x 2 waves of 64 x 64; operands are split on their way to LDS (5.5 VALU per element) into
+//     three [rows][32] bf16 planes per operand, 16-byte slots XOR-swizzled for this chip's per-instruction LDS lane groups; a fragment is one ds_read_b128 (8 bf16
+//     along k); 96 MFMAs per wave and chunk.  The MFMA's C / D layout is the fp32 16x16 one, operands swapped like gemm_kernel's
+//     (D^T), so the fused epilogues of gemm_tile.h are used unchanged.
+//
+// PLAIN A operand, fast epilogue (bias / activation / residual).  Not bit-identical to the fp32 kernels (another rounding of the same
+// products): parity is by tolerance against float64 (tests/test_gpu_parity.py::test_op_linear_split_precision).
+#include "kernels.h"
+#include "gemm_tile.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// three bf16 planes of 4 fp32 values: plane p of elements (e0,e1) and (e2,e3) as two dwords each (low half = the even element)
+__device__ __forceinline__ void split4(const f32x4 v, unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
+  unsigned h[4], m[4], l[4];
+  // (scalar copies and __float_as_uint: hipcc 7.2 reads ELEMENT 0 for every e when __builtin_bit_cast is applied to the
+  // ext-vector element expression v[e] directly -- found by the one-hot probes of tools/gemm_split_debug.py)
+  const float xs[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = xs[e];
+    const unsigned u = __float_as_uint(x);
+    h[e] = u;                                                         // upper 16 bits are taken by the pack below
+    const float r1 = x - __uint_as_float(u & 0xFFFF0000u);            // exact
+    m[e] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(m[e] & 0xFFFF0000u);        // exact
+    l[e] = __float_as_uint(r2);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {                                       // bytes [3,2] of the odd element | bytes [3,2] of the even one
+    hi[q] = __builtin_amdgcn_perm(h[2 * q + 1], h[2 * q], 0x07060302u);
+    mid[q] = __builtin_amdgcn_perm(m[2 * q + 1], m[2 * q], 0x07060302u);
+    lo[q] = __builtin_amdgcn_perm(l[2 * q + 1], l[2 * q], 0x07060302u);
+  }
+}
+
+constexpr int SBM = 128, SBN = 128, SBK = 32;
+constexpr int PLANE = SBM * SBK;          // bf16 elements of one plane of one operand tile (rows x 32)
+
+// (W pre-packed into its three planes by the weight packer -- 6 B per weight from L2, no VALU for W -- was built and measured 4.5 %
+// SLOWER in the cfg3 / cfg5 forward than splitting W on its way to LDS like A: profiles/r04_ab_split_gemm_w_planes.txt.  The
+// kernel waits for operand bytes, not for the VALU.)
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmParams pin) {
+  GemmParams p = pin;
+  // [operand A|W][plane hi|mid|lo][row][32 bf16]: 6 x 8 KB = 48 KB; ONE buffer, two barriers per chunk (the next chunk's global
+  // loads are in flight under this chunk's MFMAs; the split + LDS writes follow them)
+  __shared__ __attribute__((aligned(16))) unsigned short lds[6 * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + SBN - 1) / SBN;
+  int tile = xcd_tile(p);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * SBM, n0 = bn * SBN;
+
+  // staging: thread -> (row, 16-float half = tid % 2) of both operand tiles.  LDS banking on gfx950 is per instruction
+  // (MI355X_MICROARCH.md, LDS): ds_read_b128 is served in the lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} (+32), banks
+  // (a/4) mod 64; ds_write_b128 in groups of 8 consecutive lanes, banks (a/4) mod 32.  With 64-byte rows that asks for
+  //   * the slot swizzle sw(row) = -(row >> 2) & 3 (gemm.hip's (row >> 2) & 3 is 2-way conflicted under these read groups:
+  //     SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE in the first version, profiles/r04_pmc_gemm_split.txt), and
+  //   * 8 consecutive lanes writing rows {b, b+1, b+4, b+5}, not {b .. b+3} (rows b and b+2 share their 128-byte bank window and
+  //     their slot pair): bits 1 and 2 of the row index are swapped in the thread -> row map.
+  const int su = tid >> 1, shalf = tid & 1;
+  const int srow = (su & ~6) | ((su & 2) << 1) | ((su & 4) >> 1);
+  const int am = min(m0 + srow, p.M - 1), wnr = min(n0 + srow, p.N - 1);
+  const float* a_src = p.A + (size_t)am * p.lda + 16 * shalf;
+  const float* w_src = p.W + (size_t)wnr * p.ldw + 16 * shalf;
+  const int sw = (0 - (srow >> 2)) & 3;
+  // byte offsets (inside a plane) of this thread's two 16-byte slots: logical slots 2*shalf, 2*shalf + 1
+  const int st0 = srow * 64 + (((2 * shalf) ^ sw) << 4), st1 = srow * 64 + (((2 * shalf + 1) ^ sw) << 4);
+
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[4], rw[4];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = *reinterpret_cast<const f32x4*>(a_src + kc * SBK + 4 * j);
+      rw[j] = *reinterpret_cast<const f32x4*>(w_src + kc * SBK + 4 * j);
+    }
+  };
+  auto store_chunk = [&]() {
+    char* base = reinterpret_cast<char*>(lds);
+#pragma unroll
+    for (int opnd = 0; opnd < 2; ++opnd) {
+      unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned h2[2], m2[2], l2[2];
+        split4(opnd ? rw[j] : ra[j], h2, m2, l2);
+        hi[2 * j] = h2[0]; hi[2 * j + 1] = h2[1];
+        mid[2 * j] = m2[0]; mid[2 * j + 1] = m2[1];
+        lo[2 * j] = l2[0]; lo[2 * j + 1] = l2[1];
+      }
+      char* ob = base + opnd * 3 * PLANE * 2;
+      *reinterpret_cast<u4*>(ob + 0 * PLANE * 2 + st0) = u4{hi[0], hi[1], hi[2], hi[3]};
+      *reinterpret_cast<u4*>(ob + 0 * PLANE * 2 + st1) = u4{hi[4], hi[5], hi[6], hi[7]};
+      *reinterpret_cast<u4*>(ob + 1 * PLANE * 2 + st0) = u4{mid[0], mid[1], mid[2], mid[3]};
+      *reinterpret_cast<u4*>(ob + 1 * PLANE * 2 + st1) = u4{mid[4], mid[5], mid[6], mid[7]};
+      *reinterpret_cast<u4*>(ob + 2 * PLANE * 2 + st0) = u4{lo[0], lo[1], lo[2], lo[3]};
+      *reinterpret_cast<u4*>(ob + 2 * PLANE * 2 + st1) = u4{lo[4], lo[5], lo[6], lo[7]};
+    }
+  };
+
+  // fragment coordinates: lane (r = lane & 15, q = lane >> 4) reads the 8 bf16 k = 8q .. 8q + 7 of row 16 blk + r: logical slot q
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_fo[4], w_fo[4];                                                 // byte offsets inside a plane
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 64 + 16 * i + fr;
+    a_fo[i] = r * 64 + ((fq ^ ((0 - (r >> 2)) & 3)) << 4);
+    const int c = wn * 64 + 16 * i + fr;
+    w_fo[i] = c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / SBK;
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) load_chunk(kc + 1);                                // block-uniform; in flight under the MFMAs below
+    const char* ab = reinterpret_cast<const char*>(lds);
+    const char* wb = ab + 3 * PLANE * 2;
+    // smallest products first: (hi,lo) (lo,hi) (mid,mid) (mid,hi) (hi,mid) (hi,hi).  Every plane's fragments are read from LDS
+    // ONCE per chunk (24 ds_read_b128 per wave; re-reading them per product doubled that and put 8 waves per CU above the LDS's
+    // 128 B/clk): hi and mid of both operands stay in registers across the products that use them, lo passes through.
+    auto frag = [&](const char* base, int plane, const int (&off)[4], bf16x8 (&f)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(base + plane * PLANE * 2 + off[i]);
+    };
+    auto mma = [&](const bf16x8 (&fwp)[4], const bf16x8 (&fap)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwp[j], fap[i], acc[i][j], 0, 0, 0);     // D^T: see gemm_epilogue
+    };
+    bf16x8 a_hi[4], w_hi[4], a_mid[4], w_mid[4], t_lo[4];
+    frag(ab, 0, a_fo, a_hi);
+    frag(wb, 2, w_fo, t_lo);
+    mma(t_lo, a_hi);                                  // (hi, lo)
+    frag(wb, 0, w_fo, w_hi);
+    frag(ab, 2, a_fo, t_lo);
+    mma(w_hi, t_lo);                                  // (lo, hi)
+    frag(ab, 1, a_fo, a_mid);
+    frag(wb, 1, w_fo, w_mid);
+    mma(w_mid, a_mid);                                // (mid, mid)
+    mma(w_hi, a_mid);                                 // (mid, hi)
+    mma(w_mid, a_hi);                                 // (hi, mid)
+    mma(w_hi, a_hi);                                  // (hi, hi)
+    __syncthreads();                                                    // every wave has read this chunk's planes
+    if (kc + 1 < nk) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+  gemm_epilogue<4, 4>(p, acc, m0, n0, wm * 64, wn * 64, fr, fq);
+}
+
+}  // namespace
+
+bool gemm_split_supported(const GemmParams& p) {
+  return p.amode == AMODE_PLAIN && !p.lnx_c1 && !p.ln_gamma && !p.ln_stats && p.ksplit <= 1 && p.mag_F == 0 && p.drop_p <= 0.0f &&
+         !p.C2 && !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3)) && !(p.K & 31) && !(p.lda & 3) && !(p.ldw & 3) && p.alt.M <= 0 &&
+         !p.epi_general;
+}
+
+const char* gemm_split_instance_name(const GemmParams&) { return "gemm_split_kernel"; }
+
+hipError_t launch_gemm_split(GemmParams p, hipStream_t s) {
+  if (!gemm_split_supported(p) || p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
+  const long tiles = (long)((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
+  p.nbn_magic = 0;
+  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)tiles), dim3(256), 0, s, p);
+  return hipGetLastError();
+}

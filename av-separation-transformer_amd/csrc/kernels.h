@@ -147,6 +147,11 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 #ifdef AVSEP_DEV
 hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStream_t s);
 #endif
+// split-precision GEMM (gemm_split.hip): fp32 operands as three bf16 terms each, six bf16 MFMA products, fp32 accumulation;
+// fp32-equivalent results at 6 / 16 of the fp32 MFMA's matrix time.  PLAIN A operand, fast epilogue.
+bool gemm_split_supported(const GemmParams& p);
+hipError_t launch_gemm_split(GemmParams p, hipStream_t s);
+const char* gemm_split_instance_name(const GemmParams& p);
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
 // with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)

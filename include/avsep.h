@@ -131,6 +131,13 @@ int64_t avsep_profile_end(avsep_ctx* ctx, char* json, size_t capacity);
  * y = act(LN?(x) W^T + b) (+ residual); act: 0 none, 1 relu, 2 gelu(erf), 3 sigmoid. */
 int avsep_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M,
                     int N, int K, int act, void* stream);
+/* The same Linear on the split-precision GEMM (csrc/gemm_split.hip; what the forward runs for weights with N >= 512 and
+ * K >= 512, i.e. every nn.Linear of the d_model >= 512 configurations, /root/reference/src/av_separation/model.py:48-52, 93,
+ * 155-161, 195): each fp32 operand is cut into three bf16 terms (exact truncation splits), the six significant bf16 x bf16
+ * products are accumulated in fp32 on the bf16 matrix cores.  fp32 in, fp32 out, error against float64 at the fp32 GEMM's own level
+ * (tests/test_gpu_parity.py::test_op_linear_split_precision); NOT bit-identical to avsep_op_linear. */
+int avsep_op_linear_split(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int N,
+                          int K, int act, void* stream);
 int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                        float eps, void* stream);
 /* y = act(LayerNorm(x) W^T + b), the pair every pre-norm block of the model is made of (model.py:48-52 norm_first

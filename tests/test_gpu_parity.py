@@ -749,6 +749,43 @@ def test_mask_head_epilogue_bit_identical_to_block_by_block(devlib, dev, M, S, F
     assert torch.equal(s0, m0 * xt[:, :F].repeat(1, S))
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(16064, 512, 512, 0, True), (3200, 1536, 512, 1, False), (4016, 512, 2048, 2, True),
+                                           (251, 2048, 512, 1, False), (777, 260, 96, 3, True), (129, 516, 544, 0, False),
+                                           (1, 512, 512, 2, True)])
+def test_op_linear_split_precision(lib, dev, M, N, K, act, res):
+    """The split-precision GEMM (csrc/gemm_split.hip; what the forward runs for every nn.Linear of the d_model >= 512
+    configurations): fp32 operands cut into three bf16 terms, six bf16 MFMA products, fp32 accumulation.  Against float64 its
+    error must sit at the fp32-MFMA GEMM's own level -- gated at 2x that kernel's error on the same operands + 2e-7 of max|y|,
+    and at 4e-6 absolutely; rows are independent of the batch (a row computed alone has the bits it has inside the full problem)."""
+    x = t(seeded.tensor(23, "x", (M, K), -3, 5), dev)
+    w = t(seeded.tensor(23, "w", (N, K), -0.2, 0.2), dev)
+    b = t(seeded.tensor(23, "b", (N,), -1, 1), dev)
+    r = t(seeded.tensor(23, "r", (M, N), -2, 2), dev) if res else None
+    ref = x.double() @ w.double().t() + b.double()
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.nn.functional.gelu(ref), 3: torch.sigmoid(ref)}[act]
+    if res:
+        ref = ref + r.double()
+    y0 = torch.full((M, N), float("nan"), device=dev)
+    y1 = torch.full((M, N), float("nan"), device=dev)
+    rp = r.data_ptr() if res else None
+    assert lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), rp, y0.data_ptr(), M, N, K, act, _stream()) == 0
+    assert lib.avsep_op_linear_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), rp, y1.data_ptr(), M, N, K, act, _stream()) == 0, \
+        lib.avsep_last_error()
+    assert torch.isfinite(y1).all()
+    scale = float(ref.abs().max())
+    e0 = float((y0.double() - ref).abs().max()) / scale
+    e1 = float((y1.double() - ref).abs().max()) / scale
+    assert e1 < 2.0 * e0 + 2e-7, (e0, e1)
+    assert e1 < 4e-6, (e0, e1)
+    m = M // 2                                                    # one row alone: the bits it has inside the full problem
+    y2 = torch.full((1, N), float("nan"), device=dev)
+    r2 = r[m:m + 1].contiguous() if res else None
+    assert lib.avsep_op_linear_split(x[m:m + 1].contiguous().data_ptr(), w.data_ptr(), b.data_ptr(), r2.data_ptr() if res else None,
+                                     y2.data_ptr(), 1, N, K, act, _stream()) == 0
+    assert torch.equal(y2[0], y1[m])
+    assert lib.avsep_op_linear_split(x.data_ptr(), w.data_ptr(), None, None, y1.data_ptr(), 4, 6, 32, 0, _stream()) == -1   # N % 4
+
+
 def test_op_linear_rejects_bad_k(lib, dev):
     y = torch.empty(4, 4, device=dev)
     assert lib.avsep_op_linear(y.data_ptr(), y.data_ptr(), None, None, y.data_ptr(), 4, 4, 30, 0, _stream()) == -1
