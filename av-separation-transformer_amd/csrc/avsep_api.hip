@@ -108,10 +108,12 @@ struct avsep_ctx {
   float* zeros = nullptr;
   std::unordered_map<const float*, LnxW> lnx;     // by the packed weight of the linear layer that follows a LayerNorm
   bool use_lnx = true, lnx_all = false;
-  // Split-precision GEMM (gemm_split.hip; round 4): plain Linear GEMMs with N >= 512 and K >= 512 -- every Linear of the
-  // d_model >= 512 models, none of the d_model = 256 ones -- run their products as six bf16 MFMAs per fp32 product (operands cut
-  // into three bf16 terms, fp32 accumulation): fp32-equivalent results, ~1.5x the fp32 MFMA GEMM's speed.  The rule looks at the
-  // WEIGHT's shape only, never at the row count, so every batch size of a model computes the same bits.
+  // Split-precision GEMM (gemm_split.hip; round 4): in models with d_model >= 512, every GEMM whose weight has N >= 512 and
+  // K >= 512 -- all nn.Linear layers, the two Conv1d of the audio front-end (3-tap A operand) and the mask head -- runs its
+  // products as six bf16 MFMAs per fp32 product (operands cut into three bf16 terms, fp32 accumulation): fp32-equivalent
+  // results, ~1.6x the fp32 MFMA GEMM's speed.  The rule looks at the MODEL and the WEIGHT's shape only, never at the row
+  // count, so every batch size of a model computes the same bits; d_model = 256 models keep the fp32 MFMA everywhere (their
+  // GEMMs are latency-bound: 128 x 128 tiles would leave the chip empty).
   bool split_gemm = true;
   // streams / events for the audio || visual fork-join and graph replay
   int device = 0;                                  // the device the context (arena, streams, events, graphs) lives on
@@ -385,7 +387,9 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
   double bytes = a_bytes + (double)p.N * k * 4 * (p.alt.M > 0 ? 2 : 1) + rows * p.N * 4 * (p.C2 ? 2 : 1);
   if (p.R) bytes += (p.rperiod > 0 ? (double)p.rperiod : rows) * p.N * 4;
   if (p.C2) bytes += (double)p.M * p.F * 4;
-  if (c->split_gemm && p.N >= 512 && p.K >= 512 && gemm_split_supported(p))       // see avsep_ctx::split_gemm
+  static const bool no_taps = dev_env("AVSEP_SPLIT_NO_TAPS") != nullptr, no_mask = dev_env("AVSEP_SPLIT_NO_MASK") != nullptr;   // developer A/B
+  if (c->split_gemm && c->d >= 512 && p.N >= 512 && p.K >= 512 && gemm_split_supported(p) &&       // see avsep_ctx::split_gemm
+      !(no_taps && p.amode == AMODE_TAPS3) && !(no_mask && p.C2))
     return profiled(c, gemm_split_instance_name(p), flops, bytes, s, [&] { return launch_gemm_split(p, s); });
   return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm(p, s); });
 }

@@ -16,7 +16,7 @@
 //     along k); 96 MFMAs per wave and chunk.  The MFMA's C / D layout is the fp32 16x16 one, operands swapped like gemm_kernel's
 //     (D^T), so the fused epilogues of gemm_tile.h are used unchanged.
 //
-// PLAIN A operand, fast epilogue (bias / activation / residual).  Not bit-identical to the fp32 kernels (another rounding of the same
+// PLAIN or 3-tap (Conv1d) A operand; the straight-line bias / activation / residual epilogue or the mask head's.  Not bit-identical to the fp32 kernels (another rounding of the same
 // products): parity is by tolerance against float64 (tests/test_gpu_parity.py::test_op_linear_split_precision).
 #include "kernels.h"
 #include "gemm_tile.h"
@@ -78,6 +78,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmParams pin
   const int srow = (su & ~6) | ((su & 2) << 1) | ((su & 4) >> 1);
   const int am = min(m0 + srow, p.M - 1), wnr = min(n0 + srow, p.N - 1);
   const float* a_src = p.A + (size_t)am * p.lda + 16 * shalf;
+  // TAPS3 (nn.Conv1d k = 3, pad 1 as ONE GEMM over K = 3 Kt, like gemm_kernel's AMODE_TAPS3): the rows of tap 0 / 2 are the
+  // sequence's previous / next row, or the zero row (GemmParams::zeros) outside the sequence; block-uniform tap per chunk
+  const bool taps = p.amode == AMODE_TAPS3;
+  const float *a_prev = a_src, *a_next = a_src;
+  if (taps) {
+    const int t = am % p.T;
+    const float* zrow = p.zeros + 16 * shalf;
+    a_prev = t > 0 ? a_src - p.lda : zrow;
+    a_next = t + 1 < p.T ? a_src + p.lda : zrow;
+  }
+  const int cpt = taps ? p.Kt / SBK : 1 << 30;                          // chunks per tap
   const float* w_src = p.W + (size_t)wnr * p.ldw + 16 * shalf;
   const int sw = (0 - (srow >> 2)) & 3;
   // byte offsets (inside a plane) of this thread's two 16-byte slots: logical slots 2*shalf, 2*shalf + 1
@@ -88,7 +99,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmParams pin
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      ra[j] = *reinterpret_cast<const f32x4*>(a_src + kc * SBK + 4 * j);
+      if (taps) {
+        const int tap = kc / cpt, sub = kc - tap * cpt;                  // uniform
+        const float* row = tap == 0 ? a_prev : tap == 1 ? a_src : a_next;
+        ra[j] = *reinterpret_cast<const f32x4*>(row + sub * SBK + 4 * j);
+      } else {
+        ra[j] = *reinterpret_cast<const f32x4*>(a_src + kc * SBK + 4 * j);
+      }
       rw[j] = *reinterpret_cast<const f32x4*>(w_src + kc * SBK + 4 * j);
     }
   };
@@ -179,9 +196,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmParams pin
 }  // namespace
 
 bool gemm_split_supported(const GemmParams& p) {
-  return p.amode == AMODE_PLAIN && !p.lnx_c1 && !p.ln_gamma && !p.ln_stats && p.ksplit <= 1 && p.mag_F == 0 && p.drop_p <= 0.0f &&
-         !p.C2 && !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3)) && !(p.K & 31) && !(p.lda & 3) && !(p.ldw & 3) && p.alt.M <= 0 &&
-         !p.epi_general;
+  const bool a_ok = p.amode == AMODE_PLAIN || (p.amode == AMODE_TAPS3 && p.Kt > 0 && !(p.Kt & 31) && p.K == 3 * p.Kt && p.T > 0 && p.zeros);
+  // epilogues: the straight-line bias / activation / residual one (N % 4 == 0), or the mask head's (two outputs, N even)
+  const bool fast = !p.C2 && !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
+  const bool mask = p.C2 && p.X && !(p.N & 1) && !(p.ldc & 1) && !p.R;
+  return a_ok && !p.lnx_c1 && !p.ln_gamma && !p.ln_stats && p.ksplit <= 1 && p.mag_F == 0 && p.drop_p <= 0.0f && (fast || mask) &&
+         !(p.K & 31) && !(p.lda & 3) && !(p.ldw & 3) && p.alt.M <= 0 && !p.epi_general;
 }
 
 const char* gemm_split_instance_name(const GemmParams&) { return "gemm_split_kernel"; }
