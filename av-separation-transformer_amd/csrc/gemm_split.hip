@@ -193,6 +193,158 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmParams pin
   gemm_epilogue<4, 4>(p, acc, m0, n0, wm * 64, wn * 64, fr, fq);
 }
 
+// ---- the 256 x 128 tile (large M) -------------------------------------------------------------------------------------------
+// gemm_split_kernel alternates two phases per chunk -- 96 MFMAs, then the split of the next chunk (VALU + LDS writes) between two
+// barriers -- and leans on the CU's other workgroup to fill the matrix pipe during the second: SQ_VALU_MFMA_BUSY_CYCLES says
+// 49 %.  On this chip VALU instructions of ANOTHER wave hardly overlap with a wave's MFMAs, but one or two VALU instructions
+// BEHIND each MFMA of the same wave hide about half their cycles (profiles/r04_mfma_bf16_valu_share.txt).  This kernel therefore
+// has no phases: 512 threads = 4 x 2 waves of 64 x 64, LDS double-buffered (2 x 72 KB), ONE barrier per chunk, and inside a chunk
+// every product's 16 MFMAs are followed in program order by one sixth of the next chunk's split (22 VALU), its LDS writes into the
+// other buffer, and the global loads of the chunk after that into the registers just consumed -- so a load has one whole chunk
+// (~0.8 us) to land.  Per thread and chunk 24 operand elements instead of 32 (the 256-row tile shares W among more rows).
+// The loop body is branch-free: the last chunks split / reload clamped data into the buffer nobody reads.
+constexpr int S2BM = 256, S2BN = 128;
+constexpr int S2_APL = S2BM * SBK * 2, S2_WPL = S2BN * SBK * 2;   // bytes of one plane
+constexpr int S2_BUF = 3 * S2_APL + 3 * S2_WPL;                  // 72 KB: [A hi|mid|lo][W hi|mid|lo]
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 fp32 values -> one 16-byte slot of each of the three planes
+__device__ __forceinline__ void split8_store(const f32x4 v0, const f32x4 v1, char* hi_p, char* mid_p, char* lo_p) {
+  unsigned h0[2], m0[2], l0[2], h1[2], m1[2], l1[2];
+  split4(v0, h0, m0, l0);
+  split4(v1, h1, m1, l1);
+  *reinterpret_cast<u32x4*>(hi_p) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+  *reinterpret_cast<u32x4*>(mid_p) = u32x4{m0[0], m0[1], m1[0], m1[1]};
+  *reinterpret_cast<u32x4*>(lo_p) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_split_kernel2(const GemmParams pin) {
+  GemmParams p = pin;
+  extern __shared__ __attribute__((aligned(16))) char lds2[];           // 2 x S2_BUF
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + S2BN - 1) / S2BN;
+  int tile = xcd_tile(p);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * S2BM, n0 = bn * S2BN;
+
+  // A staging as in gemm_split_kernel (thread -> row, 16-float half; bits 1 and 2 of the row swapped); W staging: thread ->
+  // (row = tid / 4, 8-float quarter): 8 consecutive lanes write two whole 64-byte rows = every bank once
+  const int su = tid >> 1, shalf = tid & 1;
+  const int srow = (su & ~6) | ((su & 2) << 1) | ((su & 4) >> 1);
+  const int wrow = tid >> 2, wq = tid & 3;
+  const int am = min(m0 + srow, p.M - 1), wnr = min(n0 + wrow, p.N - 1);
+  const float* a_src = p.A + (size_t)am * p.lda + 16 * shalf;
+  const bool taps = p.amode == AMODE_TAPS3;
+  const float *a_prev = a_src, *a_next = a_src;
+  if (taps) {
+    const int t = am % p.T;
+    const float* zrow = p.zeros + 16 * shalf;
+    a_prev = t > 0 ? a_src - p.lda : zrow;
+    a_next = t + 1 < p.T ? a_src + p.lda : zrow;
+  }
+  const int cpt = taps ? p.Kt / SBK : 1 << 30;
+  const float* w_src = p.W + (size_t)wnr * p.ldw + 8 * wq;
+  const int sw = (0 - (srow >> 2)) & 3;
+  const int ast0 = srow * 64 + (((2 * shalf) ^ sw) << 4), ast1 = srow * 64 + (((2 * shalf + 1) ^ sw) << 4);
+  const int wst = 3 * S2_APL + wrow * 64 + ((wq ^ ((0 - (wrow >> 2)) & 3)) << 4);
+
+  const int nk = p.K / SBK;
+  f32x4 ra0, ra1, ra2, ra3, rw0, rw1;
+#define S2_A_ROW(ptr, kc)                                                                   \
+  const float* ptr;                                                                         \
+  {                                                                                         \
+    const int tap_ = (kc) / cpt, sub_ = (kc) - tap_ * cpt; /* uniform; tap 0, sub kc when PLAIN */ \
+    ptr = (taps ? (tap_ == 0 ? a_prev : tap_ == 1 ? a_src : a_next) : a_src) + sub_ * SBK;  \
+  }
+#define S2_LD4(ptr, j) (*reinterpret_cast<const f32x4*>((ptr) + 4 * (j)))
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_fo[4], w_fo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 64 + 16 * i + fr;
+    a_fo[i] = r * 64 + ((fq ^ ((0 - (r >> 2)) & 3)) << 4);
+    const int c = wn * 64 + 16 * i + fr;
+    w_fo[i] = 3 * S2_APL + c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: chunk 0 into buffer 0, chunk 1 into the registers
+  {
+    S2_A_ROW(ap, 0)
+    const float* wp = w_src;
+    ra0 = S2_LD4(ap, 0); ra1 = S2_LD4(ap, 1); ra2 = S2_LD4(ap, 2); ra3 = S2_LD4(ap, 3);
+    rw0 = S2_LD4(wp, 0); rw1 = S2_LD4(wp, 1);
+  }
+  split8_store(ra0, ra1, lds2 + ast0, lds2 + S2_APL + ast0, lds2 + 2 * S2_APL + ast0);
+  split8_store(ra2, ra3, lds2 + ast1, lds2 + S2_APL + ast1, lds2 + 2 * S2_APL + ast1);
+  split8_store(rw0, rw1, lds2 + wst, lds2 + S2_WPL + wst, lds2 + 2 * S2_WPL + wst);
+  {
+    const int k1 = min(1, nk - 1);
+    S2_A_ROW(ap, k1)
+    const float* wp = w_src + k1 * SBK;
+    ra0 = S2_LD4(ap, 0); ra1 = S2_LD4(ap, 1); ra2 = S2_LD4(ap, 2); ra3 = S2_LD4(ap, 3);
+    rw0 = S2_LD4(wp, 0); rw1 = S2_LD4(wp, 1);
+  }
+  __syncthreads();
+
+  for (int kc = 0; kc < nk; ++kc) {
+    const char* rb = lds2 + (kc & 1) * S2_BUF;                          // this chunk's planes
+    char* sb = lds2 + ((kc & 1) ^ 1) * S2_BUF;                          // the next chunk's
+    const int k2 = min(kc + 2, nk - 1);
+    S2_A_ROW(ap, k2)
+    const float* wp = w_src + k2 * SBK;
+    bf16x8 a_hi[4], w_hi[4], a_mid[4], w_mid[4], t_lo[4];
+#define S2_FRAG_A(plane, f)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(rb + (plane) * S2_APL + a_fo[i]);
+#define S2_FRAG_W(plane, f)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(rb + (plane) * S2_WPL + w_fo[i]);
+#define S2_MMA(fwp, fap)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                 \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
+    // four scheduling groups (the compiler interleaves inside a group, never across the fences): without them it hoists the
+    // three splits to the top of the chunk, where their loads are one third of a chunk old
+    S2_FRAG_A(0, a_hi)
+    S2_FRAG_W(2, t_lo)
+    S2_MMA(t_lo, a_hi)                                // (hi, lo)
+    __builtin_amdgcn_sched_barrier(0);
+    S2_FRAG_W(0, w_hi)
+    S2_FRAG_A(2, t_lo)
+    S2_MMA(w_hi, t_lo)                                // (lo, hi)
+    split8_store(ra0, ra1, sb + ast0, sb + S2_APL + ast0, sb + 2 * S2_APL + ast0);
+    ra0 = S2_LD4(ap, 0);
+    ra1 = S2_LD4(ap, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    S2_FRAG_A(1, a_mid)
+    S2_FRAG_W(1, w_mid)
+    S2_MMA(w_mid, a_mid)                              // (mid, mid)
+    S2_MMA(w_hi, a_mid)                               // (mid, hi)
+    split8_store(ra2, ra3, sb + ast1, sb + S2_APL + ast1, sb + 2 * S2_APL + ast1);
+    ra2 = S2_LD4(ap, 2);
+    ra3 = S2_LD4(ap, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    S2_MMA(w_mid, a_hi)                               // (hi, mid)
+    S2_MMA(w_hi, a_hi)                                // (hi, hi)
+    split8_store(rw0, rw1, sb + wst, sb + S2_WPL + wst, sb + 2 * S2_WPL + wst);
+    rw0 = S2_LD4(wp, 0);
+    rw1 = S2_LD4(wp, 1);
+    __syncthreads();
+  }
+#undef S2_A_ROW
+#undef S2_LD4
+#undef S2_FRAG_A
+#undef S2_FRAG_W
+#undef S2_MMA
+  gemm_epilogue<4, 4>(p, acc, m0, n0, wm * 64, wn * 64, fr, fq);
+}
+
 }  // namespace
 
 bool gemm_split_supported(const GemmParams& p) {
@@ -204,12 +356,37 @@ bool gemm_split_supported(const GemmParams& p) {
          !(p.K & 31) && !(p.lda & 3) && !(p.ldw & 3) && p.alt.M <= 0 && !p.epi_general;
 }
 
-const char* gemm_split_instance_name(const GemmParams&) { return "gemm_split_kernel"; }
+// The 256 x 128 kernel wants the chip full with ONE workgroup per CU: used from 3/4 of a round of 256-row tiles on.
+static int split_variant(const GemmParams& p) {
+  const long t2 = (long)((p.M + S2BM - 1) / S2BM) * ((p.N + S2BN - 1) / S2BN);
+  int v = t2 >= 192 ? 2 : 1;
+#ifdef AVSEP_DEV
+  if (const char* e = getenv("AVSEP_SPLIT_VARIANT")) v = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : v;   // developer A/B
+#endif
+  return v;
+}
+
+const char* gemm_split_instance_name(const GemmParams& p) { return split_variant(p) == 2 ? "gemm_split_kernel2" : "gemm_split_kernel"; }
 
 hipError_t launch_gemm_split(GemmParams p, hipStream_t s) {
   if (!gemm_split_supported(p) || p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
-  const long tiles = (long)((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
   p.nbn_magic = 0;
+  if (split_variant(p) == 2) {
+    // the dynamic-LDS ceiling of the instance is raised once per device (see conv_stack.hip)
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !raised[dev]) {
+      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel2),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S2_BUF);
+      if (attr != hipSuccess) return attr;
+      if (dev >= 0) raised[dev] = true;
+    }
+    const long tiles = (long)((p.M + S2BM - 1) / S2BM) * ((p.N + S2BN - 1) / S2BN);
+    hipLaunchKernelGGL(gemm_split_kernel2, dim3((unsigned)tiles), dim3(512), 2 * S2_BUF, s, p);
+    return hipGetLastError();
+  }
+  const long tiles = (long)((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)tiles), dim3(256), 0, s, p);
   return hipGetLastError();
 }

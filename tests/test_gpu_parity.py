@@ -751,7 +751,10 @@ def test_mask_head_epilogue_bit_identical_to_block_by_block(devlib, dev, M, S, F
 
 @pytest.mark.parametrize("M,N,K,act,res", [(16064, 512, 512, 0, True), (3200, 1536, 512, 1, False), (4016, 512, 2048, 2, True),
                                            (251, 2048, 512, 1, False), (777, 260, 96, 3, True), (129, 516, 544, 0, False),
-                                           (1, 512, 512, 2, True)])
+                                           (1, 512, 512, 2, True),
+                                           # the 256 x 128 kernel (>= 192 tiles of that size): ragged M and N, odd chunk count, one chunk
+                                           (12300, 644, 544, 2, True), (16032, 2048, 512, 1, False), (49200, 132, 32, 0, False),
+                                           (24600, 260, 64, 3, True)])
 def test_op_linear_split_precision(lib, dev, M, N, K, act, res):
     """The split-precision GEMM (csrc/gemm_split.hip; what the forward runs for every nn.Linear of the d_model >= 512
     configurations): fp32 operands cut into three bf16 terms, six bf16 MFMA products, fp32 accumulation.  Against float64 its

@@ -20,24 +20,28 @@ def timeit(fn, n=30):
 
 
 torch.manual_seed(0)
-print("shape (M, N, K)            fp32 MFMA: us  TFLOP/s  err/max|y| | split bf16x3x6: us  TFLOP/s  err/max|y| | speed-up")
+print("shape (M, N, K)            fp32 MFMA: us  TFLOP/s  err/max|y| | split 128x128: us  TFLOP/s  err | split 256x128: us  TFLOP/s  err | speed-ups")
 for M, N, K, act, res in ((16064, 2048, 512, 1, False), (16064, 1536, 512, 0, False), (16064, 512, 512, 0, True), (16064, 512, 2048, 0, True),
-                          (4016, 2048, 512, 0, False), (3200, 1536, 512, 0, False), (2016, 768, 256, 0, False), (777, 260, 96, 2, True)):
+                          (16032, 2048, 512, 1, False), (16032, 512, 2048, 0, True), (8192, 1024, 1024, 0, False),
+                          (4016, 2048, 512, 0, False), (4016, 1536, 512, 0, False), (4016, 512, 512, 0, True), (4016, 512, 2048, 0, True),
+                          (3200, 2048, 512, 1, False), (3200, 1536, 512, 0, False), (3200, 512, 512, 0, True), (3200, 512, 2048, 0, True), (2048, 512, 512, 0, False), (2016, 768, 256, 0, False), (777, 260, 96, 2, True)):
     x = (torch.randn(M, K, device=dev) * 2 + 0.7); w = torch.randn(N, K, device=dev) * 0.06; b = torch.randn(N, device=dev)
     r = torch.randn(M, N, device=dev) if res else None
-    y0 = torch.empty(M, N, device=dev); y1 = torch.empty(M, N, device=dev)
     ref = x.double() @ w.double().t() + b.double()
     ref = {0: ref, 1: torch.relu(ref), 2: torch.nn.functional.gelu(ref)}[act]
     if res: ref = ref + r.double()
-    call = lambda y: lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), M, N, K, act, st)
-    os.environ.pop("AVSEP_GEMM_SPLIT", None)
-    assert call(y0) == 0
-    t0 = timeit(lambda: call(y0))
-    os.environ["AVSEP_GEMM_SPLIT"] = "1"
-    assert call(y1) == 0
-    t1 = timeit(lambda: call(y1))
-    os.environ.pop("AVSEP_GEMM_SPLIT", None)
     sc = float(ref.abs().max())
-    e0 = float((y0.double() - ref).abs().max()) / sc; e1 = float((y1.double() - ref).abs().max()) / sc
     fl = 2.0 * M * N * K
-    print(f"({M:6d},{N:5d},{K:5d}) act {act} res {int(res)}   {t0 * 1e6:8.1f} {fl / t0 / 1e12:7.1f}  {e0:.2e} |      {t1 * 1e6:8.1f} {fl / t1 / 1e12:7.1f}  {e1:.2e} | x{t0 / t1:.2f}")
+    out = []
+    for variant in (None, "1", "2"):
+        y = torch.empty(M, N, device=dev)
+        call = lambda: lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), M, N, K, act, st)
+        os.environ.pop("AVSEP_GEMM_SPLIT", None); os.environ.pop("AVSEP_SPLIT_VARIANT", None)
+        if variant:
+            os.environ["AVSEP_GEMM_SPLIT"] = "1"; os.environ["AVSEP_SPLIT_VARIANT"] = variant
+        assert call() == 0
+        t = timeit(call)
+        out.append((t, float((y.double() - ref).abs().max()) / sc))
+    os.environ.pop("AVSEP_GEMM_SPLIT", None); os.environ.pop("AVSEP_SPLIT_VARIANT", None)
+    cells = " | ".join(f"{t * 1e6:8.1f} {fl / t / 1e12:7.1f}  {e:.2e}" for t, e in out)
+    print(f"({M:6d},{N:5d},{K:5d}) act {act} res {int(res)}  {cells} | x{out[0][0] / out[1][0]:.2f} x{out[0][0] / out[2][0]:.2f}", flush=True)
