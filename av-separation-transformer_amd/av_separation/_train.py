@@ -64,11 +64,22 @@ def _scratch(M, Cc, like):
     return torch.empty(max(n, 1), device=like.device, dtype=torch.float32)
 
 
+# Split-precision GEMM (csrc/gemm_split.hip) for every Linear forward / activation-gradient GEMM whose weight has N >= 512 and
+# K >= 512 -- the rule of the inference forward; fp32-equivalent results (the gradient gates of tests/test_train_gpu.py hold
+# with it).  A module attribute, not an environment variable: tests and tools A/B it by setting ``_train.SPLIT_GEMM``.
+SPLIT_GEMM = True
+
+
 def _gemm(x, w, bias, res, rperiod, act, drop_p=0.0, drop_seed=0):
     """res rows + dropout(act(x [M,K] @ w[N,K]^T + bias)); K % 32 == 0; the dropout (train mode) runs in the GEMM epilogue."""
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    if SPLIT_GEMM and N >= 512 and K >= 512 and N % 4 == 0:
+        _ck(_lib().avsep_op_linear_split_ex(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                            res.data_ptr() if res is not None else None, N, rperiod, y.data_ptr(), N, M, N, K,
+                                            act, drop_p, drop_seed, _st(x)), "avsep_op_linear_split_ex")
+        return y
     if drop_p > 0:
         _ck(_lib().avsep_op_linear_drop(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                                         res.data_ptr() if res is not None else None, N, rperiod, y.data_ptr(), M, N, K,

@@ -25,27 +25,25 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// three bf16 planes of 4 fp32 values: plane p of elements (e0,e1) and (e2,e3) as two dwords each (low half = the even element)
+// three bf16 planes of 4 fp32 values: plane p of elements (e0,e1) and (e2,e3) as two dwords each (low half = the even element).
+// Two elements at a time: the exact subtractions are v_pk_add_f32 (one issue for both), 4.5 VALU per element instead of 5.5.
+// (Bit casts of WHOLE vectors only: hipcc 7.2 reads element 0 for every e when __builtin_bit_cast is applied to an ext-vector
+// element expression v[e] -- found by the one-hot probes of tools/gemm_split_debug.py.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const f32x4 v, unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
-  unsigned h[4], m[4], l[4];
-  // (scalar copies and __float_as_uint: hipcc 7.2 reads ELEMENT 0 for every e when __builtin_bit_cast is applied to the
-  // ext-vector element expression v[e] directly -- found by the one-hot probes of tools/gemm_split_debug.py)
-  const float xs[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = xs[e];
-    const unsigned u = __float_as_uint(x);
-    h[e] = u;                                                         // upper 16 bits are taken by the pack below
-    const float r1 = x - __uint_as_float(u & 0xFFFF0000u);            // exact
-    m[e] = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(m[e] & 0xFFFF0000u);        // exact
-    l[e] = __float_as_uint(r2);
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {                                       // bytes [3,2] of the odd element | bytes [3,2] of the even one
-    hi[q] = __builtin_amdgcn_perm(h[2 * q + 1], h[2 * q], 0x07060302u);
-    mid[q] = __builtin_amdgcn_perm(m[2 * q + 1], m[2 * q], 0x07060302u);
-    lo[q] = __builtin_amdgcn_perm(l[2 * q + 1], l[2 * q], 0x07060302u);
+  for (int q = 0; q < 2; ++q) {
+    const f32x2 x = q ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+    const u32x2 u = __builtin_bit_cast(u32x2, x);                       // upper 16 bits are taken by the pack below
+    const f32x2 r1 = x - __builtin_bit_cast(f32x2, u & 0xFFFF0000u);    // exact
+    const u32x2 m = __builtin_bit_cast(u32x2, r1);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, m & 0xFFFF0000u);   // exact
+    const u32x2 l = __builtin_bit_cast(u32x2, r2);
+    // bytes [3,2] of the odd element | bytes [3,2] of the even one
+    hi[q] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+    mid[q] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+    lo[q] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
   }
 }
 
@@ -219,44 +217,76 @@ __device__ __forceinline__ void split8_store(const f32x4 v0, const f32x4 v1, cha
   *reinterpret_cast<u32x4*>(lo_p) = u32x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
+// per-thread operand rows of one 256 x 128 tile
+struct S2Tile {
+  const float *a, *a_prev, *a_next, *w;
+};
+
+template <bool TAPS>
+__device__ __forceinline__ S2Tile s2_tile_rows(const GemmParams& p, int tile, int nbn, int srow, int shalf, int wrow, int wq) {
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int am = min(bm * S2BM + srow, p.M - 1), wnr = min(bn * S2BN + wrow, p.N - 1);
+  S2Tile t;
+  t.a = p.A + (size_t)am * p.lda + 16 * shalf;
+  t.a_prev = t.a_next = t.a;
+  if (TAPS) {
+    const int ts = am % p.T;
+    const float* zrow = p.zeros + 16 * shalf;
+    t.a_prev = ts > 0 ? t.a - p.lda : zrow;
+    t.a_next = ts + 1 < p.T ? t.a + p.lda : zrow;
+  }
+  t.w = p.W + (size_t)wnr * p.ldw + 8 * wq;
+  return t;
+}
+
+// Persistent over tiles: with ONE workgroup per CU nothing covers a tile's first loads (~2 us) and its epilogue -- measured as
+// 3.3 chunk times per tile, 17 % of a K = 512 tile (K = 512 against K = 2048 at equal flops, profiles/r04_gemm_split_probe_256x128.txt).
+// A workgroup therefore walks its tiles in one flat chunk sequence: the last two chunks of a tile load, split and store the
+// first two of the NEXT tile, so only the epilogue itself stands between two tiles' MFMAs.  Tiles are dealt so that an XCD's
+// workgroups share a contiguous tile range (xcd_tile's rule; blockIdx % 8 = XCD).
+template <bool TAPS>
 __global__ __launch_bounds__(512, 1) void gemm_split_kernel2(const GemmParams pin) {
   GemmParams p = pin;
   extern __shared__ __attribute__((aligned(16))) char lds2[];           // 2 x S2_BUF
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nbn = (p.N + S2BN - 1) / S2BN;
-  int tile = xcd_tile(p);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int m0 = bm * S2BM, n0 = bn * S2BN;
+  const int ntiles = ((p.M + S2BM - 1) / S2BM) * nbn;
+  int tile, tile_end, tile_step;
+  {
+    const int G = gridDim.x, b = blockIdx.x;
+    if (p.no_xcd_remap) {
+      tile = b; tile_end = ntiles; tile_step = G;
+    } else {
+      const int xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
+      const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      tile = start + (b >> 3);
+      tile_end = start + q + (xcd < r ? 1 : 0);
+      tile_step = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    }
+  }
+  if (tile >= tile_end) return;                                          // block-uniform (never with grid <= tiles)
 
   // A staging as in gemm_split_kernel (thread -> row, 16-float half; bits 1 and 2 of the row swapped); W staging: thread ->
   // (row = tid / 4, 8-float quarter): 8 consecutive lanes write two whole 64-byte rows = every bank once
   const int su = tid >> 1, shalf = tid & 1;
   const int srow = (su & ~6) | ((su & 2) << 1) | ((su & 4) >> 1);
   const int wrow = tid >> 2, wq = tid & 3;
-  const int am = min(m0 + srow, p.M - 1), wnr = min(n0 + wrow, p.N - 1);
-  const float* a_src = p.A + (size_t)am * p.lda + 16 * shalf;
-  const bool taps = p.amode == AMODE_TAPS3;
-  const float *a_prev = a_src, *a_next = a_src;
-  if (taps) {
-    const int t = am % p.T;
-    const float* zrow = p.zeros + 16 * shalf;
-    a_prev = t > 0 ? a_src - p.lda : zrow;
-    a_next = t + 1 < p.T ? a_src + p.lda : zrow;
-  }
-  const int cpt = taps ? p.Kt / SBK : 1 << 30;
-  const float* w_src = p.W + (size_t)wnr * p.ldw + 8 * wq;
+  const int cpt = TAPS ? p.Kt / SBK : 1 << 30;
   const int sw = (0 - (srow >> 2)) & 3;
   const int ast0 = srow * 64 + (((2 * shalf) ^ sw) << 4), ast1 = srow * 64 + (((2 * shalf + 1) ^ sw) << 4);
   const int wst = 3 * S2_APL + wrow * 64 + ((wq ^ ((0 - (wrow >> 2)) & 3)) << 4);
 
-  const int nk = p.K / SBK;
+  const int nk = p.K / SBK;                                             // >= 2 (launch_gemm_split)
   f32x4 ra0, ra1, ra2, ra3, rw0, rw1;
-#define S2_A_ROW(ptr, kc)                                                                   \
-  const float* ptr;                                                                         \
-  {                                                                                         \
-    const int tap_ = (kc) / cpt, sub_ = (kc) - tap_ * cpt; /* uniform; tap 0, sub kc when PLAIN */ \
-    ptr = (taps ? (tap_ == 0 ? a_prev : tap_ == 1 ? a_src : a_next) : a_src) + sub_ * SBK;  \
+  // chunk kc of tile rows T: A pointer (TAPS3: block-uniform tap per chunk)
+#define S2_A_ROW(ptr, T, kc)                                                                       \
+  const float* ptr;                                                                                \
+  if (TAPS) {                                                                                      \
+    const int tap_ = (kc) / cpt, sub_ = (kc) - tap_ * cpt;                                         \
+    ptr = (tap_ == 0 ? T.a_prev : tap_ == 1 ? T.a : T.a_next) + sub_ * SBK;                        \
+  } else {                                                                                         \
+    ptr = T.a + (kc) * SBK;                                                                        \
   }
 #define S2_LD4(ptr, j) (*reinterpret_cast<const f32x4*>((ptr) + 4 * (j)))
 
@@ -270,38 +300,23 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel2(const GemmParams pi
     w_fo[i] = 3 * S2_APL + c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
   }
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // prologue: chunk 0 into buffer 0, chunk 1 into the registers
+  S2Tile cur = s2_tile_rows<TAPS>(p, tile, nbn, srow, shalf, wrow, wq);
+  // prologue (first tile only): chunk 0 into buffer 0, chunk 1 into the registers
   {
-    S2_A_ROW(ap, 0)
-    const float* wp = w_src;
+    S2_A_ROW(ap, cur, 0)
     ra0 = S2_LD4(ap, 0); ra1 = S2_LD4(ap, 1); ra2 = S2_LD4(ap, 2); ra3 = S2_LD4(ap, 3);
-    rw0 = S2_LD4(wp, 0); rw1 = S2_LD4(wp, 1);
+    rw0 = S2_LD4(cur.w, 0); rw1 = S2_LD4(cur.w, 1);
   }
   split8_store(ra0, ra1, lds2 + ast0, lds2 + S2_APL + ast0, lds2 + 2 * S2_APL + ast0);
   split8_store(ra2, ra3, lds2 + ast1, lds2 + S2_APL + ast1, lds2 + 2 * S2_APL + ast1);
   split8_store(rw0, rw1, lds2 + wst, lds2 + S2_WPL + wst, lds2 + 2 * S2_WPL + wst);
   {
-    const int k1 = min(1, nk - 1);
-    S2_A_ROW(ap, k1)
-    const float* wp = w_src + k1 * SBK;
+    S2_A_ROW(ap, cur, 1)
     ra0 = S2_LD4(ap, 0); ra1 = S2_LD4(ap, 1); ra2 = S2_LD4(ap, 2); ra3 = S2_LD4(ap, 3);
-    rw0 = S2_LD4(wp, 0); rw1 = S2_LD4(wp, 1);
+    rw0 = S2_LD4(cur.w + SBK, 0); rw1 = S2_LD4(cur.w + SBK, 1);
   }
   __syncthreads();
 
-  for (int kc = 0; kc < nk; ++kc) {
-    const char* rb = lds2 + (kc & 1) * S2_BUF;                          // this chunk's planes
-    char* sb = lds2 + ((kc & 1) ^ 1) * S2_BUF;                          // the next chunk's
-    const int k2 = min(kc + 2, nk - 1);
-    S2_A_ROW(ap, k2)
-    const float* wp = w_src + k2 * SBK;
-    bf16x8 a_hi[4], w_hi[4], a_mid[4], w_mid[4], t_lo[4];
 #define S2_FRAG_A(plane, f)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(rb + (plane) * S2_APL + a_fo[i]);
 #define S2_FRAG_W(plane, f)                                                                                   \
@@ -309,40 +324,172 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel2(const GemmParams pi
 #define S2_MMA(fwp, fap)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                 \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
-    // four scheduling groups (the compiler interleaves inside a group, never across the fences): without them it hoists the
-    // three splits to the top of the chunk, where their loads are one third of a chunk old
-    S2_FRAG_A(0, a_hi)
-    S2_FRAG_W(2, t_lo)
-    S2_MMA(t_lo, a_hi)                                // (hi, lo)
-    __builtin_amdgcn_sched_barrier(0);
-    S2_FRAG_W(0, w_hi)
-    S2_FRAG_A(2, t_lo)
-    S2_MMA(w_hi, t_lo)                                // (lo, hi)
-    split8_store(ra0, ra1, sb + ast0, sb + S2_APL + ast0, sb + 2 * S2_APL + ast0);
-    ra0 = S2_LD4(ap, 0);
-    ra1 = S2_LD4(ap, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    S2_FRAG_A(1, a_mid)
-    S2_FRAG_W(1, w_mid)
-    S2_MMA(w_mid, a_mid)                              // (mid, mid)
-    S2_MMA(w_hi, a_mid)                               // (mid, hi)
-    split8_store(ra2, ra3, sb + ast1, sb + S2_APL + ast1, sb + 2 * S2_APL + ast1);
-    ra2 = S2_LD4(ap, 2);
-    ra3 = S2_LD4(ap, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    S2_MMA(w_mid, a_hi)                               // (hi, mid)
-    S2_MMA(w_hi, a_hi)                                // (hi, hi)
-    split8_store(rw0, rw1, sb + wst, sb + S2_WPL + wst, sb + 2 * S2_WPL + wst);
-    rw0 = S2_LD4(wp, 0);
-    rw1 = S2_LD4(wp, 1);
-    __syncthreads();
+  // One chunk: the six products over buffer `par`; the registers (the chunk after it) are split into the other buffer and
+  // reloaded from ap / wp (two chunks ahead).  Four scheduling groups (the compiler interleaves inside a group, never across
+  // the fences): without them it hoists the three splits to the top of the chunk, where their loads are a third of a chunk old.
+#define S2_CHUNK(ap, wp)                                                                     \
+  {                                                                                          \
+    const char* rb = lds2 + par * S2_BUF;                                                    \
+    char* sb = lds2 + (par ^ 1) * S2_BUF;                                                    \
+    par ^= 1;                                                                                \
+    bf16x8 a_hi[4], w_hi[4], a_mid[4], w_mid[4], t_lo[4];                                    \
+    S2_FRAG_A(0, a_hi)                                                                       \
+    S2_FRAG_W(2, t_lo)                                                                       \
+    S2_MMA(t_lo, a_hi) /* (hi, lo) */                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    S2_FRAG_W(0, w_hi)                                                                       \
+    S2_FRAG_A(2, t_lo)                                                                       \
+    S2_MMA(w_hi, t_lo) /* (lo, hi) */                                                        \
+    split8_store(ra0, ra1, sb + ast0, sb + S2_APL + ast0, sb + 2 * S2_APL + ast0);           \
+    ra0 = S2_LD4(ap, 0);                                                                     \
+    ra1 = S2_LD4(ap, 1);                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    S2_FRAG_A(1, a_mid)                                                                      \
+    S2_FRAG_W(1, w_mid)                                                                      \
+    S2_MMA(w_mid, a_mid) /* (mid, mid) */                                                    \
+    S2_MMA(w_hi, a_mid)  /* (mid, hi) */                                                     \
+    split8_store(ra2, ra3, sb + ast1, sb + S2_APL + ast1, sb + 2 * S2_APL + ast1);           \
+    ra2 = S2_LD4(ap, 2);                                                                     \
+    ra3 = S2_LD4(ap, 3);                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    S2_MMA(w_mid, a_hi) /* (hi, mid) */                                                      \
+    S2_MMA(w_hi, a_hi)  /* (hi, hi) */                                                       \
+    split8_store(rw0, rw1, sb + wst, sb + S2_WPL + wst, sb + 2 * S2_WPL + wst);              \
+    rw0 = S2_LD4(wp, 0);                                                                     \
+    rw1 = S2_LD4(wp, 1);                                                                     \
+    __syncthreads();                                                                         \
   }
+
+  int par = 0;                                                          // buffer of the chunk being multiplied
+  for (;;) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 2; kc < nk; ++kc) {                                   // chunks 0 .. nk - 3 load chunks 2 .. nk - 1 of this tile
+      S2_A_ROW(ap, cur, kc)
+      const float* wp = cur.w + kc * SBK;
+      S2_CHUNK(ap, wp)
+    }
+    // the last two chunks load (and the very last splits) the first two of the next tile; without one they re-read this
+    // tile's and split them into the buffer nobody reads.  Only one tile's row pointers are live at any time.
+    const int tile_next = tile + tile_step;
+    const bool more = tile_next < tile_end;
+    cur = s2_tile_rows<TAPS>(p, more ? tile_next : tile, nbn, srow, shalf, wrow, wq);
+    for (int kc = 0; kc < 2; ++kc) {
+      S2_A_ROW(ap, cur, kc)
+      const float* wp = cur.w + kc * SBK;
+      S2_CHUNK(ap, wp)
+    }
+    {
+      const int bm = tile / nbn, bn = tile - bm * nbn;
+      gemm_epilogue<4, 4>(p, acc, bm * S2BM, bn * S2BN, wm * 64, wn * 64, fr, fq);
+    }
+    if (!more) break;
+    tile = tile_next;
+  }
+#undef S2_CHUNK
 #undef S2_A_ROW
 #undef S2_LD4
 #undef S2_FRAG_A
 #undef S2_FRAG_W
 #undef S2_MMA
-  gemm_epilogue<4, 4>(p, acc, m0, n0, wm * 64, wn * 64, fr, fq);
+}
+
+
+// ---- the 64 x 64 tile (small problems) ----------------------------------------------------------------------------------------
+// The same phase-free chunk as gemm_split_kernel2 for problems that give the 256 x 128 kernel less than half a round of tiles
+// (the visual branch: M = 3200 rows; small batches): 256 threads = 2 x 2 waves of 32 x 32, 24 MFMAs per wave and chunk,
+// 2 x 24 KB of LDS, three workgroups per CU (they cover each other's first loads and epilogues: one tile per workgroup).
+// Per element the same six products in the same order as the two kernels above: a row has the same bits in all three.
+constexpr int S3B = 64;
+constexpr int S3_PL = S3B * SBK * 2;                                    // bytes of one plane (4 KB)
+constexpr int S3_BUF = 6 * S3_PL;                                       // [A hi|mid|lo][W hi|mid|lo]
+
+__global__ __launch_bounds__(256, 3) void gemm_split_kernel3(const GemmParams pin) {
+  GemmParams p = pin;
+  __shared__ __attribute__((aligned(16))) char lds3[2 * S3_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + S3B - 1) / S3B;
+  const int tile = xcd_tile(p);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * S3B, n0 = bn * S3B;
+
+  // staging: thread -> (row = tid / 4, 8-float quarter) of both operands: 8 consecutive lanes write two whole 64-byte rows
+  const int srow = tid >> 2, sq = tid & 3;
+  const float* a_src = p.A + (size_t)min(m0 + srow, p.M - 1) * p.lda + 8 * sq;
+  const float* w_src = p.W + (size_t)min(n0 + srow, p.N - 1) * p.ldw + 8 * sq;
+  const int ast = srow * 64 + ((sq ^ ((0 - (srow >> 2)) & 3)) << 4), wst = 3 * S3_PL + ast;
+  const int nk = p.K / SBK;
+  f32x4 ra0, ra1, rw0, rw1;
+#define S3_LD4(ptr, j) (*reinterpret_cast<const f32x4*>((ptr) + 4 * (j)))
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_fo[2], w_fo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 32 + 16 * i + fr;
+    a_fo[i] = r * 64 + ((fq ^ ((0 - (r >> 2)) & 3)) << 4);
+    const int c = wn * 32 + 16 * i + fr;
+    w_fo[i] = 3 * S3_PL + c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  ra0 = S3_LD4(a_src, 0); ra1 = S3_LD4(a_src, 1);
+  rw0 = S3_LD4(w_src, 0); rw1 = S3_LD4(w_src, 1);
+  split8_store(ra0, ra1, lds3 + ast, lds3 + S3_PL + ast, lds3 + 2 * S3_PL + ast);
+  split8_store(rw0, rw1, lds3 + wst, lds3 + S3_PL + wst, lds3 + 2 * S3_PL + wst);
+  {
+    const int k1 = min(1, nk - 1);
+    ra0 = S3_LD4(a_src + k1 * SBK, 0); ra1 = S3_LD4(a_src + k1 * SBK, 1);
+    rw0 = S3_LD4(w_src + k1 * SBK, 0); rw1 = S3_LD4(w_src + k1 * SBK, 1);
+  }
+  __syncthreads();
+
+#define S3_FRAG(plane, off, f) \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) f[i] = *reinterpret_cast<const bf16x8*>(rb + (plane) * S3_PL + off[i]);
+#define S3_MMA(fwp, fap)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
+  for (int kc = 0; kc < nk; ++kc) {
+    const char* rb = lds3 + (kc & 1) * S3_BUF;
+    char* sb = lds3 + ((kc & 1) ^ 1) * S3_BUF;
+    const int k2 = min(kc + 2, nk - 1);                                 // the last chunks split / reload clamped data nobody reads
+    const float* ap = a_src + k2 * SBK;
+    const float* wp = w_src + k2 * SBK;
+    bf16x8 a_hi[2], w_hi[2], a_mid[2], w_mid[2], t_lo[2];
+    S3_FRAG(0, a_fo, a_hi)
+    S3_FRAG(2, w_fo, t_lo)
+    S3_MMA(t_lo, a_hi)                                // (hi, lo)
+    S3_FRAG(0, w_fo, w_hi)
+    S3_FRAG(2, a_fo, t_lo)
+    S3_MMA(w_hi, t_lo)                                // (lo, hi)
+    __builtin_amdgcn_sched_barrier(0);
+    S3_FRAG(1, a_fo, a_mid)
+    S3_FRAG(1, w_fo, w_mid)
+    S3_MMA(w_mid, a_mid)                              // (mid, mid)
+    S3_MMA(w_hi, a_mid)                               // (mid, hi)
+    split8_store(ra0, ra1, sb + ast, sb + S3_PL + ast, sb + 2 * S3_PL + ast);
+    ra0 = S3_LD4(ap, 0);
+    ra1 = S3_LD4(ap, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    S3_MMA(w_mid, a_hi)                               // (hi, mid)
+    S3_MMA(w_hi, a_hi)                                // (hi, hi)
+    split8_store(rw0, rw1, sb + wst, sb + S3_PL + wst, sb + 2 * S3_PL + wst);
+    rw0 = S3_LD4(wp, 0);
+    rw1 = S3_LD4(wp, 1);
+    __syncthreads();
+  }
+#undef S3_LD4
+#undef S3_FRAG
+#undef S3_MMA
+  gemm_epilogue<2, 2>(p, acc, m0, n0, wm * 32, wn * 32, fr, fq);
 }
 
 }  // namespace
@@ -352,38 +499,67 @@ bool gemm_split_supported(const GemmParams& p) {
   // epilogues: the straight-line bias / activation / residual one (N % 4 == 0), or the mask head's (two outputs, N even)
   const bool fast = !p.C2 && !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
   const bool mask = p.C2 && p.X && !(p.N & 1) && !(p.ldc & 1) && !p.R;
-  return a_ok && !p.lnx_c1 && !p.ln_gamma && !p.ln_stats && p.ksplit <= 1 && p.mag_F == 0 && p.drop_p <= 0.0f && (fast || mask) &&
+  return a_ok && !p.lnx_c1 && !p.ln_gamma && !p.ln_stats && p.ksplit <= 1 && p.mag_F == 0 && (fast || mask) &&
+         (p.drop_p <= 0.0f || (fast && p.drop_p < 1.0f && p.ldc == p.N)) &&      // training: dropout in the straight-line epilogue
          !(p.K & 31) && !(p.lda & 3) && !(p.ldw & 3) && p.alt.M <= 0 && !p.epi_general;
 }
 
-// The 256 x 128 kernel wants the chip full with ONE workgroup per CU: used from 3/4 of a round of 256-row tiles on.
+// Which kernel.  The 256 x 128 one is the efficient one per flop (190-210 TFLOP/s against 135-150 of the 64 x 64 one and 160-185 of
+// the 128 x 128 one); the 64 x 64 one fills the chip from small problems on (M = 3200, N = 512, K = 2048 alone: 65 us against 137).
+// With several forwards in flight the chip is full anyway and the per-flop figure decides: the visual branch's M = 3200 GEMMs
+// (52 tiles of 256 x 128) are 1.3 % of the cfg3 step faster on the big tile (profiles/r04_ab_split_gemm_64x64.txt).  So: the
+// 256 x 128 kernel from 48 of its tiles on (and two chunks or more), below that -- small batches, where latency is the point --
+// the 64 x 64 one (plain A operand) or the 128 x 128 one (3-tap A operand).  All three compute the same bits.
 static int split_variant(const GemmParams& p) {
   const long t2 = (long)((p.M + S2BM - 1) / S2BM) * ((p.N + S2BN - 1) / S2BN);
-  int v = t2 >= 192 ? 2 : 1;
+  int v = t2 >= 48 ? 2 : 3;
 #ifdef AVSEP_DEV
-  if (const char* e = getenv("AVSEP_SPLIT_VARIANT")) v = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : v;   // developer A/B
+  if (const char* e = getenv("AVSEP_SPLIT_VARIANT")) v = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : v;   // developer A/B
 #endif
+  if (v == 2 && p.K < 2 * SBK) v = 3;
+  if (v == 3 && p.amode != AMODE_PLAIN) v = 1;
   return v;
 }
 
-const char* gemm_split_instance_name(const GemmParams& p) { return split_variant(p) == 2 ? "gemm_split_kernel2" : "gemm_split_kernel"; }
+const char* gemm_split_instance_name(const GemmParams& p) {
+  const int v = split_variant(p);
+  return v == 2 ? (p.amode == AMODE_TAPS3 ? "gemm_split_kernel2<true>" : "gemm_split_kernel2<false>") : v == 3 ? "gemm_split_kernel3" : "gemm_split_kernel";
+}
+
+template <bool TAPS>
+static hipError_t launch_split2(const GemmParams& p, hipStream_t s) {
+  auto kern = gemm_split_kernel2<TAPS>;
+  // the dynamic-LDS ceiling of the instance is raised once per device (see conv_stack.hip); the CU count is read with it
+  static bool raised[64] = {};
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!raised[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S2_BUF);
+    if (attr != hipSuccess) return attr;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return hipErrorInvalidDevice;
+    cus[dev] = n;
+    raised[dev] = true;
+  }
+  const long tiles = (long)((p.M + S2BM - 1) / S2BM) * ((p.N + S2BN - 1) / S2BN);
+  long grid = tiles < cus[dev] ? tiles : cus[dev];                       // one resident workgroup per CU walks tiles / grid tiles
+#ifdef AVSEP_DEV
+  // developer A/B: 0 = one tile each; otherwise >= 8 workgroups (every XCD's tile range needs one)
+  if (const char* e = getenv("AVSEP_SPLIT_GRID")) grid = atol(e) >= 8 && atol(e) < tiles ? atol(e) : tiles;
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * S2_BUF, s, p);
+  return hipGetLastError();
+}
 
 hipError_t launch_gemm_split(GemmParams p, hipStream_t s) {
   if (!gemm_split_supported(p) || p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
   p.nbn_magic = 0;
-  if (split_variant(p) == 2) {
-    // the dynamic-LDS ceiling of the instance is raised once per device (see conv_stack.hip)
-    static bool raised[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-    if (dev < 0 || !raised[dev]) {
-      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel2),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S2_BUF);
-      if (attr != hipSuccess) return attr;
-      if (dev >= 0) raised[dev] = true;
-    }
-    const long tiles = (long)((p.M + S2BM - 1) / S2BM) * ((p.N + S2BN - 1) / S2BN);
-    hipLaunchKernelGGL(gemm_split_kernel2, dim3((unsigned)tiles), dim3(512), 2 * S2_BUF, s, p);
+  const int v = split_variant(p);
+  if (v == 2) return p.amode == AMODE_TAPS3 ? launch_split2<true>(p, s) : launch_split2<false>(p, s);
+  if (v == 3) {
+    const long tiles = (long)((p.M + S3B - 1) / S3B) * ((p.N + S3B - 1) / S3B);
+    hipLaunchKernelGGL(gemm_split_kernel3, dim3((unsigned)tiles), dim3(256), 0, s, p);
     return hipGetLastError();
   }
   const long tiles = (long)((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);

@@ -64,6 +64,30 @@ int avsep_op_linear_drop(const float* x, int lda, const float* w, int ldw, const
   return AVSEP_OK;
 }
 
+// The split-precision form of the two ops above (gemm_split.hip: fp32 operands cut into three bf16 terms, six bf16 MFMA products,
+// fp32 accumulation -- fp32-equivalent results, see include/avsep.h): what the training step runs for every Linear forward and
+// activation-gradient GEMM whose weight has N >= 512 and K >= 512 (av_separation/_train.py::_gemm).  drop_p = 0: no dropout.
+int avsep_op_linear_split_ex(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
+                             int ldr, int rperiod, float* y, int ldc, int M, int N, int K, int act, float drop_p,
+                             uint64_t drop_seed, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || (lda & 3) || (ldw & 3)) return fail(AVSEP_EINVAL, "K must be a multiple of 32 and rows 16-byte aligned");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  if (drop_p < 0.0f || drop_p >= 1.0f) return fail(AVSEP_EINVAL, "dropout probability must be in [0, 1)");
+  if (drop_p > 0.0f && ldc != N) return fail(AVSEP_EINVAL, "dropout needs a dense output (ldc == N)");
+  GemmParams p{};
+  p.A = x; p.W = w; p.bias = bias; p.C = y;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+  p.amode = AMODE_PLAIN;
+  p.act = act;
+  p.R = residual; p.ldr = ldr; p.rperiod = rperiod;
+  if (drop_p > 0.0f) { p.drop_p = drop_p; p.drop_seed = dropout_mix_seed(drop_seed); }
+  if (!gemm_split_supported(p)) return fail(AVSEP_EINVAL, "shape not supported by the split-precision GEMM (N, ldc, ldr multiples of 4)");
+  TCK(launch_gemm_split(p, S(stream)));
+  return AVSEP_OK;
+}
+
 // ---- weight gradient dW[N][K] = dYt[N][R] . Xt[K][R]^T with the (long) row index R as the contraction.  Few output
 // tiles and R in the thousands to hundreds of thousands (conv layers: N*K = 32x32, R = 307200) would leave the chip
 // idle, so the contraction is cut into slices (gridDim.y) whose partial products are summed in a fixed order.

@@ -331,6 +331,8 @@ def main():
                          "encoder layers of each branch as one dependency-driven persistent launch")
     ap.add_argument("--chain-group", type=int, default=8, help="schedule 1: clips per group of the work-list order")
     ap.add_argument("--chain-skew", type=float, default=0.0, help="schedule 1: ops between consecutive clip groups (0 = op-major)")
+    ap.add_argument("--train-fp32-gemm", action="store_true",
+                    help="train mode, developer A/B: the fp32 MFMA GEMM for every Linear (default: split-precision GEMM for N, K >= 512)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` block (short cfg3 / cfg5 forward and cfg4 training lines behind the default cfg2 run; "
                          "--no-cpu and --no-profile, the developer tools' flags, skip it too)")
@@ -737,8 +739,10 @@ def train_main(a, av, dev, dist, rank, world):
     """--mode train: a step = zero_grad, train-mode forward (dropout, BatchNorm batch statistics), PIT loss, backward,
     gradient all-reduce (N>1), clip_grad_norm_(1.0), Adam -- the reference's quick_train loop body (demo.py:96-106)
     on one resident batch per rank.  Not the headline metric; reported for the N1 row."""
-    from av_separation import parallel
+    from av_separation import parallel, _train
     from av_separation.losses import SeparationLoss
+    if a.train_fp32_gemm:
+        _train.SPLIT_GEMM = False
     wl = WORKLOADS[a.workload]
     B = a.batch or wl["batch"]
     mk, dk = wl["model"], wl["data"]

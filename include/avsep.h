@@ -346,6 +346,14 @@ int avsep_op_layernorm_bwd_res(const float* dy, const float* x, const float* gam
 int avsep_op_linear_drop(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
                          int ldr, int rperiod, float* y, int M, int N, int K, int act, float drop_p, uint64_t drop_seed,
                          void* stream);
+/* avsep_op_linear_ex / avsep_op_linear_drop (drop_p = 0: no dropout) on the split-precision GEMM of avsep_op_linear_split:
+ * y = residual + dropout(act(x w^T + b)), same keep-mask as avsep_op_linear_drop, values equal to the fp32-MFMA ops' within
+ * the fp32 GEMM's own rounding (tests/test_train_gpu.py).  The training step (av_separation/_train.py) runs every Linear
+ * forward and activation-gradient GEMM whose weight has N >= 512 and K >= 512 through it -- the rule of the inference forward
+ * (nn.Linear, /root/reference/src/av_separation/model.py:38-60).  N, ldc and ldr multiples of 4; dropout needs ldc == N. */
+int avsep_op_linear_split_ex(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
+                             int ldr, int rperiod, float* y, int ldc, int M, int N, int K, int act, float drop_p,
+                             uint64_t drop_seed, void* stream);
 /* backward of y = dropout(relu(z)) from y alone: dx = y > 0 ? dy / (1 - p) : 0 */
 int avsep_op_relu_dropout_bwd(const float* dy, const float* y, float* dx, int64_t n, float p, void* stream);
 

@@ -20,11 +20,11 @@ def timeit(fn, n=30):
 
 
 torch.manual_seed(0)
-print("shape (M, N, K)            fp32 MFMA: us  TFLOP/s  err/max|y| | split 128x128: us  TFLOP/s  err | split 256x128: us  TFLOP/s  err | speed-ups")
+print("shape (M, N, K)            fp32 MFMA: us  TFLOP/s  err/max|y| | split 128x128: us  TFLOP/s  err | split 256x128: us  TFLOP/s  err | split 64x64: us  TFLOP/s  err | speed-ups")
 for M, N, K, act, res in ((16064, 2048, 512, 1, False), (16064, 1536, 512, 0, False), (16064, 512, 512, 0, True), (16064, 512, 2048, 0, True),
                           (16032, 2048, 512, 1, False), (16032, 512, 2048, 0, True), (8192, 1024, 1024, 0, False),
                           (4016, 2048, 512, 0, False), (4016, 1536, 512, 0, False), (4016, 512, 512, 0, True), (4016, 512, 2048, 0, True),
-                          (3200, 2048, 512, 1, False), (3200, 1536, 512, 0, False), (3200, 512, 512, 0, True), (3200, 512, 2048, 0, True), (2048, 512, 512, 0, False), (2016, 768, 256, 0, False), (777, 260, 96, 2, True)):
+                          (3200, 2048, 512, 1, False), (3200, 1536, 512, 0, False), (3200, 512, 512, 0, True), (3200, 512, 2048, 0, True), (2048, 512, 512, 0, False), (1004, 2048, 512, 1, False), (1004, 512, 2048, 0, True), (251, 1536, 512, 0, False), (251, 512, 2048, 0, True), (2016, 768, 256, 0, False), (777, 260, 96, 2, True)):
     x = (torch.randn(M, K, device=dev) * 2 + 0.7); w = torch.randn(N, K, device=dev) * 0.06; b = torch.randn(N, device=dev)
     r = torch.randn(M, N, device=dev) if res else None
     ref = x.double() @ w.double().t() + b.double()
@@ -33,7 +33,7 @@ for M, N, K, act, res in ((16064, 2048, 512, 1, False), (16064, 1536, 512, 0, Fa
     sc = float(ref.abs().max())
     fl = 2.0 * M * N * K
     out = []
-    for variant in (None, "1", "2"):
+    for variant in (None, "1", "2", "3"):
         y = torch.empty(M, N, device=dev)
         call = lambda: lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), M, N, K, act, st)
         os.environ.pop("AVSEP_GEMM_SPLIT", None); os.environ.pop("AVSEP_SPLIT_VARIANT", None)
@@ -44,4 +44,4 @@ for M, N, K, act, res in ((16064, 2048, 512, 1, False), (16064, 1536, 512, 0, Fa
         out.append((t, float((y.double() - ref).abs().max()) / sc))
     os.environ.pop("AVSEP_GEMM_SPLIT", None); os.environ.pop("AVSEP_SPLIT_VARIANT", None)
     cells = " | ".join(f"{t * 1e6:8.1f} {fl / t / 1e12:7.1f}  {e:.2e}" for t, e in out)
-    print(f"({M:6d},{N:5d},{K:5d}) act {act} res {int(res)}  {cells} | x{out[0][0] / out[1][0]:.2f} x{out[0][0] / out[2][0]:.2f}", flush=True)
+    print(f"({M:6d},{N:5d},{K:5d}) act {act} res {int(res)}  {cells} | x{out[0][0] / out[1][0]:.2f} x{out[0][0] / out[2][0]:.2f} x{out[0][0] / out[3][0]:.2f}", flush=True)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 4, run 28: split-precision GEMM in the training step -- training tests (gradient gates), step A/B
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04t; mkdir -p $O; cd $R
+set -o pipefail
+timeout -k 10 900 python3 -m pytest tests/test_train_gpu.py -x -q -m gpu 2>&1 | tail -15 || exit 1
+one() { timeout -k 10 300 python3 bench.py --mode train --workload cfg4 --no-cpu --no-profile --no-also --no-quality "$@" 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['loss_first_last'])"; }
+for i in 1 2; do
+  echo -n "cfg4 training, split-precision GEMM (N, K >= 512): "; one --steps 10 --warmup 3 --rounds 5
+  echo -n "cfg4 training, fp32 MFMA GEMM everywhere         : "; one --steps 10 --warmup 3 --rounds 5 --train-fp32-gemm
+done 2>&1 | tee $O/ab_train_split_gemm.txt
