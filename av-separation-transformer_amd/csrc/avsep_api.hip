@@ -389,8 +389,11 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
   if (p.C2) bytes += (double)p.M * p.F * 4;
   static const bool no_taps = dev_env("AVSEP_SPLIT_NO_TAPS") != nullptr, no_mask = dev_env("AVSEP_SPLIT_NO_MASK") != nullptr;   // developer A/B
   if (c->split_gemm && c->d >= 512 && p.N >= 512 && p.K >= 512 && gemm_split_supported(p) &&       // see avsep_ctx::split_gemm
-      !(no_taps && p.amode == AMODE_TAPS3) && !(no_mask && p.C2))
-    return profiled(c, gemm_split_instance_name(p), flops, bytes, s, [&] { return launch_gemm_split(p, s); });
+      !(no_taps && p.amode == AMODE_TAPS3) && !(no_mask && p.C2)) {
+    GemmParams ps = p;
+    ps.split_t2_min = 48;                                          // several forwards in flight: see gemm_split.hip, "Which kernel"
+    return profiled(c, gemm_split_instance_name(ps), flops, bytes, s, [&] { return launch_gemm_split(ps, s); });
+  }
   return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm(p, s); });
 }
 int run_layernorm(avsep_ctx* c, const float* x, const float* g, const float* b, float* y, int M, int d, hipStream_t s) {

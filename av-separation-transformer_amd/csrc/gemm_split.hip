@@ -506,13 +506,15 @@ bool gemm_split_supported(const GemmParams& p) {
 
 // Which kernel.  The 256 x 128 one is the efficient one per flop (190-210 TFLOP/s against 135-150 of the 64 x 64 one and 160-185 of
 // the 128 x 128 one); the 64 x 64 one fills the chip from small problems on (M = 3200, N = 512, K = 2048 alone: 65 us against 137).
-// With several forwards in flight the chip is full anyway and the per-flop figure decides: the visual branch's M = 3200 GEMMs
-// (52 tiles of 256 x 128) are 1.3 % of the cfg3 step faster on the big tile (profiles/r04_ab_split_gemm_64x64.txt).  So: the
-// 256 x 128 kernel from 48 of its tiles on (and two chunks or more), below that -- small batches, where latency is the point --
-// the 64 x 64 one (plain A operand) or the 128 x 128 one (3-tap A operand).  All three compute the same bits.
+// A problem running ALONE on the chip wants the 256 x 128 kernel from half a round of its tiles on (128: it wins from 156 tiles
+// down in profiles/r04_gemm_split_probe_3kernels.txt) -- the default.  With several forwards in flight the chip is full anyway
+// and the per-flop figure decides: the visual branch's M = 3200 GEMMs (52 tiles of 256 x 128) are 1.3 % of the cfg3 step faster
+// on the big tile (profiles/r04_ab_split_gemm_64x64.txt), so the inference forward asks for it from 48 tiles on
+// (GemmParams::split_t2_min).  Below the threshold: the 64 x 64 kernel (plain A operand) or the 128 x 128 one (3-tap A operand).
+// All three compute the same bits.
 static int split_variant(const GemmParams& p) {
   const long t2 = (long)((p.M + S2BM - 1) / S2BM) * ((p.N + S2BN - 1) / S2BN);
-  int v = t2 >= 48 ? 2 : 3;
+  int v = t2 >= (p.split_t2_min > 0 ? p.split_t2_min : 128) ? 2 : 3;
 #ifdef AVSEP_DEV
   if (const char* e = getenv("AVSEP_SPLIT_VARIANT")) v = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : v;   // developer A/B
 #endif

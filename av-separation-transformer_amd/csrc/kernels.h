@@ -81,6 +81,7 @@ struct GemmParams {
   // i.e. the reference's (B, F, T) spectrogram layout; bias / act / R / C2 are not used then.
   int frame_hop, frame_len, mag_F;
   int no_xcd_remap;    // developer switch: 1 = launch-order tiles (A/B measurements)
+  int split_t2_min;    // split-precision GEMM: 256 x 128 kernel from this many of its tiles on (0: 128, the single-stream optimum)
   int epi_general;           // developer A/B switch (AVSEP_EPI_GENERAL): 1 = block-by-block epilogue everywhere
   unsigned long long* dbg;   // developer diagnostics (AVSEP_GEMM_DBG): per-workgroup phase stamps, null otherwise
   // Fused LayerNorm prologue (PLAIN mode, K == normalised width): A' = (A - mean_row) * rstd_row * gamma + beta,

@@ -331,8 +331,9 @@ def main():
                          "encoder layers of each branch as one dependency-driven persistent launch")
     ap.add_argument("--chain-group", type=int, default=8, help="schedule 1: clips per group of the work-list order")
     ap.add_argument("--chain-skew", type=float, default=0.0, help="schedule 1: ops between consecutive clip groups (0 = op-major)")
-    ap.add_argument("--train-fp32-gemm", action="store_true",
-                    help="train mode, developer A/B: the fp32 MFMA GEMM for every Linear (default: split-precision GEMM for N, K >= 512)")
+    ap.add_argument("--train-split-gemm", action="store_true",
+                    help="train mode, A/B: split-precision GEMM for every Linear forward / activation-gradient GEMM with N, K >= 512 "
+                         "(av_separation._train.SPLIT_GEMM; default: the fp32 MFMA GEMM)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` block (short cfg3 / cfg5 forward and cfg4 training lines behind the default cfg2 run; "
                          "--no-cpu and --no-profile, the developer tools' flags, skip it too)")
@@ -741,8 +742,8 @@ def train_main(a, av, dev, dist, rank, world):
     on one resident batch per rank.  Not the headline metric; reported for the N1 row."""
     from av_separation import parallel, _train
     from av_separation.losses import SeparationLoss
-    if a.train_fp32_gemm:
-        _train.SPLIT_GEMM = False
+    if a.train_split_gemm:
+        _train.SPLIT_GEMM = True
     wl = WORKLOADS[a.workload]
     B = a.batch or wl["batch"]
     mk, dk = wl["model"], wl["data"]
