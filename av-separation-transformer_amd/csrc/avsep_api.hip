@@ -404,6 +404,13 @@ int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk
                   int ldo, int B, int Lq, int Lk, hipStream_t s) {
   const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh;
   const double bytes = 4.0 * B * c->d * (2.0 * Lq + 2.0 * Lk);
+  // split-precision attention (attention_split.hip): the models whose Linear layers run on the split-precision GEMM
+  // (d_model >= 512), head width 64, sequences of 128 keys or more -- the domain of the LDS-staged fp32 kernel it replaces.
+  // The rule looks at the model and the sequence lengths only, never at the batch size.
+  static const bool no_split_attn = dev_env("AVSEP_NO_SPLIT_ATTN") != nullptr;                       // developer A/B
+  if (c->split_gemm && c->d >= 512 && Lk >= 128 && attention_split_supported(c->dh, Lq, Lk) && !no_split_attn)
+    return profiled(c, "attention_split_kernel<2>", flops, bytes, s,
+                    [&] { return launch_attention_split(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, 1.0f, s); });
   return profiled(c, attention_instance_name(c->dh, Lq, Lk, B, c->h), flops, bytes, s,
                   [&] { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, s); });
 }
@@ -1577,6 +1584,16 @@ int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const f
                        int B, int nhead, int dh, int Lq, int Lk, void* stream) {
   if (!q || !k || !v || !out) return fail(AVSEP_EINVAL, "null pointer");
   HCK(launch_attention(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
+                             int B, int nhead, int dh, int Lq, int Lk, void* stream) {
+  if (!q || !k || !v || !out) return fail(AVSEP_EINVAL, "null pointer");
+  if (B <= 0 || nhead <= 0 || Lq <= 0 || Lk <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (!attention_split_supported(dh, Lq, Lk)) return fail(AVSEP_EINVAL, "the split-precision attention needs dh = 64");
+  if ((ldq | ldk | ldv | ldo) & 3) return fail(AVSEP_EINVAL, "rows must be 16-byte aligned");
+  HCK(launch_attention_split(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, 1.0f, reinterpret_cast<hipStream_t>(stream)));
   return AVSEP_OK;
 }
 

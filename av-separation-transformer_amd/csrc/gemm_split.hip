@@ -20,31 +20,16 @@
 // products): parity is by tolerance against float64 (tests/test_gpu_parity.py::test_op_linear_split_precision).
 #include "kernels.h"
 #include "gemm_tile.h"
+#include "split_terms.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// three bf16 planes of 4 fp32 values: plane p of elements (e0,e1) and (e2,e3) as two dwords each (low half = the even element).
-// Two elements at a time: the exact subtractions are v_pk_add_f32 (one issue for both), 4.5 VALU per element instead of 5.5.
-// (Bit casts of WHOLE vectors only: hipcc 7.2 reads element 0 for every e when __builtin_bit_cast is applied to an ext-vector
-// element expression v[e] -- found by the one-hot probes of tools/gemm_split_debug.py.)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// three bf16 planes of 4 fp32 values: plane p of elements (e0,e1) and (e2,e3) as two dwords each (low half = the even element)
 __device__ __forceinline__ void split4(const f32x4 v, unsigned (&hi)[2], unsigned (&mid)[2], unsigned (&lo)[2]) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const f32x2 x = q ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
-    const u32x2 u = __builtin_bit_cast(u32x2, x);                       // upper 16 bits are taken by the pack below
-    const f32x2 r1 = x - __builtin_bit_cast(f32x2, u & 0xFFFF0000u);    // exact
-    const u32x2 m = __builtin_bit_cast(u32x2, r1);
-    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, m & 0xFFFF0000u);   // exact
-    const u32x2 l = __builtin_bit_cast(u32x2, r2);
-    // bytes [3,2] of the odd element | bytes [3,2] of the even one
-    hi[q] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
-    mid[q] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
-    lo[q] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
-  }
+  split_pair(f32x2{v[0], v[1]}, hi[0], mid[0], lo[0]);
+  split_pair(f32x2{v[2], v[3]}, hi[1], mid[1], lo[1]);
 }
 
 constexpr int SBM = 128, SBN = 128, SBK = 32;

@@ -153,6 +153,10 @@ hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStrea
 bool gemm_split_supported(const GemmParams& p);
 hipError_t launch_gemm_split(GemmParams p, hipStream_t s);
 const char* gemm_split_instance_name(const GemmParams& p);
+// split-precision attention (attention_split.hip): dh = 64, fp32 in / out, QK^T and PV as six bf16 MFMA products per fp32 product
+bool attention_split_supported(int dh, int Lq, int Lk);
+hipError_t launch_attention_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                  int B, int nhead, int dh, int Lq, int Lk, float qscale, hipStream_t s);
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
 // with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)

@@ -1,0 +1,29 @@
+// split_terms.h -- the operand split of the split-precision kernels (gemm_split.hip, attention_split.hip): an fp32 value x is cut
+// into THREE bf16 terms by truncation, x = hi + mid + lo exactly (8 + 8 + 8 significand bits): hi = the upper 16 bits of x,
+// mid = the upper 16 bits of (x - hi), lo = the upper 16 bits of (x - hi - mid); the two subtractions are exact.
+// Anonymous namespace: one copy per translation unit.
+#pragma once
+#include "kernels.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Two values at a time: the subtractions are v_pk_add_f32 (one issue for both), 4.5 VALU per element.  Each plane's two bf16
+// land in one dword, the first value in the low half (the k order of an MFMA operand).
+// (Bit casts of WHOLE vectors only: hipcc 7.2 reads element 0 for every e when __builtin_bit_cast is applied to an ext-vector
+// element expression v[e] -- found by the one-hot probes of tools/gemm_split_debug.py.)
+__device__ __forceinline__ void split_pair(const f32x2 x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const u32x2 u = __builtin_bit_cast(u32x2, x);                       // upper 16 bits are taken by the pack below
+  const f32x2 r1 = x - __builtin_bit_cast(f32x2, u & 0xFFFF0000u);    // exact
+  const u32x2 m = __builtin_bit_cast(u32x2, r1);
+  const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, m & 0xFFFF0000u);   // exact
+  const u32x2 l = __builtin_bit_cast(u32x2, r2);
+  // bytes [3,2] of the second value | bytes [3,2] of the first
+  hi = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+  mid = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+  lo = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+}
+
+}  // namespace

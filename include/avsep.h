@@ -156,6 +156,13 @@ int avsep_op_ln_linear(const float* x, const float* gamma, const float* beta, co
  * column offset h*dh; out (B,Lq,ldo). */
 int avsep_op_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
                        int ldo, int B, int nhead, int dh, int Lq, int Lk, void* stream);
+/* The same function with both matrix products (q k^T and p v) on the bf16 matrix pipe: every fp32 operand -- q, k, v and the
+ * probabilities -- cut into three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation and softmax
+ * (csrc/attention_split.hip); dh = 64.  Not the bits of avsep_op_attention: the same distance from float64
+ * (tests/test_gpu_parity.py::test_op_attention_split_precision).  What the forward runs for d_model >= 512 models at 128
+ * keys or more (nn.MultiheadAttention, /root/reference/src/av_separation/model.py:46-60,159-172). */
+int avsep_op_attention_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
+                             int ldo, int B, int nhead, int dh, int Lq, int Lk, void* stream);
 #ifdef AVSEP_DEV
 /* Developer build only (measured slower than the two launches it replaces).
  * x += softmax(q k^T) v  W_o^T + b_o in ONE launch: the attention core of a pre-norm block with its out_proj and the
