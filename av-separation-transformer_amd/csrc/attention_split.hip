@@ -33,13 +33,23 @@ constexpr int AS_KEYS = 32;                  // keys per step
 constexpr int AS_PL = AS_KEYS * 128;         // bytes of one plane: 32 rows x 64 bf16
 constexpr int AS_BUF = 6 * AS_PL;            // [K hi|mid|lo][V hi|mid|lo] = 24 KB
 
-// exp_neg (attn_tile.h) on a pair with packed fp32 VALU: the same operations in the same order, the same bits
+// exp_neg (attn_tile.h) without its clamp at -120, scalar and on a pair with packed fp32 VALU.  The clamp exists for -inf
+// arguments (masked keys, the first tile's running maximum); this kernel masks with MASKED = -1e30 instead, for which every
+// intermediate stays finite and v_exp_f32 returns exactly 0, and for finite arguments the two forms have the same bits
+// (below -120 both give 0: exp2(-173) is 0 on v_exp_f32) -- 18 v_max per step less in a VALU-bound loop.
+constexpr float MASKED = -1e30f;
+__device__ __forceinline__ float exp_neg_finite(float x) {
+  const float L2E_HI = 1.44269502162933349609f, L2E_LO = 1.92596299112661746e-08f;
+  const float t = x * L2E_HI;
+  float r = fmaf(x, L2E_HI, -t);
+  r = fmaf(x, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.69314718055994530942f, e);
+}
 __device__ __forceinline__ f32x2 exp_neg_pair(f32x2 x) {
   const f32x2 HI = {1.44269502162933349609f, 1.44269502162933349609f};
   const f32x2 LO = {1.92596299112661746e-08f, 1.92596299112661746e-08f};
   const f32x2 LN2 = {0.69314718055994530942f, 0.69314718055994530942f};
-  x[0] = fmaxf(x[0], -120.0f);
-  x[1] = fmaxf(x[1], -120.0f);
   const f32x2 t = x * HI;
   f32x2 r = __builtin_elementwise_fma(x, HI, -t);
   r = __builtin_elementwise_fma(x, LO, r);
@@ -65,6 +75,7 @@ __device__ __forceinline__ u32x4 vec4(const unsigned (&a)[4]) { return u32x4{a[0
 
 __device__ __forceinline__ bf16x8 as_frag(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
+// (Three workgroups per CU -- 168 VGPRs, 4 spilled -- measured: no difference, profiles/r04_ab_split_attention_wgs.txt.)
 template <int QT>
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                                  int ldk, const float* __restrict__ v, int ldv,
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float* __
   float mrun[QT], lrun[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    mrun[t] = -INFINITY;
+    mrun[t] = MASKED;
     lrun[t] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -204,13 +215,13 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float* __
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) stt[kt][t][r] = st * AS_KEYS + 16 * kt + 4 * g + r < Lk ? stt[kt][t][r] : -INFINITY;
+          for (int r = 0; r < 4; ++r) stt[kt][t][r] = st * AS_KEYS + 16 * kt + 4 * g + r < Lk ? stt[kt][t][r] : MASKED;
       }
       float tmax = fmaxf(fmaxf(fmaxf(stt[0][t][0], stt[0][t][1]), fmaxf(stt[0][t][2], stt[0][t][3])),
                          fmaxf(fmaxf(stt[1][t][0], stt[1][t][1]), fmaxf(stt[1][t][2], stt[1][t][3])));
       tmax = rows_max(tmax);
       const float mnew = fmaxf(mrun[t], tmax);                       // finite: step 0 always holds key 0
-      const float alpha = exp_neg(mrun[t] - mnew);                   // 0 on the first step (mrun = -inf)
+      const float alpha = exp_neg_finite(mrun[t] - mnew);            // 0 on the first step (mrun = MASKED)
       const f32x2 m2 = {mnew, mnew};
       const f32x2 p01 = exp_neg_pair(f32x2{stt[0][t][0], stt[0][t][1]} - m2), p23 = exp_neg_pair(f32x2{stt[0][t][2], stt[0][t][3]} - m2);
       const f32x2 p45 = exp_neg_pair(f32x2{stt[1][t][0], stt[1][t][1]} - m2), p67 = exp_neg_pair(f32x2{stt[1][t][2], stt[1][t][3]} - m2);

@@ -548,7 +548,7 @@ def main():
         "metric": metric_string(mk, dk, R),
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if mk["d_model"] < 512 else "f32 (nn.Linear products as 6 bf16 MFMA products per fp32 product, fp32 accumulation)",
+        "dtype": "f32" if mk["d_model"] < 512 else "f32 (nn.Linear and attention products as 6 bf16 MFMA products per fp32 product, fp32 accumulation)",
         "data": "synthetic",
         "config": {"workload": f"{a.workload}: SyntheticAVDataset {S}-speaker, F={F}, T={T}, N={N}, {H}x{W} lips, "
                                f"d_model={mk['d_model']}, nhead={mk['nhead']}, {mk['num_encoder_layers']}+"

@@ -2,6 +2,7 @@
 """Developer tool (GPU box): the split-precision attention kernel against the fp32-MFMA one on the long-sequence shapes of
 configs 3-5: time and error against float64."""
 import os
+os.environ.setdefault("AVSEP_LIB", "dev")
 import ctypes as C, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av-separation-transformer_amd"))
