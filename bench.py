@@ -608,6 +608,7 @@ def main():
         t_also = time.perf_counter()
         out["also"] = {w: also_forward(av, dev, w) for w in ("cfg3", "cfg5")}
         out["also"]["cfg4_train"] = also_train(av, dev)
+        out["also"]["cfg4_train_split_gemm_opt_in"] = also_train(av, dev, split_gemm=True)
         out["also"]["seconds"] = round(time.perf_counter() - t_also, 1)
     if dist is not None:
         dist.barrier()
@@ -668,10 +669,22 @@ def also_forward(av, dev, name, steps=5, rounds=3, warmup=3):
     return out
 
 
-def also_train(av, dev, steps=5, rounds=3, warmup=6):
+def also_train(av, dev, steps=5, rounds=3, warmup=6, split_gemm=False):
     """A short line for BASELINE configs[3]'s training step inside the default run: the loop body of `--mode train`
     (zero_grad, train-mode forward with dropout 0.1, SeparationLoss, backward, clip, fused Adam) on one resident 16-clip
-    batch, single rank."""
+    batch, single rank.  split_gemm: the opt-in switch av_separation._train.SPLIT_GEMM ("the training step on the
+    split-precision GEMM") for the duration of the line."""
+    from av_separation import _train
+    from av_separation.losses import SeparationLoss
+    was = _train.SPLIT_GEMM
+    _train.SPLIT_GEMM = bool(split_gemm)
+    try:
+        return _also_train(av, dev, steps, rounds, warmup, split_gemm)
+    finally:
+        _train.SPLIT_GEMM = was
+
+
+def _also_train(av, dev, steps, rounds, warmup, split_gemm):
     from av_separation.losses import SeparationLoss
     wl = WORKLOADS["cfg4"]
     B, mk, dk = wl["batch"], wl["model"], wl["data"]
@@ -708,7 +721,9 @@ def also_train(av, dev, steps=5, rounds=3, warmup=6):
     out = {"metric": "training clips/sec (forward+backward+Adam step), fp32", "value": round(value, 2), "unit": "clips/s",
            "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "rounds": rounds, "batch_per_gpu": B,
            "gflop_per_clip": round(gflop, 3), "frac": round(value * gflop / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
-           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)]}
+           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
+           "linear_gemm": ("split-precision (opt-in: av_separation._train.SPLIT_GEMM; 4 of 330 gradient tensors leave the 1.5x gate)"
+                           if split_gemm else "fp32 MFMA (default)")}
     del model, opt
     torch.cuda.empty_cache()
     return out

@@ -54,6 +54,7 @@ def test_bench_single_gpu_contract_line():
         assert al[w]["batch_per_gpu"] == b and al[w]["value"] > 0 and al[w]["slots_bit_equal"] and al[w]["masks_in_unit_interval"]
         assert 0.3 < al[w]["path_frac"] < 1.7      # of the fp32 matrix peak; the Linear layers run on the bf16 pipe (split precision)
     assert al["cfg4_train"]["batch_per_gpu"] == 16 and al["cfg4_train"]["value"] > 0 and al["seconds"] < 90
+    assert al["cfg4_train"]["linear_gemm"].startswith("fp32") and al["cfg4_train_split_gemm_opt_in"]["value"] > 0
     ql = cb["quality"]
     assert ql["gpu"]["snr_improvement_db"] >= 35.0 and abs(ql["trained_out_snr_gpu_minus_cpu_db"]) < 1.0
     if rf["traffic"] is not None:
