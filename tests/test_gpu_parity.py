@@ -793,22 +793,29 @@ def test_op_linear_split_precision(lib, dev, M, N, K, act, res):
 def test_split_terms_are_exact(lib, dev, M):
     """x = hi + mid + lo must hold EXACTLY (three bf16 terms by truncation, two exact subtractions): a split-precision GEMM
     against the identity matrix returns x bit for bit -- every output is hi*1 + mid*1 + lo*1, whose fp32 sums are exact --
-    for ordinary values, values at the edges of the exponent range, exact bf16 values and zeros, on all three kernels
-    (M = 3 / 300: the 64 x 64 one; M = 20000: 256 x 128)."""
+    for ordinary values, values towards the edges of the exponent range, exact bf16 values and zeros, on all three kernels
+    (M = 3 / 300: the 64 x 64 one; M = 20000: 256 x 128).  The one limit: a term below the smallest normal number (2^-126) is
+    flushed by the matrix pipe, so values under ~2^-110 come back with an ABSOLUTE error below 2^-126 (second half of the test)."""
     K = 512
     g = torch.Generator(device="cpu").manual_seed(17)
     x = torch.randn(M, K, generator=g)
+    x = torch.where(x.abs() < 1e-3, torch.full_like(x, 0.5), x)       # keeps the scaled columns below inside the exact range
     x[:, 0::7] *= 1e30
-    x[:, 1::7] *= 1e-30
+    x[:, 1::7] *= 1e-25
     x[:, 2::7] = x[:, 2::7].to(torch.bfloat16).float()
     x[:, 3::7] = 0.0
-    x[:, 4::7] = -x[:, 4::7].abs() * 3.0e38 / 4.0
+    x[:, 4::7] = -x[:, 4::7].abs().clamp(max=4.0) * (3.0e38 / 4.0)
+    assert torch.isfinite(x).all()
     x[0, :8] = torch.tensor([1.0, -1.0, 2.0 ** -126, -(2.0 ** -126), 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.4028234e38, -3.4028234e38])
     xd = x.to(dev)
     eye = torch.eye(K, device=dev)
     y = torch.full((M, K), float("nan"), device=dev)
     assert lib.avsep_op_linear_split(xd.data_ptr(), eye.data_ptr(), None, None, y.data_ptr(), M, K, K, 0, _stream()) == 0
-    assert torch.equal(y, xd)
+    bad = (y != xd).nonzero()
+    assert bad.numel() == 0, (bad[:5].tolist(), [(float(xd[i, j]), float(y[i, j])) for i, j in bad[:5].tolist()])
+    tiny = (torch.randn(M, K, generator=g) * 1e-36).to(dev)
+    assert lib.avsep_op_linear_split(tiny.data_ptr(), eye.data_ptr(), None, None, y.data_ptr(), M, K, K, 0, _stream()) == 0
+    assert float((y.double() - tiny.double()).abs().max()) < 2.0 ** -126
 
 
 def test_op_linear_rejects_bad_k(lib, dev):
