@@ -818,6 +818,64 @@ def test_split_terms_are_exact(lib, dev, M):
     assert float((y.double() - tiny.double()).abs().max()) < 2.0 ** -126
 
 
+def test_op_linear_split_random_shapes(lib, dev):
+    """40 random (M, N, K, activation, residual) problems through the split-precision GEMM -- whichever of its three kernels the
+    shape selects (tiny, ragged, tall: the last ten have 20 k - 60 k rows) -- against float64, at the fp32 GEMM's error level."""
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for it in range(40):
+        tall = it >= 30
+        M = int(rng.integers(20000, 60000)) if tall else int(rng.integers(1, 3000))
+        N = 4 * int(rng.integers(1, 130 if tall else 300))
+        K = 32 * int(rng.integers(1, 9 if tall else 40))
+        act, res = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
+        g = torch.Generator(device="cpu").manual_seed(1000 + it)
+        x = (torch.randn(M, K, generator=g) * 2 + 0.3).to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        r = torch.randn(M, N, generator=g).to(dev) if res else None
+        ref = x.double() @ w.double().t() + b.double()
+        ref = {0: ref, 1: torch.relu(ref), 2: torch.nn.functional.gelu(ref), 3: torch.sigmoid(ref)}[act]
+        if res:
+            ref = ref + r.double()
+        y0 = torch.full((M, N), float("nan"), device=dev)
+        y1 = torch.full((M, N), float("nan"), device=dev)
+        rp = r.data_ptr() if res else None
+        assert lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), rp, y0.data_ptr(), M, N, K, act, _stream()) == 0
+        assert lib.avsep_op_linear_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), rp, y1.data_ptr(), M, N, K, act, _stream()) == 0, \
+            (M, N, K, lib.avsep_last_error())
+        sc = float(ref.abs().max())
+        e0 = float((y0.double() - ref).abs().max()) / sc
+        e1 = float((y1.double() - ref).abs().max()) / sc
+        assert torch.isfinite(y1).all() and e1 < 2.0 * e0 + 2e-7 and e1 < 4e-6, (M, N, K, act, res, e0, e1)
+        worst = max(worst, e1 / max(e0, 1e-9))
+    print(f"split / fp32 error ratio, worst of 40 shapes: {worst:.2f}")
+
+
+def test_op_attention_split_random_shapes(lib, dev):
+    """30 random (B, heads, Lq, Lk) problems through the split-precision attention against float64 and the fp32 kernel."""
+    from av_separation._native import check
+    rng = np.random.default_rng(12)
+    dh = 64
+    for it in range(30):
+        B, h = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        Lq, Lk = int(rng.integers(1, 420)), int(rng.integers(1, 420))
+        d = h * dh
+        g = torch.Generator(device="cpu").manual_seed(2000 + it)
+        q = (torch.randn(B, Lq, d, generator=g) * 0.5).to(dev)
+        k = torch.randn(B, Lk, d, generator=g).to(dev)
+        v = (torch.randn(B, Lk, d, generator=g) * 2).to(dev)
+        o0 = torch.full((B, Lq, d), float("nan"), device=dev)
+        o1 = torch.full((B, Lq, d), float("nan"), device=dev)
+        check(lib.avsep_op_attention(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, o0.data_ptr(), d, B, h, dh, Lq, Lk, _stream()))
+        check(lib.avsep_op_attention_split(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, o1.data_ptr(), d, B, h, dh, Lq, Lk, _stream()))
+        qq, kk, vv = (t_.double().view(B, -1, h, dh).transpose(1, 2) for t_ in (q, k, v))
+        ref = (torch.softmax(qq @ kk.transpose(-1, -2), -1) @ vv).transpose(1, 2).reshape(B, Lq, d)
+        e0 = float((o0.double() - ref).abs().max())
+        e1 = float((o1.double() - ref).abs().max())
+        assert torch.isfinite(o1).all() and e1 < 2.0 * e0 + 3e-7 and e1 < 1e-5, (B, h, Lq, Lk, e0, e1)
+
+
 def test_op_linear_rejects_bad_k(lib, dev):
     y = torch.empty(4, 4, device=dev)
     assert lib.avsep_op_linear(y.data_ptr(), y.data_ptr(), None, None, y.data_ptr(), 4, 4, 30, 0, _stream()) == -1
