@@ -477,103 +477,6 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel3(const GemmParams pi
   gemm_epilogue<2, 2>(p, acc, m0, n0, wm * 32, wn * 32, fr, fq);
 }
 
-
-// The same kernel with a FOUR-deep register ring: a chunk of this tile is 24 MFMAs per wave (0.2 us) against a 1-2 us memory
-// round trip, and a small problem has no second workgroup per CU to wait behind -- at M = 251 rows (one clip of configs 3-5) the
-// kernel above spends its time in s_waitcnt (K = 2048: 42 us against the fp32 MFMA GEMM's 17).  Here the loads of chunk c + 5 are
-// issued while chunk c is multiplied (slot (c + 1) % 4 is split into the other LDS buffer, then reloaded), so a load has four
-// chunk times to land.  64 staging registers instead of 16 (132 VGPRs: still three workgroups per CU).  Same products, same order, same bits.
-__global__ __launch_bounds__(256, 3) void gemm_split_kernel3r(const GemmParams pin) {
-  GemmParams p = pin;
-  __shared__ __attribute__((aligned(16))) char lds3[2 * S3_BUF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nbn = (p.N + S3B - 1) / S3B;
-  const int tile = xcd_tile(p);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int m0 = bm * S3B, n0 = bn * S3B;
-  const int srow = tid >> 2, sq = tid & 3;
-  const float* a_src = p.A + (size_t)min(m0 + srow, p.M - 1) * p.lda + 8 * sq;
-  const float* w_src = p.W + (size_t)min(n0 + srow, p.N - 1) * p.ldw + 8 * sq;
-  const int ast = srow * 64 + ((sq ^ ((0 - (srow >> 2)) & 3)) << 4), wst = 3 * S3_PL + ast;
-  const int nk = p.K / SBK;
-  const int fr = lane & 15, fq = lane >> 4;
-  int a_fo[2], w_fo[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = wm * 32 + 16 * i + fr;
-    a_fo[i] = r * 64 + ((fq ^ ((0 - (r >> 2)) & 3)) << 4);
-    const int c = wn * 32 + 16 * i + fr;
-    w_fo[i] = 3 * S3_PL + c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
-  }
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // slot s holds a chunk c with c % 4 == s: {A 8 floats, W 8 floats} of this thread
-  f32x4 a0_0, a1_0, w0_0, w1_0, a0_1, a1_1, w0_1, w1_1, a0_2, a1_2, w0_2, w1_2, a0_3, a1_3, w0_3, w1_3;
-#define S3R_LOAD(S, kc)                                                                          \
-  {                                                                                              \
-    const int kk_ = min((kc), nk - 1) * SBK; /* beyond K: clamped data nobody multiplies */      \
-    a0_##S = *reinterpret_cast<const f32x4*>(a_src + kk_);                                       \
-    a1_##S = *reinterpret_cast<const f32x4*>(a_src + kk_ + 4);                                   \
-    w0_##S = *reinterpret_cast<const f32x4*>(w_src + kk_);                                       \
-    w1_##S = *reinterpret_cast<const f32x4*>(w_src + kk_ + 4);                                   \
-  }
-  S3R_LOAD(0, 0)
-  split8_store(a0_0, a1_0, lds3 + ast, lds3 + S3_PL + ast, lds3 + 2 * S3_PL + ast);
-  split8_store(w0_0, w1_0, lds3 + wst, lds3 + S3_PL + wst, lds3 + 2 * S3_PL + wst);
-  S3R_LOAD(1, 1)
-  S3R_LOAD(2, 2)
-  S3R_LOAD(3, 3)
-  S3R_LOAD(0, 4)
-  __syncthreads();
-
-#define S3_FRAG(plane, off, f) \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) f[i] = *reinterpret_cast<const bf16x8*>(rb + (plane) * S3_PL + off[i]);
-#define S3_MMA(fwp, fap)                                                                                      \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                 \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
-  // chunk c = kc + J (buffer J & 1): multiply it, split slot SN = (J + 1) % 4 (chunk c + 1) into the other buffer, reload the slot
-#define S3R_BODY(J, SN)                                                                          \
-  if (kc + (J) < nk) { /* block-uniform */                                                       \
-    const char* rb = lds3 + ((J) & 1) * S3_BUF;                                                  \
-    char* sb = lds3 + (((J) & 1) ^ 1) * S3_BUF;                                                  \
-    bf16x8 a_hi[2], w_hi[2], a_mid[2], w_mid[2], t_lo[2];                                        \
-    S3_FRAG(0, a_fo, a_hi)                                                                       \
-    S3_FRAG(2, w_fo, t_lo)                                                                       \
-    S3_MMA(t_lo, a_hi) /* (hi, lo) */                                                            \
-    S3_FRAG(0, w_fo, w_hi)                                                                       \
-    S3_FRAG(2, a_fo, t_lo)                                                                       \
-    S3_MMA(w_hi, t_lo) /* (lo, hi) */                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    S3_FRAG(1, a_fo, a_mid)                                                                      \
-    S3_FRAG(1, w_fo, w_mid)                                                                      \
-    S3_MMA(w_mid, a_mid) /* (mid, mid) */                                                        \
-    S3_MMA(w_hi, a_mid)  /* (mid, hi) */                                                         \
-    split8_store(a0_##SN, a1_##SN, sb + ast, sb + S3_PL + ast, sb + 2 * S3_PL + ast);            \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    S3_MMA(w_mid, a_hi) /* (hi, mid) */                                                          \
-    S3_MMA(w_hi, a_hi)  /* (hi, hi) */                                                           \
-    split8_store(w0_##SN, w1_##SN, sb + wst, sb + S3_PL + wst, sb + 2 * S3_PL + wst);            \
-    S3R_LOAD(SN, kc + (J) + 5)                                                                   \
-    __syncthreads();                                                                             \
-  }
-  for (int kc = 0; kc < nk; kc += 4) {
-    S3R_BODY(0, 1)
-    S3R_BODY(1, 2)
-    S3R_BODY(2, 3)
-    S3R_BODY(3, 0)
-  }
-#undef S3R_LOAD
-#undef S3R_BODY
-#undef S3_FRAG
-#undef S3_MMA
-  gemm_epilogue<2, 2>(p, acc, m0, n0, wm * 32, wn * 32, fr, fq);
-}
-
 }  // namespace
 
 bool gemm_split_supported(const GemmParams& p) {
@@ -643,12 +546,7 @@ hipError_t launch_gemm_split(GemmParams p, hipStream_t s) {
   if (v == 2) return p.amode == AMODE_TAPS3 ? launch_split2<true>(p, s) : launch_split2<false>(p, s);
   if (v == 3) {
     const long tiles = (long)((p.M + S3B - 1) / S3B) * ((p.N + S3B - 1) / S3B);
-    bool ring = true;
-#ifdef AVSEP_DEV
-    if (const char* e = getenv("AVSEP_SPLIT_RING")) ring = atoi(e) != 0;                             // developer A/B
-#endif
-    if (ring) hipLaunchKernelGGL(gemm_split_kernel3r, dim3((unsigned)tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gemm_split_kernel3, dim3((unsigned)tiles), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(gemm_split_kernel3, dim3((unsigned)tiles), dim3(256), 0, s, p);
     return hipGetLastError();
   }
   const long tiles = (long)((p.M + SBM - 1) / SBM) * ((p.N + SBN - 1) / SBN);
