@@ -221,6 +221,7 @@ class _Engine:
         self.ws = None
         self.taps = False
         self.schedule = (0, 8, 0.0)   # avsep_set_schedule arguments, re-applied to every native context this engine creates
+        self.split_precision = True   # avsep_set_split_precision, likewise
         self.static = None     # graph-replay buffers
         self._flat, self._flat_epoch = None, -1
 
@@ -238,6 +239,8 @@ class _Engine:
         if self.schedule[0]:
             _native.check(lib.avsep_set_schedule(self.ctx, int(self.schedule[0]), int(self.schedule[1]), float(self.schedule[2])),
                           "avsep_set_schedule")
+        if not self.split_precision:
+            _native.check(lib.avsep_set_split_precision(self.ctx, 0), "avsep_set_split_precision")
 
     def close(self):
         if self.ctx is not None:
@@ -306,6 +309,11 @@ class _Engine:
         if self.ctx is not None and hasattr(_native.load(), "avsep_set_schedule"):
             _native.check(_native.load().avsep_set_schedule(self.ctx, *self.schedule[:2], C.c_float(self.schedule[2])),
                           "avsep_set_schedule")
+
+    def set_split_precision(self, on: bool):
+        self.split_precision = bool(on)
+        if self.ctx is not None:
+            _native.check(_native.load().avsep_set_split_precision(self.ctx, int(self.split_precision)), "avsep_set_split_precision")
 
     def set_taps(self, on: bool):
         self.taps = bool(on)
@@ -545,6 +553,16 @@ class AVSeparationTransformer(_Tracked):
             eng.set_schedule(schedule, group, skew)
         return self
 
+    def set_split_precision(self, on: bool = True):
+        """The split-precision GEMM / attention kernels of the fused eval forward on (default) or off (include/avsep.h
+        avsep_set_split_precision).  They only ever apply to d_model >= 512 models and are fp32-equivalent; they win from 8-16
+        clips per forward on and LOSE at 1-4 clips, and the library never looks at the batch size by itself (same bits at every
+        batch size under either setting): a latency deployment of a d_model >= 512 model calls ``set_split_precision(False)``."""
+        self._engine.set_split_precision(on)
+        for eng in self.__dict__.get("_slot_engines", {}).values():
+            eng.set_split_precision(on)
+        return self
+
     def chain_status(self):
         """Raises if a chained launch (schedule 1) of the last forward gave up waiting for a producer tile."""
         eng = self._engine
@@ -578,6 +596,7 @@ class AVSeparationTransformer(_Tracked):
             if eng is None:
                 eng = extra[slot] = _Engine(self, "", *self._engine.cfg)
                 eng.schedule = self._engine.schedule
+                eng.split_precision = self._engine.split_precision
         lib = _native.load()
         with torch.cuda.device(dev):
             st = _stream(dev)

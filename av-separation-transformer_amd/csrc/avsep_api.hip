@@ -1076,6 +1076,24 @@ void avsep_destroy(avsep_ctx* c) {
   delete c;
 }
 
+// Split-precision kernels on (the default) or off for this context: see include/avsep.h.  Captured graphs hold the kernels of
+// the previous setting: drain and drop them.
+int avsep_set_split_precision(avsep_ctx* c, int enable) try {
+  if (!c) return fail(AVSEP_EINVAL, "null context");
+  const bool on = enable != 0;
+  if (on == c->split_gemm) return AVSEP_OK;
+  DeviceScope guard(c->device);
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  for (auto& g : c->graphs) (void)hipStreamSynchronize(g.last_stream);
+  (void)hipDeviceSynchronize();
+  for (auto& g : c->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipStreamDestroy(g.cap); (void)hipStreamDestroy(g.side); }
+  c->graphs.clear();
+  c->split_gemm = on;
+  return AVSEP_OK;
+} catch (...) {
+  return on_exception();
+}
+
 #ifdef AVSEP_DEV
 int avsep_set_schedule(avsep_ctx* c, int schedule, int group, float skew) try {
   if (!c) return fail(AVSEP_EINVAL, "null context");

@@ -12,6 +12,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Two values at a time: the subtractions are v_pk_add_f32 (one issue for both), 4.5 VALU per element.  Each plane's two bf16
 // land in one dword, the first value in the low half (the k order of an MFMA operand).
+// (The residual as ONE v_dot2c_f32_bf16 per value from the packed plane dword -- d = x, d += hi * -1, exact -- was tried: the
+// instruction accumulates in place, hipcc adds a v_mov per use, and the GEMM's chunk has 117 VALU instead of 115.)
 // (Bit casts of WHOLE vectors only: hipcc 7.2 reads element 0 for every e when __builtin_bit_cast is applied to an ext-vector
 // element expression v[e] -- found by the one-hot probes of tools/gemm_split_debug.py.)
 __device__ __forceinline__ void split_pair(const f32x2 x, unsigned& hi, unsigned& mid, unsigned& lo) {

@@ -102,6 +102,13 @@ int avsep_fusion(avsep_ctx* ctx, const float* audio, const float* visual, float*
 int avsep_decoder(avsep_ctx* ctx, const float* fused, const float* mixed, float* masks_btsf,
                   float* separated_btsf, void* ws, size_t ws_bytes, int B, int T, void* stream);
 
+/* Split-precision kernels (csrc/gemm_split.hip, attention_split.hip) of this context's forwards on (1, the default) or off (0).
+ * They apply to d_model >= 512 models only (weights with N, K >= 512; attention at 128 keys or more), are fp32-equivalent
+ * (see avsep_op_linear_split) and 1.3-1.45x faster from 8-16 clips per forward on -- but SLOWER than the fp32 MFMA kernels
+ * at 1-4 clips (profiles/r04_ab_split_small_batches.txt: 1.40 ms against 0.84 ms for one clip of config 3).  The choice never
+ * looks at the batch size by itself (a model computes the same bits at every batch size under either setting), so a latency
+ * deployment turns them off here.  Captured graphs of the other setting are dropped. */
+int avsep_set_split_precision(avsep_ctx* ctx, int enable);
 /* Debug/parity taps.  After avsep_set_debug_taps(ctx, 1), avsep_workspace_bytes() reserves a tap area and
  * every eager forward/stage call copies its stage-boundary activations there; avsep_read_tap() copies one
  * of them (names follow oracle/numpy_forward.py: "a_conv1","a_pe","a_enc0","v_conv0".."v_conv2" (channels-

@@ -818,6 +818,34 @@ def test_split_terms_are_exact(lib, dev, M):
     assert float((y.double() - tiny.double()).abs().max()) < 2.0 ** -126
 
 
+def test_split_precision_can_be_turned_off_per_model(golden, dev):
+    """``set_split_precision(False)`` (include/avsep.h avsep_set_split_precision): a d_model = 512 model then runs the fp32 MFMA
+    kernels -- other bits than with the split-precision kernels, both within MASK_TOL of the reference's golden, eager and graph
+    replay agree under either setting, and switching back restores the first bits (captured graphs are dropped on a switch)."""
+    g = golden("fwd_cfg3")
+    c = g["config"]
+    m = build_model(g, dev)
+    mx0, lp0 = golden_inputs(g)
+    mx, lp = seeded.inputs(c["seed"] + 1000, 3, c["F"], c["T"], c["N"], c["H"], c["W"])
+    mx[0], lp[0] = mx0[0], lp0[0]
+    x, l = t(mx, dev), t(lp, dev)
+    outs = []
+    for on in (True, False, True):
+        m.set_split_precision(on)
+        with torch.no_grad():
+            sep, masks = m(x, l)
+        B, S, F, T = masks.shape
+        mk = torch.empty(B, T, S, F, device=dev)
+        sp = torch.empty(B, T, S, F, device=dev)
+        m.run_static(x, l, mk, sp, graph=True)
+        m.run_static(x, l, mk, sp, graph=True)
+        torch.cuda.synchronize()
+        assert torch.equal(mk.permute(0, 2, 3, 1), masks), on
+        assert maxabs(sliced(masks[:1].contiguous().cpu().numpy(), 7), g["masks.slice"]) < MASK_TOL, on
+        outs.append(masks.clone())
+    assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
+
+
 def test_op_linear_split_random_shapes(lib, dev):
     """40 random (M, N, K, activation, residual) problems through the split-precision GEMM -- whichever of its three kernels the
     shape selects (tiny, ragged, tall: the last ten have 20 k - 60 k rows) -- against float64, at the fp32 GEMM's error level."""
