@@ -65,7 +65,7 @@ def _scratch(M, Cc, like):
 
 
 # Split-precision GEMM (csrc/gemm_split.hip, avsep_op_linear_split_ex) for every Linear forward / activation-gradient GEMM whose
-# weight has N >= 512 and K >= 512 -- the rule of the inference forward.  OFF by default: the cfg4 step is 7.5 % faster with it
+# weight has N >= 512 and K >= 512 -- the rule of the inference forward.  OFF by default for the FORWARD GEMMs: the cfg4 step is 7.5 % faster with it
 # (profiles/r04_ab_train_split_gemm.txt) and the GEMM is as close to float64 as the fp32 MFMA one
 # (profiles/r04_gemm_split_error_stats.txt), but its roundings are DIFFERENT ones, so other pre-activations fall on the other
 # side of a ReLU's kink than in the reference's fp32 run: 4 of the 330 cfg4 gradient tensors (linear1.weight / norm2 of two
@@ -73,14 +73,17 @@ def _scratch(M, Cc, like):
 # tests/test_train_gpu.py::test_train_forward_backward_matches_reference, which this round leaves as it is
 # (test_train_split_gemm_gradients pins what the switch does).  A module attribute, not an environment variable.
 SPLIT_GEMM = False
+# The activation-gradient GEMMs (dX = dY W) alone: they sit behind every ReLU decision of the step, so their rounding moves no
+# pre-activation across a kink -- the gradient gates hold unchanged with them on the split-precision kernels (ON by default).
+SPLIT_GEMM_DGRAD = True
 
 
-def _gemm(x, w, bias, res, rperiod, act, drop_p=0.0, drop_seed=0):
+def _gemm(x, w, bias, res, rperiod, act, drop_p=0.0, drop_seed=0, dgrad=False):
     """res rows + dropout(act(x [M,K] @ w[N,K]^T + bias)); K % 32 == 0; the dropout (train mode) runs in the GEMM epilogue."""
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    if SPLIT_GEMM and N >= 512 and K >= 512 and N % 4 == 0:
+    if (SPLIT_GEMM or (dgrad and SPLIT_GEMM_DGRAD)) and N >= 512 and K >= 512 and N % 4 == 0:
         _ck(_lib().avsep_op_linear_split_ex(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
                                             res.data_ptr() if res is not None else None, N, rperiod, y.data_ptr(), N, M, N, K,
                                             act, drop_p, drop_seed, _st(x)), "avsep_op_linear_split_ex")
@@ -367,7 +370,7 @@ class LinearFn(torch.autograd.Function):
             wt = _wt_table(w.device).get(w) if (BATCHED_WT and w.is_cuda and w.is_leaf) else None
             if wt is None:
                 wt = _transpose(w, Np)                                     # [K, Np] = w^T
-            dx = _gemm(dpp, wt, None, None, 0, ACT_NONE)                   # dY W
+            dx = _gemm(dpp, wt, None, None, 0, ACT_NONE, dgrad=True)       # dY W
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2]
 
         def param_grads():

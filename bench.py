@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--train-split-gemm", action="store_true",
                     help="train mode, A/B: split-precision GEMM for every Linear forward / activation-gradient GEMM with N, K >= 512 "
                          "(av_separation._train.SPLIT_GEMM; default: the fp32 MFMA GEMM)")
+    ap.add_argument("--train-fp32-dgrad", action="store_true",
+                    help="train mode, A/B: the fp32 MFMA GEMM also for the activation-gradient GEMMs (default: split-precision for N, K >= 512)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` block (short cfg3 / cfg5 forward and cfg4 training lines behind the default cfg2 run; "
                          "--no-cpu and --no-profile, the developer tools' flags, skip it too)")
@@ -723,7 +725,7 @@ def _also_train(av, dev, steps, rounds, warmup, split_gemm):
            "gflop_per_clip": round(gflop, 3), "frac": round(value * gflop / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
            "linear_gemm": ("split-precision (opt-in: av_separation._train.SPLIT_GEMM; 4 of 330 gradient tensors leave the 1.5x gate)"
-                           if split_gemm else "fp32 MFMA (default)")}
+                           if split_gemm else "fp32 MFMA forward, split-precision activation-gradient GEMMs (default)")}
     del model, opt
     torch.cuda.empty_cache()
     return out
@@ -759,6 +761,8 @@ def train_main(a, av, dev, dist, rank, world):
     from av_separation.losses import SeparationLoss
     if a.train_split_gemm:
         _train.SPLIT_GEMM = True
+    if a.train_fp32_dgrad:
+        _train.SPLIT_GEMM_DGRAD = False
     wl = WORKLOADS[a.workload]
     B = a.batch or wl["batch"]
     mk, dk = wl["model"], wl["data"]
