@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "avsep_op_act_fwd", "avsep_op_act_bwd", "avsep_op_mul_mixed", "avsep_op_add_rows", "avsep_read_stamps", "avsep_op_dropout", "avsep_op_dropout_add", "avsep_op_wgrad_scratch_floats", "avsep_op_wgrad", "avsep_op_wgrad_direct_scratch_floats",
     "avsep_op_wgrad_direct", "avsep_op_wgrad_bias_direct_scratch_floats", "avsep_op_wgrad_bias_direct", "avsep_op_transpose_many",
     "avsep_op_bn_stats", "avsep_op_bn_apply", "avsep_op_bn_bwd_sums", "avsep_op_bn_bwd_dx", "avsep_op_avgpool_fwd", "avsep_op_avgpool_bwd",
-    "avsep_op_interp_linear_bwd", "avsep_op_layernorm_bwd", "avsep_op_layernorm_bwd_res", "avsep_op_linear_drop", "avsep_op_linear_split_ex",
+    "avsep_op_interp_linear_bwd", "avsep_op_layernorm_bwd", "avsep_op_layernorm_bwd_res", "avsep_op_linear_drop", "avsep_op_linear_split_ex", "avsep_op_wgrad_direct_split",
     "avsep_op_relu_dropout_bwd",
 )
 
@@ -165,6 +165,7 @@ def _open(path):
     lib.avsep_op_layernorm_bwd_res.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp, i, i, f, p]
     lib.avsep_op_linear_drop.argtypes = [fp, i, fp, i, fp, fp, i, i, fp, i, i, i, i, f, u64, p]
     lib.avsep_op_linear_split_ex.argtypes = [fp, i, fp, i, fp, fp, i, i, fp, i, i, i, i, i, f, u64, p]
+    lib.avsep_op_wgrad_direct_split.argtypes = [fp, i, fp, i, fp, fp, i, i, i, i, p]
     lib.avsep_op_relu_dropout_bwd.argtypes = [fp, fp, fp, i64, f, p]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)     # AttributeError here = ABI drift between header and library

@@ -297,6 +297,15 @@ def _wgrad(dyt, xt):
     return dw
 
 
+# The weight gradients dW = dY^T X of weights with N, K >= 512 on the split-precision kernel (csrc/wgrad_split.hip).  Like the
+# activation-gradient GEMMs they sit behind every ReLU decision: the gradient gates hold unchanged (ON by default).
+SPLIT_GEMM_WGRAD = True
+
+
+def _split_wgrad(N, K):
+    return SPLIT_GEMM_WGRAD and N >= 512 and K >= 512
+
+
 def _wgrad_direct(dy, x):
     """dW [N, K] = dY^T X from the row-major tensors themselves (k-major wgrad kernel; N, K multiples of 4)."""
     R, N = dy.shape
@@ -305,6 +314,10 @@ def _wgrad_direct(dy, x):
     dw = torch.empty(N, K, device=dy.device)
     ns = lib.avsep_op_wgrad_direct_scratch_floats(N, K, R)
     scratch = torch.empty(ns, device=dy.device) if ns else None
+    if _split_wgrad(N, K):
+        _ck(lib.avsep_op_wgrad_direct_split(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), scratch.data_ptr() if ns else None,
+                                            N, K, R, 0, _st(dy)), "wgrad_direct_split")
+        return dw
     _ck(lib.avsep_op_wgrad_direct(dy.data_ptr(), N, x.data_ptr(), K, dw.data_ptr(), scratch.data_ptr() if ns else None,
                                   N, K, R, _st(dy)), "wgrad_direct")
     return dw
@@ -318,6 +331,10 @@ def _wgrad_bias_direct(dy, x):
     buf = torch.empty(N * K + N, device=dy.device)
     ns = lib.avsep_op_wgrad_bias_direct_scratch_floats(N, K, R)
     scratch = torch.empty(ns, device=dy.device) if ns else None
+    if _split_wgrad(N, K):
+        _ck(lib.avsep_op_wgrad_direct_split(dy.data_ptr(), N, x.data_ptr(), K, buf.data_ptr(), scratch.data_ptr() if ns else None,
+                                            N, K, R, 1, _st(dy)), "wgrad_direct_split")
+        return buf[:N * K].view(N, K), buf[N * K:]
     _ck(lib.avsep_op_wgrad_bias_direct(dy.data_ptr(), N, x.data_ptr(), K, buf.data_ptr(),
                                        scratch.data_ptr() if ns else None, N, K, R, _st(dy)), "wgrad_bias_direct")
     return buf[:N * K].view(N, K), buf[N * K:]

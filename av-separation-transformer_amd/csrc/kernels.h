@@ -165,6 +165,9 @@ int wgrad_slices(int N, int K, int R);
 hipError_t launch_wgrad(const float* dy, int ldy, const float* x, int ldx, float* out, int N, int K, int R, int slices,
                         bool with_bias, hipStream_t s, float* merged = nullptr, unsigned* counters = nullptr);
 int wgrad_tiles(int N, int K, int R);
+// the same on the split-precision bf16 pipe (wgrad_split.hip): 64 x 64 tiles, the slices / output layout of launch_wgrad
+hipError_t launch_wgrad_split(const float* dy, int ldy, const float* x, int ldx, float* out, int N, int K, int R, int slices,
+                              bool with_bias, hipStream_t s);
 const char* gemm_instance_name(const GemmParams& p);
 bool gemm_ln_supported(int K);                          // can launch_gemm() fuse a LayerNorm over K columns?   // template instance launch_gemm() will pick
 

@@ -177,6 +177,26 @@ int avsep_op_wgrad_bias_direct(const float* dy, int ldy, const float* x, int ldx
   return AVSEP_OK;
 }
 
+// avsep_op_wgrad_direct / avsep_op_wgrad_bias_direct on the split-precision bf16 pipe (wgrad_split.hip) where the fp32 plan takes
+// its 64 x 64 tile (N*K / 4096 >= 128 tiles, or >= 64 with R >= 2048); the fp32 kernel otherwise.  Same scratch, same slices,
+// the bias gradient bit-identical to the fp32 op's.  with_bias: dwb = [N*K weight gradients][N bias gradients].
+int avsep_op_wgrad_direct_split(const float* dy, int ldy, const float* x, int ldx, float* dwb, float* scratch, int N, int K, int R,
+                                int with_bias, void* stream) {
+  if (!dy || !x || !dwb || N <= 0 || K <= 0 || R <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if ((N & 3) || (K & 3) || (ldy & 3) || (ldx & 3))
+    return fail(AVSEP_EINVAL, "wgrad_direct_split needs N, K and both row strides to be multiples of 4");
+  const int sl = wgrad_slices(N, K, R);
+  const bool bias = with_bias != 0;
+  const bool tile64 = wgrad_tiles(N, K, R) == ((N + 63) / 64) * ((K + 63) / 64);
+  const size_t per = (size_t)N * K + (bias ? N : 0);
+  float* dst = sl > 1 ? scratch : dwb;
+  if (sl > 1 && !scratch) return fail(AVSEP_EINVAL, "wgrad_direct_split needs the scratch floats of the fp32 op");
+  if (tile64) TCK(launch_wgrad_split(dy, ldy, x, ldx, dst, N, K, R, sl, bias, S(stream)));
+  else TCK(launch_wgrad(dy, ldy, x, ldx, dst, N, K, R, sl, bias, S(stream)));
+  if (sl > 1) TCK(launch_sum_slices(scratch, dwb, sl, per, S(stream)));
+  return AVSEP_OK;
+}
+
 #ifdef AVSEP_DEV   // in-launch slice merge: bit-identical, measured 12 % SLOWER on the training step (profiles/r03_ab_wgrad_merged.txt)
 int64_t avsep_op_wgrad_tiles(int N, int K, int R) { return wgrad_tiles(N, K, R); }
 

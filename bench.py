@@ -336,6 +336,8 @@ def main():
                          "(av_separation._train.SPLIT_GEMM; default: the fp32 MFMA GEMM)")
     ap.add_argument("--train-fp32-dgrad", action="store_true",
                     help="train mode, A/B: the fp32 MFMA GEMM also for the activation-gradient GEMMs (default: split-precision for N, K >= 512)")
+    ap.add_argument("--train-fp32-wgrad", action="store_true",
+                    help="train mode, A/B: the fp32 MFMA weight-gradient kernel everywhere (default: split-precision for N, K >= 512)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` block (short cfg3 / cfg5 forward and cfg4 training lines behind the default cfg2 run; "
                          "--no-cpu and --no-profile, the developer tools' flags, skip it too)")
@@ -763,6 +765,8 @@ def train_main(a, av, dev, dist, rank, world):
         _train.SPLIT_GEMM = True
     if a.train_fp32_dgrad:
         _train.SPLIT_GEMM_DGRAD = False
+    if a.train_fp32_wgrad:
+        _train.SPLIT_GEMM_WGRAD = False
     wl = WORKLOADS[a.workload]
     B = a.batch or wl["batch"]
     mk, dk = wl["model"], wl["data"]

@@ -368,6 +368,14 @@ int avsep_op_linear_drop(const float* x, int lda, const float* w, int ldw, const
 int avsep_op_linear_split_ex(const float* x, int lda, const float* w, int ldw, const float* bias, const float* residual,
                              int ldr, int rperiod, float* y, int ldc, int M, int N, int K, int act, float drop_p,
                              uint64_t drop_seed, void* stream);
+/* avsep_op_wgrad_direct (with_bias = 0: dwb = N*K floats) / avsep_op_wgrad_bias_direct (with_bias = 1: dwb = N*K + N floats) on
+ * the split-precision kernels (csrc/wgrad_split.hip): dW = dY^T X with both operands cut into three bf16 terms on their way to
+ * LDS and transposed by the LDS read; the bias gradient is the fp32 op's, bit for bit.  Scratch: the fp32 op's
+ * (avsep_op_wgrad_direct_scratch_floats / avsep_op_wgrad_bias_direct_scratch_floats).  Problems whose fp32 plan takes the
+ * 32 x 32 tile run the fp32 kernel.  The training step uses it for weights with N, K >= 512 (av_separation/_train.py;
+ * nn.Linear backward, /root/reference/src/av_separation/model.py:38-60). */
+int avsep_op_wgrad_direct_split(const float* dy, int ldy, const float* x, int ldx, float* dwb, float* scratch, int N, int K, int R,
+                                int with_bias, void* stream);
 /* backward of y = dropout(relu(z)) from y alone: dx = y > 0 ? dy / (1 - p) : 0 */
 int avsep_op_relu_dropout_bwd(const float* dy, const float* y, float* dx, int64_t n, float p, void* stream);
 

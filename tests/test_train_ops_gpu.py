@@ -212,6 +212,43 @@ def test_interp_fn_backward_is_the_adjoint_of_f_interpolate(dev, B, N, T, d):
     assert _rel(xd.grad.cpu(), xr.grad) < 3e-6
 
 
+@pytest.mark.parametrize("R,N,K", [(4016, 512, 512), (4016, 1536, 512), (4016, 2048, 512), (4016, 512, 2048), (3990, 516, 1028),
+                                   (8032, 1536, 512), (100, 2048, 2048), (33, 512, 512), (1200, 64, 288)])
+def test_wgrad_direct_split_against_float64(dev, R, N, K):
+    """The split-precision weight gradient (csrc/wgrad_split.hip: both operands cut into three bf16 terms on their way to LDS,
+    transposed by the LDS read, six bf16 MFMA products per fp32 product) against float64 at the fp32 kernel's error level -- at
+    most 2x its measured error + 2e-7 on the same operands -- with ragged row counts / tile edges, sliced and unsliced row
+    ranges, with and without the bias gradient, which must be the fp32 op's bit for bit.  (1200, 64, 288) takes the fp32
+    plan's 32-wide tile: the op then runs the fp32 kernel itself.)"""
+    import ctypes as C
+    from av_separation import _native
+    lib = _native.load()
+    g = torch.Generator(device="cpu").manual_seed(R + N + K)
+    dy = torch.randn(R, N, generator=g).to(dev)
+    x = (torch.randn(R, K, generator=g) * 1.5 + 0.2).to(dev)
+    ref_w = (dy.double().T @ x.double())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ns = lib.avsep_op_wgrad_bias_direct_scratch_floats(N, K, R)
+    scratch = torch.empty(max(ns, 1), device=dev)
+    out0 = torch.full((N * K + N,), float("nan"), device=dev)
+    assert lib.avsep_op_wgrad_bias_direct(dy.data_ptr(), N, x.data_ptr(), K, out0.data_ptr(), scratch.data_ptr() if ns else None,
+                                          N, K, R, st) == 0, lib.avsep_last_error()
+    sc = float(ref_w.abs().max())
+    e0 = float((out0[:N * K].view(N, K).double() - ref_w).abs().max()) / sc
+    for with_bias in (1, 0):
+        out1 = torch.full((N * K + N,), float("nan"), device=dev)
+        assert lib.avsep_op_wgrad_direct_split(dy.data_ptr(), N, x.data_ptr(), K, out1.data_ptr(), scratch.data_ptr() if ns else None,
+                                               N, K, R, with_bias, st) == 0, lib.avsep_last_error()
+        gw = out1[:N * K].view(N, K)
+        assert torch.isfinite(gw).all()
+        e1 = float((gw.double() - ref_w).abs().max()) / sc
+        assert e1 < 2.0 * e0 + 2e-7 and e1 < 3e-7 * math.sqrt(R) + 1e-6, (with_bias, e0, e1)
+        if with_bias:
+            assert torch.equal(out1[N * K:], out0[N * K:])
+        else:
+            assert torch.isnan(out1[N * K:]).all()                  # nothing written behind the weight gradients
+
+
 @pytest.mark.parametrize("R,N,K", [(4016, 512, 512), (4016, 1536, 512), (4016, 2048, 512), (4016, 512, 2048),
                                    (4016, 512, 128), (1200, 64, 288), (37, 772, 1024)])
 def test_wgrad_bias_direct_against_float64(dev, R, N, K):
