@@ -833,6 +833,11 @@ def train_main(a, av, dev, dist, rank, world):
                                f"clip 1.0, Adam lr 3e-4",
                    "batch_per_gpu": B, "global_batch": world * B, "gflop_per_clip": round(gflop_clip, 3),
                    "parameters": nparam, "launch": "eager, one launch per op",
+                   "gemm": ("Linear layers with N, K >= 512: forward GEMMs " +
+                            ("split-precision (opt-in)" if _train.SPLIT_GEMM else "fp32 MFMA") + ", activation-gradient GEMMs " +
+                            ("split-precision" if (_train.SPLIT_GEMM or _train.SPLIT_GEMM_DGRAD) else "fp32 MFMA") + ", weight gradients " +
+                            ("split-precision" if _train.SPLIT_GEMM_WGRAD else "fp32 MFMA") +
+                            " (split-precision = six bf16 MFMA products per fp32 product, fp32-equivalent); everything else fp32 MFMA"),
                    "parallelism": f"dp{world} (bucketed gradient all-reduce + cross-rank BatchNorm statistics)"
                    if world > 1 else "single rank"},
         "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward FLOPs)", "achieved": round(tf, 3),
