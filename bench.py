@@ -621,7 +621,7 @@ def main():
         print(json.dumps(out))
 
 
-def also_forward(av, dev, name, steps=5, rounds=3, warmup=3):
+def also_forward(av, dev, name, steps=20, rounds=5, warmup=4):
     """A short line for another BASELINE forward config inside the default run: the workload's own model and per-GPU batch,
     SyntheticAVDataset clips, hipGraph replay, `rounds` rounds of EXACTLY `steps` steps with two steps in flight (median
     round) and the same steps one at a time.  Both in-flight slots hold the same clips (dataset generation is host time)."""
