@@ -846,6 +846,23 @@ def test_split_precision_can_be_turned_off_per_model(golden, dev):
     assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
 
 
+def test_graph_capture_as_the_first_forward_of_a_process():
+    """A fresh process whose FIRST forward is a hipGraph capture (tools/graph_first_check.py): the kernels that raise their
+    dynamic-LDS ceiling on their first launch (the fused conv stack, the 256 x 128 split-precision GEMM) do so inside the
+    capture; the replayed outputs equal the eager forward's, for a d_model = 512 and a d_model = 256 model."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.pop("AVSEP_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graph_first_check.py")], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if "graph-first == eager" in ln]
+    assert len(lines) == 2 and all("True" in ln for ln in lines), r.stdout
+
+
 def test_op_linear_split_random_shapes(lib, dev):
     """40 random (M, N, K, activation, residual) problems through the split-precision GEMM -- whichever of its three kernels the
     shape selects (tiny, ragged, tall: the last ten have 20 k - 60 k rows) -- against float64, at the fp32 GEMM's error level."""
