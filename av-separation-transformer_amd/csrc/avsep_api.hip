@@ -1520,6 +1520,27 @@ int avsep_op_linear_split(const float* x, const float* w, const float* bias, con
   return AVSEP_OK;
 }
 
+int avsep_op_split_planes(const float* x, int ld, uint16_t* planes, int64_t rows, int M, int K, void* stream) {
+  if (!x || !planes || M <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || ld % 4 || ld < K || rows < M) return fail(AVSEP_EINVAL, "K must be a multiple of 32, ld of 4 and >= K, rows >= M");
+  HCK(launch_split_planes(x, ld, planes, rows, M, K, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_linear_planes(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* bias,
+                           const float* residual, float* y, uint16_t* yp, int64_t y_rows, int M, int N, int K, int act,
+                           void* stream) {
+  if (!xp || !wp || (!y && !yp) || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || N % 4) return fail(AVSEP_EINVAL, "K must be a multiple of 32 and N of 4");
+  if (act < 0 || act > 3) return fail(AVSEP_EINVAL, "unknown activation");
+  GemmParams p = linear_params(nullptr, K, nullptr, K, bias, y, N, M, N, act);
+  p.Ap = xp; p.a_rows = x_rows; p.Wp = wp; p.w_rows = w_rows; p.Cp = yp; p.c_rows = y_rows;
+  if (residual) { p.R = residual; p.ldr = N; }
+  if (!gemm_planes_supported(p)) return fail(AVSEP_EINVAL, "shape / epilogue not supported by the pre-split GEMM");
+  HCK(launch_gemm_planes(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
 #ifdef AVSEP_DEV
 int avsep_op_linear_pair(const float* x0, const float* w0, const float* b0, const float* r0, const float* gamma0,
                          const float* beta0, float* y0, int M0, const float* x1, const float* w1, const float* b1,

@@ -130,6 +130,14 @@ struct GemmParams {
   // TAPS3: at least Kt floats of zeros.  A tap outside its sequence (t - 1 < 0, t + 1 >= T) reads THIS row instead of being
   // loaded from a valid address and zeroed by four selects per float4 on the way to LDS: the same zeros without the VALU.
   const float* zeros;
+  // Pre-split operands (gemm_planes.hip, round 5): the three bf16 terms of A / W as "P32" plane buffers -- bf16 [K/32][3][rows][32],
+  // element (m, k) of term t at ((k/32 * 3 + t) * rows + m) * 32 + k % 32 -- cut ONCE by the operand's producer instead of in every
+  // column tile of every GEMM; a_rows / w_rows = the buffers' row counts (>= M / N).  Cp (c_rows): the result written as the
+  // planes of the NEXT GEMM's A operand (bias + activation only), instead of or beside the fp32 C.
+  const unsigned short* Ap;
+  const unsigned short* Wp;
+  unsigned short* Cp;
+  long long a_rows, w_rows, c_rows;
 #ifdef AVSEP_DEV
   struct Alt {
     const float *A, *W, *bias, *R, *ln_gamma, *ln_beta;
@@ -153,6 +161,11 @@ hipError_t launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, hipStrea
 bool gemm_split_supported(const GemmParams& p);
 hipError_t launch_gemm_split(GemmParams p, hipStream_t s);
 const char* gemm_split_instance_name(const GemmParams& p);
+// the same GEMM on PRE-SPLIT operands (gemm_planes.hip): GemmParams::Ap / Wp (/ Cp), staged by LDS-DMA; same bits as the kernels above
+bool gemm_planes_supported(const GemmParams& p);
+hipError_t launch_gemm_planes(GemmParams p, hipStream_t s);
+// x [M][ld] fp32 -> its three bf16 terms in P32 plane format (rows >= M: the buffer's row count); K % 32 == 0, ld % 4 == 0
+hipError_t launch_split_planes(const float* x, int ld, unsigned short* planes, long long rows, int M, int K, hipStream_t s);
 // split-precision attention (attention_split.hip): dh = 64, fp32 in / out, QK^T and PV as six bf16 MFMA products per fp32 product
 bool attention_split_supported(int dh, int Lq, int Lk);
 hipError_t launch_attention_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,

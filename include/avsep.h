@@ -145,6 +145,18 @@ int avsep_op_linear(const float* x, const float* w, const float* bias, const flo
  * (tests/test_gpu_parity.py::test_op_linear_split_precision); NOT bit-identical to avsep_op_linear. */
 int avsep_op_linear_split(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int N,
                           int K, int act, void* stream);
+/* The same GEMM on PRE-SPLIT operands (csrc/gemm_planes.hip, round 5).  avsep_op_split_planes cuts x (M, K; row stride ld floats)
+ * into its three bf16 terms ("planes": bf16 [K/32][3][rows][32], element (m, k) of term t at ((k/32 * 3 + t) * rows + m) * 32 + k % 32;
+ * rows >= M is the buffer's row count, 6 * rows * K bytes) -- what the forward's producers (weight packer, LayerNorm, GEMM and
+ * attention epilogues) write once per element.  avsep_op_linear_planes multiplies two such operands, staging them by LDS-DMA:
+ * y = act(x w^T + bias) + residual as fp32 (y, may be null) and / or as the planes of the next GEMM's operand (yp / y_rows, may be
+ * null; N % 32 == 0, no residual).  Same six products in the same order as avsep_op_linear_split: bit-identical to it on the
+ * fp32 operands the planes were cut from.  A term of +-inf is NaN (inf - inf): non-finite inputs give non-finite outputs, but an
+ * inf may come out as NaN.  nn.Linear, /root/reference/src/av_separation/model.py:48-52,155-161,194-199. */
+int avsep_op_split_planes(const float* x, int ld, uint16_t* planes, int64_t rows, int M, int K, void* stream);
+int avsep_op_linear_planes(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* bias,
+                           const float* residual, float* y, uint16_t* yp, int64_t y_rows, int M, int N, int K, int act,
+                           void* stream);
 int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                        float eps, void* stream);
 /* y = act(LayerNorm(x) W^T + b), the pair every pre-norm block of the model is made of (model.py:48-52 norm_first
