@@ -80,7 +80,8 @@ template <int QT>
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                                  int ldk, const float* __restrict__ v, int ldv,
                                                                  float* __restrict__ o, int ldo, int nhead, int Lq, int Lk,
-                                                                 int nqt, float qscale) {
+                                                                 int nqt, float qscale, unsigned short* __restrict__ op,
+                                                                 long long o_rows, float h2_scale) {
   constexpr int DH = 64;
   __shared__ __attribute__((aligned(16))) char lds[2 * AS_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -280,8 +281,43 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float* __
     l = rows_sum(l);
     const float inv = 1.0f / l;
     const int qo = (qw * QT + t) * 16 + c;
-    if (qo < Lq) {
-      // lane (c, g) holds O[qo][16 blk + 4 g + r] in acc[t][blk][r]
+    // lane (c, g) holds O[qo][16 blk + 4 g + r] in acc[t][blk][r]
+    if (op) {                                           // block-uniform: the planes of the out-projection's A operand (gemm_planes.hip)
+      // blocks 2u, 2u + 1 = one 32-column chunk; v_permlane16_swap leaves lane g with 8 consecutive columns of it (the plane
+      // epilogue of gemm_planes.hip): one 16-byte slot per term.  Every lane takes part in the swap; rows >= Lq store nothing.
+      const size_t ts = (size_t)o_rows * 64;
+      const int slot = ((g & 1) << 1) | (g >> 1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float lo4[4], hi4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[t][2 * u][r] * inv), __float_as_uint(acc[t][2 * u + 1][r] * inv), false, false);
+          lo4[r] = __uint_as_float(sw[0]);
+          hi4[r] = __uint_as_float(sw[1]);
+        }
+        if (h2_scale > 0.0f) {                        // block-uniform: two fp16 terms (gemm_h2.hip), scaled by the site's power of two
+          unsigned hh[4], ll[4];
+          split_pair_h2(f32x2{lo4[0], lo4[1]} * h2_scale, hh[0], ll[0]);
+          split_pair_h2(f32x2{lo4[2], lo4[3]} * h2_scale, hh[1], ll[1]);
+          split_pair_h2(f32x2{hi4[0], hi4[1]} * h2_scale, hh[2], ll[2]);
+          split_pair_h2(f32x2{hi4[2], hi4[3]} * h2_scale, hh[3], ll[3]);
+          if (qo < Lq) {
+            char* dst = reinterpret_cast<char*>(op) + (((size_t)(2 * h + u) * 2) * o_rows + (size_t)b * Lq + qo) * 64 + slot * 16;
+            *reinterpret_cast<u32x4*>(dst) = vec4(hh);
+            *reinterpret_cast<u32x4*>(dst + ts) = vec4(ll);
+          }
+          continue;
+        }
+        const Planes w = split8(f32x4{lo4[0], lo4[1], lo4[2], lo4[3]}, f32x4{hi4[0], hi4[1], hi4[2], hi4[3]});
+        if (qo < Lq) {
+          char* dst = reinterpret_cast<char*>(op) + (((size_t)(2 * h + u) * 3) * o_rows + (size_t)b * Lq + qo) * 64 + slot * 16;
+          *reinterpret_cast<u32x4*>(dst) = vec4(w.hi);
+          *reinterpret_cast<u32x4*>(dst + ts) = vec4(w.mid);
+          *reinterpret_cast<u32x4*>(dst + 2 * ts) = vec4(w.lo);
+        }
+      }
+    } else if (qo < Lq) {
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk)
         *reinterpret_cast<f32x4*>(ob + (size_t)qo * ldo + 16 * blk + 4 * g) =
@@ -295,12 +331,15 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float* __
 bool attention_split_supported(int dh, int Lq, int Lk) { return dh == 64 && Lq > 0 && Lk > 0; }
 
 hipError_t launch_attention_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
-                                  int B, int nhead, int dh, int Lq, int Lk, float qscale, hipStream_t s) {
+                                  int B, int nhead, int dh, int Lq, int Lk, float qscale, hipStream_t s, unsigned short* op,
+                                  long long o_rows, int h2, int h2_exp) {
   if (B <= 0 || nhead <= 0 || !attention_split_supported(dh, Lq, Lk)) return hipErrorInvalidValue;
+  if (op && o_rows < (long long)B * Lq) return hipErrorInvalidValue;
   if ((ldq | ldk | ldv | ldo) & 3) return hipErrorInvalidValue;    // float4 row alignment
   constexpr int QT = 2;
   const int nqt = (Lq + 15) / 16, nqw = (nqt + QT - 1) / QT;
   const dim3 grid((unsigned)((long)B * nhead * ((nqw + 3) / 4)));
-  hipLaunchKernelGGL((attention_split_kernel<QT>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt, qscale);
+  hipLaunchKernelGGL((attention_split_kernel<QT>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt, qscale, op, o_rows,
+                     h2 ? ldexpf(1.0f, h2_exp) : 0.0f);
   return hipGetLastError();
 }

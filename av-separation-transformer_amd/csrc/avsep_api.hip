@@ -5,6 +5,7 @@
 #include "../../include/avsep.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -70,6 +71,11 @@ struct Workspace {   // all float*, carved from the caller's buffer
   float *act1, *act2, *act3, *pool, *v_x, *v_ln, *v_qkv, *v_att, *v_ffn, *v_up;
   float *kv_all, *f_q;
   float* taps;
+  // Pre-split GEMM operands (gemm_planes.hip, round 5): the bf16 planes of the tensors that only GEMMs read -- LayerNorm outputs,
+  // attention outputs, FFN hidden activations, the resized visual stream -- written by their producers INSTEAD of the fp32 tensor.
+  // rows_a / rows_v: row counts of the audio-length / frame-length buffers (the planes' slab height; a half-batch view keeps them)
+  unsigned short *ln_p, *att_p, *ffn_p, *v_ln_p, *v_att_p, *v_ffn_p, *v_up_p;
+  long long rows_a, rows_v;
   size_t floats;
 };
 
@@ -115,6 +121,18 @@ struct avsep_ctx {
   // count, so every batch size of a model computes the same bits; d_model = 256 models keep the fp32 MFMA everywhere (their
   // GEMMs are latency-bound: 128 x 128 tiles would leave the chip empty).
   bool split_gemm = true;
+  // ... and with operands PRE-SPLIT (gemm_planes.hip; round 5): the weights' planes are cut once by avsep_finalize_weights (keyed by
+  // the packed fp32 weight), the activations' by their producers, whenever a stage has enough rows for the 256 x 128 kernel
+  // (planes_rows()).  Same bits as the in-flight split, so the choice may look at the row count.
+  bool use_planes = true;
+  std::unordered_map<const float*, unsigned short*> wplanes;
+  std::vector<std::pair<const float*, std::pair<int, int>>> wplane_sites;   // (weight, (N, K)) in arena order
+  // Two fp16 terms, three products (gemm_h2.hip; round 5): the GEMM sites whose A operand has a STATIC bound from the weights alone
+  // (LayerNorm outputs, act(LayerNorm(x) W^T + b), self-attention outputs).  Per site: the weight's H2 planes (row n scaled by
+  // 2^ew[n]), the A operand's exponent eA, cscale[n] = 2^-(eA + ew[n]).  A rule on the model and the weight, never on the batch.
+  struct H2Site { unsigned short* wp; float* cscale; int* ew; float* l2; int eA, N, K; };
+  std::unordered_map<const float*, H2Site> h2;
+  bool use_h2 = true;
   // streams / events for the audio || visual fork-join and graph replay
   int device = 0;                                  // the device the context (arena, streams, events, graphs) lives on
   hipStream_t side = nullptr;                      // eager forwards: the visual branch's stream
@@ -186,6 +204,41 @@ void layout_arena(avsep_ctx* c, F&& take) {
   c->d_w1 = take((size_t)2 * d * d); c->d_b1 = take(2 * d);
   c->d_w2 = take((size_t)S * c->F * 2 * d); c->d_b2 = take((size_t)S * c->F);
   c->zeros = take((size_t)std::max(c->Fp, c->d) + 64);   // GemmParams::zeros (zeroed by avsep_create)
+  // planes of the weights the split-precision rule sends to the bf16 pipe (d_model >= 512: N >= 512 and K >= 512), PLAIN A operand
+  c->wplanes.clear();
+  c->wplane_sites.clear();
+  if (d >= 512) {
+    auto wp = [&](const float* w, int n, int k) {
+      if (n < 512 || k < 512 || (k & 31)) return;
+      float* q = take(((size_t)n * k * 3 + 1) / 2);                  // 6 bytes per weight
+      if (w) {
+        c->wplanes[w] = reinterpret_cast<unsigned short*>(q);
+        c->wplane_sites.push_back({w, {n, k}});
+      }
+    };
+    for (auto* v : {&c->a_layers, &c->v_layers})
+      for (auto& L : *v) { wp(L.wqkv, 3 * d, d); wp(L.wo, d, d); wp(L.w1, 4 * d, d); wp(L.w2, d, 4 * d); }
+    wp(c->wkv_all, c->Lf * 2 * d, d);
+    for (auto& L : c->f_layers) { wp(L.wq, d, d); wp(L.wo, d, d); wp(L.w1, 4 * d, d); wp(L.w2, d, 4 * d); }
+    wp(c->d_w1, 2 * d, d);
+    wp(c->d_w2, S * c->F, 2 * d);
+    c->h2.clear();
+    auto h2 = [&](const float* w, int n, int k) {
+      if (n < 512 || k < 512 || (k & 31)) return;
+      avsep_ctx::H2Site t{};
+      t.wp = reinterpret_cast<unsigned short*>(take((size_t)n * k));           // 4 bytes per weight
+      t.cscale = take(n);
+      t.ew = reinterpret_cast<int*>(take(n));
+      t.l2 = take(n);
+      t.N = n; t.K = k;
+      if (w) c->h2[w] = t;
+    };
+    for (auto* v : {&c->a_layers, &c->v_layers})
+      for (auto& L : *v) { h2(L.wqkv, 3 * d, d); h2(L.wo, d, d); h2(L.w1, 4 * d, d); h2(L.w2, d, 4 * d); }
+    for (auto& L : c->f_layers) { h2(L.wq, d, d); h2(L.w1, 4 * d, d); h2(L.w2, d, 4 * d); }   // wo: cross-attention output, no static bound
+    h2(c->d_w1, 2 * d, d);
+    h2(c->d_w2, S * c->F, 2 * d);
+  }
   c->lnx.clear();
   if (c->use_lnx) {
     auto site = [&](const float* w, int n) {
@@ -327,6 +380,15 @@ size_t carve(const avsep_ctx* c, Workspace* w, float* base, int B, int T, int N,
   t.v_up = take(Ma * d);
   t.kv_all = take(Ma * (size_t)c->Lf * 2 * d);
   t.f_q = take(Ma * d);
+  if (d >= 512 && !(d & 31)) {                                           // 6 bytes per element = 1.5 floats
+    auto planes = [&](size_t n) { return reinterpret_cast<unsigned short*>(take((n * 3 + 1) / 2)); };
+    t.ln_p = planes(Ma * d); t.att_p = planes(Ma * d); t.ffn_p = planes(Ma * 4 * d);
+    t.v_ln_p = planes(Mv * d); t.v_att_p = planes(Mv * d); t.v_ffn_p = planes(Mv * 4 * d);
+    t.v_up_p = planes(Ma * d);
+    if (!base) t.ln_p = t.att_p = t.ffn_p = t.v_ln_p = t.v_att_p = t.v_ffn_p = t.v_up_p = nullptr;
+  }
+  t.rows_a = (long long)Ma;
+  t.rows_v = (long long)Mv;
   if (c->keep_taps) {
     // generous bound: every tap is at most one (M, d)-sized activation or one conv activation
     size_t n = (size_t)(2 + 2 * c->Le + c->Lf + 3) * align_up(Ma * d > Mv * d ? Ma * d : Mv * d, 64);
@@ -388,6 +450,26 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
   if (p.R) bytes += (p.rperiod > 0 ? (double)p.rperiod : rows) * p.N * 4;
   if (p.C2) bytes += (double)p.M * p.F * 4;
   static const bool no_taps = dev_env("AVSEP_SPLIT_NO_TAPS") != nullptr, no_mask = dev_env("AVSEP_SPLIT_NO_MASK") != nullptr;   // developer A/B
+  if (p.h2) {                                                       // two fp16 terms, three products (gemm_h2.hip): the caller asked h2_site() first
+    GemmParams pp = p;
+    auto it = c->h2.find(p.W);
+    if (it == c->h2.end() || !c->use_h2) return fail(AVSEP_EINTERNAL, "two-term GEMM: not a site of it");
+    pp.Wp = it->second.wp; pp.w_rows = p.N; pp.cscale = it->second.cscale;
+    pp.split_t2_min = 48;
+    if (!gemm_h2_supported(pp)) return fail(AVSEP_EINTERNAL, "two-term GEMM: unsupported problem");
+    bytes = rows * k * 4 + (double)p.N * k * 4 + (p.C ? rows * p.N * 4 * (p.C2 ? 2 : 1) : 0.0) + (p.Cp ? rows * p.N * 4 : 0.0) +
+            (p.R ? rows * p.N * 4 : 0.0) + (p.C2 ? (double)p.M * p.F * 4 : 0.0);
+    return profiled(c, gemm_h2_instance_name(pp), flops, bytes, s, [&] { return launch_gemm_h2(pp, s); });
+  }
+  if (p.Ap || p.Cp) {                                               // pre-split operands: the caller asked planes_rows() first
+    GemmParams pp = p;
+    auto it = c->wplanes.find(p.W);
+    if (it == c->wplanes.end()) return fail(AVSEP_EINTERNAL, "pre-split GEMM: the weight has no planes");
+    pp.Wp = it->second; pp.w_rows = p.N;
+    if (!gemm_planes_supported(pp)) return fail(AVSEP_EINTERNAL, "pre-split GEMM: unsupported problem");
+    bytes += (p.Ap ? rows * k * 2 : 0.0) + (double)p.N * k * 2 + (p.Cp ? rows * p.N * (p.C ? 6.0 : 2.0) : 0.0);   // 6 bytes per plane element
+    return profiled(c, gemm_planes_instance_name(), flops, bytes, s, [&] { return launch_gemm_planes(pp, s); });
+  }
   if (c->split_gemm && c->d >= 512 && p.N >= 512 && p.K >= 512 && gemm_split_supported(p) &&       // see avsep_ctx::split_gemm
       !(no_taps && p.amode == AMODE_TAPS3) && !(no_mask && p.C2)) {
     GemmParams ps = p;
@@ -396,12 +478,40 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
   }
   return profiled(c, c->prof_on ? gemm_instance_name(p) : "", flops, bytes, s, [&] { return launch_gemm(p, s); });
 }
+// Does a stage with M rows run its GEMMs on PRE-SPLIT operands (gemm_planes.hip)?  The planes kernel has the 256 x 128 tile only:
+// from 48 of its tiles on at the narrowest weight (N = 512: 4 column tiles) -- the threshold run_gemm gives the in-flight 256 x 128
+// kernel (split_t2_min); below it the 64 x 64 in-flight kernel fills the chip better.  Both compute the same bits, so the choice
+// may look at the row count.  Debug taps read fp32 tensors: a tapped forward takes the in-flight path.
+bool planes_rows(const avsep_ctx* c, const Workspace& w, int M) {
+  static const bool off = dev_env("AVSEP_NO_PLANES") != nullptr;                                    // developer A/B
+  return c->use_planes && !off && c->split_gemm && c->d >= 512 && !(c->d & 31) && w.ln_p && !c->keep_taps && !c->wplanes.empty() &&
+         (long)((M + 255) / 256) * 4 >= 48;
+}
+// The two-term fp16 site of weight W (gemm_h2.hip), or null: the model / the weight is not on that path.  Never looks at a row count.
+const avsep_ctx::H2Site* h2_site(const avsep_ctx* c, const Workspace& w, const float* W) {
+  if (!c->use_h2 || !c->split_gemm || c->d < 512 || !w.ln_p) return nullptr;
+  auto it = c->h2.find(W);
+  return it == c->h2.end() ? nullptr : &it->second;
+}
+int run_layernorm_h2(avsep_ctx* c, const float* x, const float* g, const float* b, unsigned short* yp, long long rows, int M, int d,
+                     int e, hipStream_t s) {
+  return profiled(c, layernorm_planes_instance_name(d, 2), 8.0 * M * d, 2.0 * M * d * 4, s,
+                  [&] { return launch_layernorm_h2(x, g, b, yp, rows, M, d, 1e-5f, e, s); });
+}
+int run_layernorm_planes(avsep_ctx* c, const float* x, const float* g, const float* b, unsigned short* yp, long long rows, int M, int d,
+                         hipStream_t s) {
+  return profiled(c, layernorm_planes_instance_name(d, 1), 8.0 * M * d, 2.5 * M * d * 4, s,
+                  [&] { return launch_layernorm_planes(x, g, b, yp, rows, M, d, 1e-5f, s); });
+}
 int run_layernorm(avsep_ctx* c, const float* x, const float* g, const float* b, float* y, int M, int d, hipStream_t s) {
   return profiled(c, layernorm_instance_name(d, false), 8.0 * M * d, 2.0 * M * d * 4, s,
                   [&] { return launch_layernorm(x, g, b, y, M, d, 1e-5f, s); });
 }
+bool attention_is_split(const avsep_ctx* c, int Lq, int Lk);
+// op (o_rows): the output as the planes of the out-projection's A operand instead of fp32 `o` (only where attention_is_split())
 int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
-                  int ldo, int B, int Lq, int Lk, hipStream_t s) {
+                  int ldo, int B, int Lq, int Lk, hipStream_t s, unsigned short* op = nullptr, long long o_rows = 0, int h2 = 0,
+                  int h2_exp = 0) {
   const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh;
   const double bytes = 4.0 * B * c->d * (2.0 * Lq + 2.0 * Lk);
   // split-precision attention (attention_split.hip): the models whose Linear layers run on the split-precision GEMM
@@ -409,10 +519,16 @@ int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk
   // The rule looks at the model and the sequence lengths only, never at the batch size.
   static const bool no_split_attn = dev_env("AVSEP_NO_SPLIT_ATTN") != nullptr;                       // developer A/B
   if (c->split_gemm && c->d >= 512 && Lk >= 128 && attention_split_supported(c->dh, Lq, Lk) && !no_split_attn)
-    return profiled(c, "attention_split_kernel<2>", flops, bytes, s,
-                    [&] { return launch_attention_split(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, 1.0f, s); });
+    return profiled(c, "attention_split_kernel<2>", flops, bytes, s, [&] {
+      return launch_attention_split(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, 1.0f, s, op, o_rows, h2, h2_exp);
+    });
+  if (op) return fail(AVSEP_EINTERNAL, "plane output asked of the fp32 attention kernel");
   return profiled(c, attention_instance_name(c->dh, Lq, Lk, B, c->h), flops, bytes, s,
                   [&] { return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, s); });
+}
+bool attention_is_split(const avsep_ctx* c, int Lq, int Lk) {
+  static const bool no_split_attn = dev_env("AVSEP_NO_SPLIT_ATTN") != nullptr;
+  return c->split_gemm && c->d >= 512 && Lk >= 128 && attention_split_supported(c->dh, Lq, Lk) && !no_split_attn;
 }
 
 GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
@@ -420,9 +536,18 @@ GemmParams linear_params(const float* A, int lda, const float* W, int K, const f
 
 // x += softmax(q k^T) v W_o^T + b_o: one launch for short sequences (attn_proj_kernel), else attention into `att` and the
 // projection GEMM with its residual epilogue
+// att_p (rows): with planes_rows(), the attention output goes to the projection as planes (split-precision attention only)
 int run_attention_proj(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* att,
-                       const float* wo, const float* bo, float* x, int B, int Lq, int Lk, hipStream_t s) {
+                       const float* wo, const float* bo, float* x, int B, int Lq, int Lk, hipStream_t s,
+                       unsigned short* att_p = nullptr, long long rows = 0, const avsep_ctx::H2Site* h2 = nullptr) {
   const int d = c->d, M = B * Lq;
+  if (att_p && attention_is_split(c, Lq, Lk)) {
+    RCK(run_attention(c, q, ldq, k, ldk, v, ldv, att, d, B, Lq, Lk, s, att_p, rows, h2 != nullptr, h2 ? h2->eA : 0));
+    GemmParams po = linear_params(nullptr, d, wo, d, bo, x, d, M, d, ACT_NONE);
+    po.Ap = att_p; po.a_rows = rows; po.h2 = h2 != nullptr;
+    po.R = x; po.ldr = d; po.rperiod = 0;
+    return run_gemm(c, po, s);
+  }
   if (attn_proj_supported(c->h, c->dh, Lk)) {
     const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh + 2.0 * M * (double)d * d;
     const double bytes = 4.0 * B * d * (1.0 * Lq + 2.0 * Lk) + 4.0 * d * d + 8.0 * M * d;
@@ -478,6 +603,31 @@ int run_ln_linear(avsep_ctx* c, const float* x, const float* g, const float* be,
   }
   RCK(run_layernorm(c, x, g, be, ln_buf, M, d, s));
   p.A = ln_buf;
+  return run_gemm(c, p, s);
+}
+
+// run_ln_linear on pre-split operands: LayerNorm writes the planes of its output into ln_p, the GEMM reads them; its result goes
+// to y (fp32) or, with yp, to the planes of the NEXT GEMM's operand (FFN-1 -> FFN-2, decoder layer 1 -> mask head)
+int run_ln_linear_planes(avsep_ctx* c, const float* x, const float* g, const float* be, unsigned short* ln_p, long long rows,
+                         const float* W, const float* bias, float* y, unsigned short* yp, int M, int N, int act, hipStream_t s) {
+  const int d = c->d;
+  RCK(run_layernorm_planes(c, x, g, be, ln_p, rows, M, d, s));
+  GemmParams p = linear_params(nullptr, d, W, d, bias, y, N, M, N, act);
+  p.Ap = ln_p; p.a_rows = rows;
+  p.Cp = yp; p.c_rows = rows;
+  return run_gemm(c, p, s);
+}
+
+// ... on two fp16 terms (gemm_h2.hip): `site` = h2_site(W); next = the site of the GEMM that consumes the plane output yp (its
+// static exponent scales the planes), null with y
+int run_ln_linear_h2(avsep_ctx* c, const float* x, const float* g, const float* be, unsigned short* ln_p, long long rows,
+                     const float* W, const float* bias, float* y, unsigned short* yp, const avsep_ctx::H2Site* site,
+                     const avsep_ctx::H2Site* next, int M, int N, int act, hipStream_t s) {
+  const int d = c->d;
+  RCK(run_layernorm_h2(c, x, g, be, ln_p, rows, M, d, site->eA, s));
+  GemmParams p = linear_params(nullptr, d, W, d, bias, y, N, M, N, act);
+  p.Ap = ln_p; p.a_rows = rows; p.h2 = 1;
+  if (yp) { p.Cp = yp; p.c_rows = rows; p.cp_scale = std::ldexp(1.0f, next->eA); }
   return run_gemm(c, p, s);
 }
 
@@ -591,8 +741,10 @@ int get_chain(avsep_ctx* c, const std::vector<EncLayerW>& layers, float* x, floa
 
 #endif  // AVSEP_DEV
 
+// plane buffers of one branch (null: the stage has too few rows for the pre-split GEMM, see planes_rows())
+struct BranchPlanes { unsigned short *ln, *att, *ffn; long long rows; bool h2; };   // h2: two fp16 terms (gemm_h2.hip)
 int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
-                  int Lseq, hipStream_t s);
+                  int Lseq, hipStream_t s, const BranchPlanes& bp);
 
 // every encoder layer of one branch, in place on x
 int encoder_layers(avsep_ctx* c, const std::vector<EncLayerW>& layers, const Workspace& w, bool audio, int B, int L,
@@ -610,8 +762,12 @@ int encoder_layers(avsep_ctx* c, const std::vector<EncLayerW>& layers, const Wor
                     chain_plan_flops(plan), chain_plan_bytes(plan), s, [&] { return launch_chain(plan, s); });
   }
 #endif
+  BranchPlanes bp{nullptr, nullptr, nullptr, 0, false};
+  const bool h2 = !layers.empty() && h2_site(c, w, layers[0].wqkv) != nullptr;                       // at EVERY row count: other bits
+  if (h2 || planes_rows(c, w, B * L))
+    bp = audio ? BranchPlanes{w.ln_p, w.att_p, w.ffn_p, w.rows_a, h2} : BranchPlanes{w.v_ln_p, w.v_att_p, w.v_ffn_p, w.rows_v, h2};
   for (size_t i = 0; i < layers.size(); ++i) {
-    RCK(encoder_layer(c, layers[i], x, ln, qkv, att, ffn, B, L, s));
+    RCK(encoder_layer(c, layers[i], x, ln, qkv, att, ffn, B, L, s, bp));
     RCK(record_tap(c, w, ((audio ? "a_enc" : "v_enc") + std::to_string(i)).c_str(), x, (size_t)B * L * c->d, s));
   }
   return AVSEP_OK;
@@ -619,8 +775,27 @@ int encoder_layers(avsep_ctx* c, const std::vector<EncLayerW>& layers, const Wor
 
 // one pre-norm encoder layer: x += Wo*Attn(LN1 x); x += W2*relu(W1*LN2 x)   (model.py:48-52, norm_first)
 int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* qkv, float* att, float* ffn, int B,
-                  int Lseq, hipStream_t s) {
+                  int Lseq, hipStream_t s, const BranchPlanes& bp) {
   const int d = c->d, M = B * Lseq;
+  if (bp.ln && bp.h2) {   // two fp16 terms, three products: LayerNorm, attention and FFN-1 write the scaled planes their consumers read
+    const avsep_ctx::H2Site *sq = &c->h2.at(L.wqkv), *so = &c->h2.at(L.wo), *s1 = &c->h2.at(L.w1), *s2 = &c->h2.at(L.w2);
+    RCK(run_ln_linear_h2(c, x, L.g1, L.be1, bp.ln, bp.rows, L.wqkv, L.bqkv, qkv, nullptr, sq, nullptr, M, 3 * d, ACT_NONE, s));
+    RCK(run_attention_proj(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, L.wo, L.bo, x, B, Lseq, Lseq, s, bp.att, bp.rows, so));
+    RCK(run_ln_linear_h2(c, x, L.g2, L.be2, bp.ln, bp.rows, L.w1, L.b1, nullptr, bp.ffn, s1, s2, M, 4 * d, ACT_RELU, s));
+    GemmParams p2 = linear_params(nullptr, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
+    p2.Ap = bp.ffn; p2.a_rows = bp.rows; p2.h2 = 1;
+    p2.R = x; p2.ldr = d; p2.rperiod = 0;
+    return run_gemm(c, p2, s);
+  }
+  if (bp.ln) {   // pre-split operands: LayerNorm, attention and FFN-1 write the planes their consumer GEMMs read (same bits)
+    RCK(run_ln_linear_planes(c, x, L.g1, L.be1, bp.ln, bp.rows, L.wqkv, L.bqkv, qkv, nullptr, M, 3 * d, ACT_NONE, s));
+    RCK(run_attention_proj(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, L.wo, L.bo, x, B, Lseq, Lseq, s, bp.att, bp.rows));
+    RCK(run_ln_linear_planes(c, x, L.g2, L.be2, bp.ln, bp.rows, L.w1, L.b1, nullptr, bp.ffn, M, 4 * d, ACT_RELU, s));
+    GemmParams p2 = linear_params(nullptr, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
+    p2.Ap = bp.ffn; p2.a_rows = bp.rows;
+    p2.R = x; p2.ldr = d; p2.rperiod = 0;
+    return run_gemm(c, p2, s);
+  }
   RCK(run_ln_linear(c, x, L.g1, L.be1, ln, L.wqkv, L.bqkv, qkv, M, 3 * d, ACT_NONE, s));   // norm1 -> in_proj
   RCK(run_attention_proj(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, L.wo, L.bo, x, B, Lseq, Lseq, s));
   RCK(run_ln_linear(c, x, L.g2, L.be2, ln, L.w1, L.b1, ffn, M, 4 * d, ACT_RELU, s));        // norm2 -> linear1
@@ -752,7 +927,10 @@ int visual_front(avsep_ctx* c, const Workspace& w, const float* lips, int B, int
 // F.interpolate(mode="linear") of the frame sequence to the audio length (model.py:114-116): w.v_x -> w.v_up
 int visual_upsample(avsep_ctx* c, const Workspace& w, int B, int N, int T, hipStream_t s) {
   const int d = c->d;
-  RCK(profiled(c, "interp_linear_kernel", 3.0 * B * T * d, 4.0 * B * d * (N + T), s,
+  if (planes_rows(c, w, B * T))                    // only the fusion K/V projection reads it: its planes instead of the fp32 tensor
+    return profiled(c, "interp_linear_kernel<true>", 3.0 * B * T * d, 4.0 * B * d * (N + 1.5 * T), s,
+                    [&] { return launch_interp_linear_planes(w.v_x, w.v_up_p, w.rows_a, B, N, T, d, s); });
+  RCK(profiled(c, "interp_linear_kernel<false>", 3.0 * B * T * d, 4.0 * B * d * (N + T), s,
                [&] { return launch_interp_linear(w.v_x, w.v_up, B, N, T, d, s); }));
   return record_tap(c, w, "v_interp", w.v_up, (size_t)B * T * d, s);
 }
@@ -770,7 +948,11 @@ int fusion_kv(avsep_ctx* c, const Workspace& w, const float* visual, int B, int 
   if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
   if (c->Lf == 0) return AVSEP_OK;
   const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
-  RCK(run_gemm(c, linear_params(visual, d, c->wkv_all, d, c->bkv_all, w.kv_all, nkv, M, nkv, ACT_NONE), s));
+  GemmParams p = linear_params(visual, d, c->wkv_all, d, c->bkv_all, w.kv_all, nkv, M, nkv, ACT_NONE);
+  if (visual == w.v_up && planes_rows(c, w, M)) {   // the full forward: visual_upsample() wrote planes, not w.v_up
+    p.A = nullptr; p.Ap = w.v_up_p; p.a_rows = w.rows_a;
+  }
+  RCK(run_gemm(c, p, s));
   return AVSEP_OK;
 }
 
@@ -778,8 +960,32 @@ int fusion_kv(avsep_ctx* c, const Workspace& w, const float* visual, int B, int 
 int fusion_layer(avsep_ctx* c, const Workspace& w, float* x, int B, int T, int i, hipStream_t s) {
   const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
   const FusLayerW& L = c->f_layers[i];
-  RCK(run_ln_linear(c, x, L.g1, L.be1, w.ln, L.wq, L.bq, w.f_q, M, d, ACT_NONE, s));       // norm1 -> q proj
   const float* kk = w.kv_all + (size_t)i * 2 * d;
+  if (const avsep_ctx::H2Site* sq = h2_site(c, w, L.wq)) {   // two fp16 terms, see encoder_layer()
+    const avsep_ctx::H2Site *s1 = &c->h2.at(L.w1), *s2 = &c->h2.at(L.w2);
+    RCK(run_ln_linear_h2(c, x, L.g1, L.be1, w.ln_p, w.rows_a, L.wq, L.bq, w.f_q, nullptr, sq, nullptr, M, d, ACT_NONE, s));
+    // the cross-attention output (a combination of rows of the VISUAL stream's projection) has no static bound: its projection stays
+    // on three bf16 terms -- as planes from the 256 x 128 kernel's row count on, else cut in flight (same bits)
+    if (planes_rows(c, w, M)) RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s, w.att_p, w.rows_a));
+    else RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s));
+    RCK(run_ln_linear_h2(c, x, L.g2, L.be2, w.ln_p, w.rows_a, L.w1, L.b1, nullptr, w.ffn_p, s1, s2, M, 4 * d, ACT_GELU, s));
+    GemmParams p2 = linear_params(nullptr, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
+    p2.Ap = w.ffn_p; p2.a_rows = w.rows_a; p2.h2 = 1;
+    p2.R = x; p2.ldr = d;
+    RCK(run_gemm(c, p2, s));
+    return record_tap(c, w, ("f_layer" + std::to_string(i)).c_str(), x, (size_t)M * d, s);
+  }
+  if (planes_rows(c, w, M)) {                       // pre-split operands, see encoder_layer()
+    RCK(run_ln_linear_planes(c, x, L.g1, L.be1, w.ln_p, w.rows_a, L.wq, L.bq, w.f_q, nullptr, M, d, ACT_NONE, s));
+    RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s, w.att_p, w.rows_a));
+    RCK(run_ln_linear_planes(c, x, L.g2, L.be2, w.ln_p, w.rows_a, L.w1, L.b1, nullptr, w.ffn_p, M, 4 * d, ACT_GELU, s));
+    GemmParams p2 = linear_params(nullptr, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
+    p2.Ap = w.ffn_p; p2.a_rows = w.rows_a;
+    p2.R = x; p2.ldr = d;
+    RCK(run_gemm(c, p2, s));
+    return record_tap(c, w, ("f_layer" + std::to_string(i)).c_str(), x, (size_t)M * d, s);
+  }
+  RCK(run_ln_linear(c, x, L.g1, L.be1, w.ln, L.wq, L.bq, w.f_q, M, d, ACT_NONE, s));       // norm1 -> q proj
   RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s));
   RCK(run_ln_linear(c, x, L.g2, L.be2, w.ln, L.w1, L.b1, w.ffn, M, 4 * d, ACT_GELU, s));   // norm2 -> ff.0
   GemmParams p2 = linear_params(w.ffn, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
@@ -807,6 +1013,25 @@ int decoder_stage(avsep_ctx* c, const Workspace& w, const float* fused, float* m
                   hipStream_t s, bool fuse_norm) {
   if (!c->ok_decoder) return fail(AVSEP_ENOWEIGHT, "decoder weights are incomplete");
   const int d = c->d, M = B * T, SF = c->S * c->F;
+  // (an odd S * F -- three speakers -- has no two-output epilogue on the bf16 / fp16 pipes: the mask head then runs the fp32 MFMA kernel
+  // and the decoder keeps fp32 tensors)
+  if (fuse_norm && !(SF & 1) && h2_site(c, w, c->d_w1) && h2_site(c, w, c->d_w2)) {                      // two fp16 terms
+    if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
+    const avsep_ctx::H2Site *s1 = h2_site(c, w, c->d_w1), *s2 = h2_site(c, w, c->d_w2);
+    RCK(run_ln_linear_h2(c, fused, c->fn_g, c->fn_b, w.ln_p, w.rows_a, c->d_w1, c->d_b1, nullptr, w.ffn_p, s1, s2, M, 2 * d, ACT_GELU, s));
+    GemmParams p = linear_params(nullptr, 2 * d, c->d_w2, 2 * d, c->d_b2, masks, SF, M, SF, ACT_SIGMOID);
+    p.Ap = w.ffn_p; p.a_rows = w.rows_a; p.h2 = 1;
+    if (sep) { p.C2 = sep; p.X = w.xt; p.ldx = c->Fp; p.F = c->F; }
+    return run_gemm(c, p, s);
+  }
+  if (fuse_norm && !(SF & 1) && planes_rows(c, w, M) && c->wplanes.count(c->d_w1) && c->wplanes.count(c->d_w2)) {   // pre-split operands
+    if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
+    RCK(run_ln_linear_planes(c, fused, c->fn_g, c->fn_b, w.ln_p, w.rows_a, c->d_w1, c->d_b1, nullptr, w.ffn_p, M, 2 * d, ACT_GELU, s));
+    GemmParams p = linear_params(nullptr, 2 * d, c->d_w2, 2 * d, c->d_b2, masks, SF, M, SF, ACT_SIGMOID);
+    p.Ap = w.ffn_p; p.a_rows = w.rows_a;
+    if (sep) { p.C2 = sep; p.X = w.xt; p.ldx = c->Fp; p.F = c->F; }
+    return run_gemm(c, p, s);
+  }
   if (fuse_norm) {
     if (!c->ok_fusion) return fail(AVSEP_ENOWEIGHT, "fusion weights are incomplete");
     RCK(run_ln_linear(c, fused, c->fn_g, c->fn_b, w.ln, c->d_w1, c->d_b1, w.ffn, M, 2 * d, ACT_GELU, s));
@@ -832,6 +1057,8 @@ Workspace shift_rows(const avsep_ctx* c, const Workspace& w, int b0, int T) {
   v.att += rows * d;
   v.ffn += rows * 4 * d;
   v.kv_all += rows * (size_t)c->Lf * 2 * d;
+  // plane buffers: a row-range view is the same slab layout 32 * row0 elements further on, with the same slab height
+  if (v.ln_p) { v.ln_p += rows * 32; v.att_p += rows * 32; v.ffn_p += rows * 32; v.v_up_p += rows * 32; }
   return v;
 }
 
@@ -971,6 +1198,94 @@ int forward_impl(avsep_ctx* c, const float* mixed, const float* lips, float* mas
   if (serial || c->prof_on) sv = s;
   HCK(hipStreamWaitEvent(sv, c->ev_fork, 0));
   return forward_part(c, w, mixed, lips, masks, sep, B, T, N, H, W, s, sv);
+}
+
+// ---- static exponents of the two-term fp16 GEMM sites (gemm_h2.hip) from the packed weights alone
+// exponent e with bound * 2^e <= 2^14 (one binade of slack for the roundings inside the bound itself)
+int h2_exponent(double bound) {
+  if (!(bound > 0.0)) return 0;
+  int ex;
+  (void)std::frexp(bound * (1.0 + 1e-5), &ex);                          // bound <= 2^ex
+  const int e = 14 - ex;
+  return e > 100 ? 100 : e < -100 ? -100 : e;
+}
+int h2_prepare(avsep_ctx* c, hipStream_t s) {
+  if (c->h2.empty()) return AVSEP_OK;
+  const int d = c->d;
+  for (auto& kv : c->h2) HCK(launch_h2_row_stats(kv.first, kv.second.N, kv.second.K, kv.second.ew, kv.second.l2, s));
+  HCK(hipStreamSynchronize(s));
+  auto host = [&](const float* p, size_t n) {
+    std::vector<float> v(n);
+    if (hipMemcpy(v.data(), p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) v.clear();
+    return v;
+  };
+  bool finite = true;
+  // LayerNorm(x) = xhat o gamma + beta with |xhat_k| <= sqrt(d - 1), ||xhat||_2 <= sqrt(d): element bound and 2-norm bound
+  struct LnB { double elem, l2; };
+  auto ln_bound = [&](const float* g, const float* be) {
+    const std::vector<float> gv = host(g, d), bv = host(be, d);
+    LnB r{0.0, 0.0};
+    double gmax = 0.0, b2 = 0.0;
+    for (int k = 0; k < d && k < (int)gv.size() && k < (int)bv.size(); ++k) {
+      r.elem = std::max(r.elem, std::sqrt((double)d - 1.0) * std::fabs((double)gv[k]) + std::fabs((double)bv[k]));
+      gmax = std::max(gmax, std::fabs((double)gv[k]));
+      b2 += (double)bv[k] * bv[k];
+    }
+    r.l2 = std::sqrt((double)d) * gmax + std::sqrt(b2);
+    if (gv.empty() || bv.empty() || !std::isfinite(r.elem) || !std::isfinite(r.l2)) finite = false;
+    return r;
+  };
+  // max over the rows [n0, n1) of a projection of (l2_in ||w_n||_2 + |b_n|): bounds act(x W^T + b) for ||x||_2 <= l2_in (|relu|, |gelu| <= |.|)
+  auto proj_bound = [&](const float* w, const float* b, int n0, int n1, double l2_in) {
+    auto it = c->h2.find(w);
+    if (it == c->h2.end()) { finite = false; return 0.0; }
+    const std::vector<float> l2 = host(it->second.l2, it->second.N), bv = b ? host(b, it->second.N) : std::vector<float>(it->second.N, 0.0f);
+    double r = 0.0;
+    for (int n = n0; n < n1 && n < (int)l2.size() && n < (int)bv.size(); ++n) r = std::max(r, l2_in * (double)l2[n] + std::fabs((double)bv[n]));
+    if (l2.empty() || bv.empty() || !std::isfinite(r)) finite = false;
+    return r;
+  };
+  auto set = [&](const float* w, double bound) {
+    auto it = c->h2.find(w);
+    if (it != c->h2.end()) it->second.eA = h2_exponent(bound);
+  };
+  auto encoder = [&](std::vector<EncLayerW>& layers, bool ok) {
+    if (!ok) return;
+    for (auto& L : layers) {
+      const LnB n1 = ln_bound(L.g1, L.be1), n2 = ln_bound(L.g2, L.be2);
+      set(L.wqkv, n1.elem);
+      set(L.wo, proj_bound(L.wqkv, L.bqkv, 2 * d, 3 * d, n1.l2));          // a convex combination of value rows
+      set(L.w1, n2.elem);
+      set(L.w2, proj_bound(L.w1, L.b1, 0, 4 * d, n2.l2));
+    }
+  };
+  encoder(c->a_layers, c->ok_audio);
+  encoder(c->v_layers, c->ok_visual);
+  if (c->ok_fusion) {
+    for (auto& L : c->f_layers) {
+      const LnB n1 = ln_bound(L.g1, L.be1), n2 = ln_bound(L.g2, L.be2);
+      set(L.wq, n1.elem);
+      set(L.w1, n2.elem);
+      set(L.w2, proj_bound(L.w1, L.b1, 0, 4 * d, n2.l2));
+    }
+    if (c->ok_decoder) {
+      const LnB nf = ln_bound(c->fn_g, c->fn_b);
+      set(c->d_w1, nf.elem);
+      set(c->d_w2, proj_bound(c->d_w1, c->d_b1, 0, 2 * d, nf.l2));
+    }
+  }
+  c->use_h2 = finite && dev_env("AVSEP_NO_H2") == nullptr;               // non-finite weights: the three-term bf16 kernels (full fp32 range)
+  if (!c->use_h2) return AVSEP_OK;
+  for (auto& kv : c->h2) {
+    avsep_ctx::H2Site& t = kv.second;
+    std::vector<int> ew(t.N);
+    if (hipMemcpy(ew.data(), t.ew, t.N * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(AVSEP_EHIP, "hipMemcpy(h2 exponents)");
+    std::vector<float> cs(t.N);
+    for (int n = 0; n < t.N; ++n) cs[n] = std::ldexp(1.0f, -(t.eA + ew[n]));
+    HCK(hipMemcpy(t.cscale, cs.data(), t.N * sizeof(float), hipMemcpyHostToDevice));
+    HCK(launch_split_h2(kv.first, t.K, t.wp, t.N, t.N, t.K, t.ew, 0, s));
+  }
+  return AVSEP_OK;
 }
 
 // Guard for entry points that own device-wide state: makes the context's device current for the scope.
@@ -1328,6 +1643,11 @@ int avsep_finalize_weights(avsep_ctx* c, void* stream) try {
       if (c->ok_decoder) HCK(site(c->d_w1, c->d_b1, c->fn_g, c->fn_b, 2 * d));
     }
   }
+  // the bf16 planes of every weight the split-precision GEMM takes (after the packs above, same stream): gemm_planes.hip
+  for (const auto& site : c->wplane_sites)
+    HCK(launch_split_planes(site.first, site.second.second, c->wplanes[site.first], site.second.first, site.second.first,
+                            site.second.second, s));
+  RCK(h2_prepare(c, s));
   c->finalized = true;
   return AVSEP_OK;
 } catch (...) {
@@ -1538,6 +1858,74 @@ int avsep_op_linear_planes(const uint16_t* xp, int64_t x_rows, const uint16_t* w
   if (residual) { p.R = residual; p.ldr = N; }
   if (!gemm_planes_supported(p)) return fail(AVSEP_EINVAL, "shape / epilogue not supported by the pre-split GEMM");
   HCK(launch_gemm_planes(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_layernorm_planes(const float* x, const float* gamma, const float* beta, uint16_t* yp, int64_t rows, int M, int d, float eps,
+                              void* stream) {
+  if (!x || !gamma || !beta || !yp) return fail(AVSEP_EINVAL, "null pointer");
+  if (M <= 0 || d <= 0 || d % 32 || d > 2048 || rows < M) return fail(AVSEP_EINVAL, "d must be a multiple of 32 and <= 2048, rows >= M");
+  HCK(launch_layernorm_planes(x, gamma, beta, yp, rows, M, d, eps, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_interp_linear_planes(const float* x, uint16_t* yp, int64_t rows, int B, int N, int T, int d, void* stream) {
+  if (!x || !yp || B <= 0 || N <= 0 || T <= 0 || d <= 0 || d % 32 || rows < (int64_t)B * T) return fail(AVSEP_EINVAL, "bad argument");
+  HCK(launch_interp_linear_planes(x, yp, rows, B, N, T, d, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_split_planes(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* op, int64_t rows,
+                                    int B, int nhead, int dh, int Lq, int Lk, void* stream) {
+  if (!q || !k || !v || !op) return fail(AVSEP_EINVAL, "null pointer");
+  if (!attention_split_supported(dh, Lq, Lk) || B <= 0 || nhead <= 0 || rows < (int64_t)B * Lq) return fail(AVSEP_EINVAL, "unsupported shape");
+  HCK(launch_attention_split(q, ldq, k, ldk, v, ldv, nullptr, 0, B, nhead, dh, Lq, Lk, 1.0f, reinterpret_cast<hipStream_t>(stream), op, rows));
+  return AVSEP_OK;
+}
+
+int avsep_op_h2_row_stats(const float* w, int N, int K, int32_t* ew, float* l2, void* stream) {
+  if (!w || !ew || !l2 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  HCK(launch_h2_row_stats(w, N, K, reinterpret_cast<int*>(ew), l2, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_split_h2(const float* x, int ld, uint16_t* planes, int64_t rows, int M, int K, const int32_t* row_exp, int e, void* stream) {
+  if (!x || !planes || M <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || ld % 4 || ld < K || rows < M || e < -120 || e > 120) return fail(AVSEP_EINVAL, "K must be a multiple of 32, ld of 4 and >= K, rows >= M, |e| <= 120");
+  HCK(launch_split_h2(x, ld, planes, rows, M, K, reinterpret_cast<const int*>(row_exp), e, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_linear_h2(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* cscale, const float* bias,
+                       const float* residual, float* y, uint16_t* yp, int64_t y_rows, int yp_exp, int M, int N, int K, int act,
+                       void* stream) {
+  if (!xp || !wp || !cscale || (!y && !yp) || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (K % 32 || N % 2) return fail(AVSEP_EINVAL, "K must be a multiple of 32 and N even");
+  if (act < 0 || act > 3 || yp_exp < -120 || yp_exp > 120) return fail(AVSEP_EINVAL, "unknown activation / exponent out of range");
+  GemmParams p = linear_params(nullptr, K, nullptr, K, bias, y, N, M, N, act);
+  p.Ap = xp; p.a_rows = x_rows; p.Wp = wp; p.w_rows = w_rows; p.Cp = yp; p.c_rows = y_rows; p.cscale = cscale; p.h2 = 1;
+  p.cp_scale = std::ldexp(1.0f, yp_exp);
+  if (residual) { p.R = residual; p.ldr = N; }
+  if (!gemm_h2_supported(p)) return fail(AVSEP_EINVAL, "shape / epilogue not supported by the two-term GEMM");
+  HCK(launch_gemm_h2(p, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_layernorm_h2(const float* x, const float* gamma, const float* beta, uint16_t* yp, int64_t rows, int M, int d, float eps, int e,
+                          void* stream) {
+  if (!x || !gamma || !beta || !yp) return fail(AVSEP_EINVAL, "null pointer");
+  if (M <= 0 || d <= 0 || d % 32 || d > 2048 || rows < M || e < -120 || e > 120) return fail(AVSEP_EINVAL, "bad argument");
+  HCK(launch_layernorm_h2(x, gamma, beta, yp, rows, M, d, eps, e, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_split_h2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* op, int64_t rows,
+                                int e, int B, int nhead, int dh, int Lq, int Lk, void* stream) {
+  if (!q || !k || !v || !op) return fail(AVSEP_EINVAL, "null pointer");
+  if (!attention_split_supported(dh, Lq, Lk) || B <= 0 || nhead <= 0 || rows < (int64_t)B * Lq || e < -120 || e > 120)
+    return fail(AVSEP_EINVAL, "unsupported shape");
+  HCK(launch_attention_split(q, ldq, k, ldk, v, ldv, nullptr, 0, B, nhead, dh, Lq, Lk, 1.0f, reinterpret_cast<hipStream_t>(stream), op, rows,
+                             1, e));
   return AVSEP_OK;
 }
 

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
   GemmParams q{};   // float4 rows (K % 4 == 0 is a precondition of this kernel)
   q.C = out; q.M = p.N; q.N = p.K; q.ldc = p.K; q.act = ACT_NONE;
+  q.W = p.x;   // the epilogue reads (and discards) K floats from W when there is no bias: a readable buffer, never the null page
   gemm_epilogue<WBM, WBN>(q, acc, m0, n0, wm * (BM / 2), wn * (BN / 2), fr, fq);
   if (p.merged == nullptr) return;                     // block-uniform
   // ---- in-launch slice merge: the split-K hand-off of cdna_hip_programming.md (section 5, "Projection GEMM at M = 256",

@@ -24,6 +24,9 @@
 #include "kernels.h"
 #include "gemm_tile.h"
 #include "split_terms.h"
+#include <algorithm>
+#include <cstdio>
+#include <vector>
 
 namespace {
 
@@ -410,12 +413,20 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel_b(const GemmParams 
       f_rows = tile_rows(f_tile);                    \
     }                                                \
   }
+  // V & 16 (developer diagnostics, p.dbg): wall-clock stamps (10 ns ticks) of thread 0 -- [0] entry, [1] first chunks landed, then per
+  // tile [2 + 2t] last product issued, [3 + 2t] epilogue issued
+#define PB_STAMP(idx) \
+  if ((V & 16) && p.dbg && tid == 0 && (idx) < 32) p.dbg[(size_t)blockIdx.x * 32 + (idx)] = __builtin_amdgcn_s_memrealtime();
+  int stamp_i = 2;
+  PB_STAMP(0)
+  if ((V & 16) && p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 32 + 30] = __builtin_amdgcn_s_memtime();      // shader-clock cycles
   PB_PIECES3(f_kc, f_rows, 0, 0) PB_PIECES3(f_kc, f_rows, 0, 3) PB_PIECES3(f_kc, f_rows, 0, 6)
   PB_ADVANCE
   PB_PIECES3(f_kc, f_rows, 1, 0) PB_PIECES3(f_kc, f_rows, 1, 3) PB_PIECES3(f_kc, f_rows, 1, 6)
   PB_ADVANCE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  PB_STAMP(1)
 
 #define P_FRAG_A(term, f) \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(rb + (term) * P_APL + a_fo[i]);
@@ -458,6 +469,18 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel_b(const GemmParams 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (;;) {
+    if (V & 32) {   // TIMING PROBE of a two-term, three-product scheme (wrong results): terms 0 and 1 only
+      const char* rb = ldsp + par * P_BUF;
+      P_FRAG_A(0, a_hi) P_FRAG_W(1, w_mid) P_FRAG_W(0, w_hi) P_FRAG_A(1, a_mid)
+      P_FENCE
+      P_MMA(w_mid, a_hi)
+      P_FENCE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      PB_ADVANCE_SAVE
+      P_MMA_D(w_hi, a_mid, 0)
+      P_MMA_D(w_hi, a_hi, 3)
+    } else {
     {
       const char* rb = ldsp + par * P_BUF;
       P_FRAG_A(0, a_hi) P_FRAG_W(2, w_lo) P_FRAG_W(0, w_hi) P_FRAG_A(2, a_lo)
@@ -477,11 +500,16 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel_b(const GemmParams 
     P_MMA_D(w_hi, a_mid, 0)  /* (mid, hi) */
     P_MMA_D(w_mid, a_hi, 3)  /* (hi, mid) */
     P_MMA_D(w_hi, a_hi, 6)   /* (hi, hi) */
+    }
     par ^= 1;
     if (++kc == nk) {                                                      // block-uniform
       const int bm = tile / nbn, bn = tile - bm * nbn;
+      PB_STAMP(stamp_i)
       if (p.Cp) planes_epilogue(p, acc, bm * PBM + wm * 64, bn * PBN + wn * 64, fr, fq);
       if (p.C) gemm_epilogue<4, 4>(p, acc, bm * PBM, bn * PBN, wm * 64, wn * 64, fr, fq);
+      PB_STAMP(stamp_i + 1)
+      if ((V & 16) && p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memtime();
+      stamp_i += 2;
       tile += tile_step;
       if (tile >= tile_end) break;
       kc = 0;
@@ -496,6 +524,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel_b(const GemmParams 
 #undef PB_PIECES3
 #undef PB_ADVANCE
 #undef PB_ADVANCE_SAVE
+#undef PB_STAMP
 #undef P_MMA_D
 #undef P_FENCE
 #undef P_FRAG_A
@@ -709,7 +738,8 @@ bool gemm_planes_supported(const GemmParams& p) {
          p.alt.M <= 0 && !p.epi_general;
 }
 
-constexpr int PLANES_V = 0;                                               // the shipped variant (see gemm_planes_kernel)
+[[maybe_unused]] constexpr int PLANES_V = 0;                                               // the shipped variant of gemm_planes_kernel_b
+const char* gemm_planes_instance_name() { return "gemm_planes_kernel_b<0>"; }
 #ifdef AVSEP_DEV
 static const void* const planes_kernels[] = {
     reinterpret_cast<const void*>(gemm_planes_kernel<0>), reinterpret_cast<const void*>(gemm_planes_kernel<1>),
@@ -717,14 +747,16 @@ static const void* const planes_kernels[] = {
     reinterpret_cast<const void*>(gemm_planes_kernel_b<0>), reinterpret_cast<const void*>(gemm_planes_kernel_b<1>),
     reinterpret_cast<const void*>(gemm_planes_kernel_b<2>), reinterpret_cast<const void*>(gemm_planes_kernel_b<4>),
     reinterpret_cast<const void*>(gemm_planes_kernel_b<8>), reinterpret_cast<const void*>(gemm_planes_kernel_b<9>),
-    reinterpret_cast<const void*>(gemm_planes_kernel_c<0>), reinterpret_cast<const void*>(gemm_planes_kernel_c<2>)};
+    reinterpret_cast<const void*>(gemm_planes_kernel_c<0>), reinterpret_cast<const void*>(gemm_planes_kernel_c<2>),
+    reinterpret_cast<const void*>(gemm_planes_kernel_b<16>), reinterpret_cast<const void*>(gemm_planes_kernel_b<32>)};
 #else
-static const void* const planes_kernels[] = {reinterpret_cast<const void*>(gemm_planes_kernel<PLANES_V>)};
+static const void* const planes_kernels[] = {reinterpret_cast<const void*>(gemm_planes_kernel_b<PLANES_V>)};
 #endif
 
 hipError_t launch_gemm_planes(GemmParams p, hipStream_t s) {
   if (!gemm_planes_supported(p) || p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
   p.nbn_magic = 0;
+  if (!p.W) p.W = reinterpret_cast<const float*>(p.Wp);   // gemm_tile.h's epilogue reads N floats from W when there is no bias (discarded)
   // the dynamic-LDS ceiling of the kernel is raised once per device (see conv_stack.hip); the CU count is read with it
   static bool raised[64] = {};
   static int cus[64] = {};
@@ -742,8 +774,38 @@ hipError_t launch_gemm_planes(GemmParams p, hipStream_t s) {
   }
   const long tiles = (long)((p.M + PBM - 1) / PBM) * ((p.N + PBN - 1) / PBN);
   const long grid = tiles < cus[dev] ? tiles : cus[dev];                 // one resident workgroup per CU walks tiles / grid tiles
-  int v = PLANES_V;
+  int v = -1;                                                              // the shipped kernel
 #ifdef AVSEP_DEV
+  if (getenv("AVSEP_PLANES_DBG")) {   // developer diagnostics: where a workgroup's life goes (wall-clock stamps, 10 ns ticks)
+    unsigned long long* buf = nullptr;
+    if (hipMalloc(&buf, (size_t)grid * 32 * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(buf, 0, (size_t)grid * 32 * 8, s);
+    p.dbg = buf;
+    hipLaunchKernelGGL(gemm_planes_kernel_b<16>, dim3((unsigned)grid), dim3(512), 2 * P_BUF, s, p);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)grid * 32);
+    (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    unsigned long long t0 = ~0ull, t1 = 0, e_max = 0;
+    for (long b = 0; b < grid; ++b) { t0 = std::min(t0, h[b * 32]); e_max = std::max(e_max, h[b * 32]); }
+    double pro = 0, loop = 0, epi = 0, clk = 0; long nt = 0; double life = 0;
+    unsigned long long end_min = ~0ull;
+    for (long b = 0; b < grid; ++b) {
+      const unsigned long long* r = &h[b * 32];
+      pro += (double)(r[1] - r[0]);
+      unsigned long long prev = r[1], last = r[1];
+      for (int t = 0; t < 14 && r[2 + 2 * t]; ++t) {
+        loop += (double)(r[2 + 2 * t] - prev); epi += (double)(r[3 + 2 * t] - r[2 + 2 * t]); prev = r[3 + 2 * t]; last = prev; ++nt;
+      }
+      t1 = std::max(t1, last); end_min = std::min(end_min, last); life += (double)(last - r[0]);
+      clk += (double)(r[31] - r[30]) / ((double)(last - r[0]) * 10.0);     // cycles per ns = GHz
+    }
+    fprintf(stderr, "[planes dbg] M=%d N=%d K=%d grid %ld: span %.2f us (first entry -> last epilogue issued); entry skew %.2f us, end skew %.2f us; mean workgroup life %.2f us; "
+            "mean prologue %.2f us; per tile: loop %.2f us (%.3f us per chunk), epilogue %.2f us; %ld tiles; in-kernel shader clock %.3f GHz\n",
+            p.M, p.N, p.K, grid, (t1 - t0) / 100.0, (e_max - t0) / 100.0, (t1 - end_min) / 100.0, life / grid / 100.0, pro / grid / 100.0,
+            loop / nt / 100.0, loop / nt / 100.0 / (p.K / 32), epi / nt / 100.0, nt, clk / grid);
+    return hipGetLastError();
+  }
   if (const char* e = getenv("AVSEP_PLANES_V")) v = atoi(e);               // developer A/B: 0, 1, 4 = first kernel; 8 + V = gemm_planes_kernel_b<V>
 #define PL_(K) hipLaunchKernelGGL(K, dim3((unsigned)grid), dim3(512), 2 * P_BUF, s, p); break;
   switch (v) {
@@ -755,14 +817,16 @@ hipError_t launch_gemm_planes(GemmParams p, hipStream_t s) {
     case 12: PL_(gemm_planes_kernel_b<4>)
     case 16: PL_(gemm_planes_kernel_b<8>)
     case 17: PL_(gemm_planes_kernel_b<9>)
+    case 40: PL_(gemm_planes_kernel_b<32>)
     case 32: PL_(gemm_planes_kernel_c<0>)
     case 34: PL_(gemm_planes_kernel_c<2>)
-    default: PL_(gemm_planes_kernel<0>)
+    case 0: PL_(gemm_planes_kernel<0>)
+    default: PL_(gemm_planes_kernel_b<0>)
   }
 #undef PL_
 #else
   (void)v;
-  hipLaunchKernelGGL(gemm_planes_kernel<PLANES_V>, dim3((unsigned)grid), dim3(512), 2 * P_BUF, s, p);
+  hipLaunchKernelGGL(gemm_planes_kernel_b<PLANES_V>, dim3((unsigned)grid), dim3(512), 2 * P_BUF, s, p);
 #endif
   return hipGetLastError();
 }

@@ -138,6 +138,11 @@ struct GemmParams {
   const unsigned short* Wp;
   unsigned short* Cp;
   long long a_rows, w_rows, c_rows;
+  // Two-term fp16 planes (gemm_h2.hip): operands stored scaled by powers of two -- cscale[n] = 2^-(eA + ew[n]) brings an accumulator
+  // back to true scale (exact), cp_scale = 2^eC is the scale of the plane OUTPUT (the consumer's static exponent).
+  const float* cscale;
+  float cp_scale;
+  int h2;              // 1: Ap / Wp / Cp hold two fp16 terms (gemm_h2.hip), 0: three bf16 terms (gemm_planes.hip)
 #ifdef AVSEP_DEV
   struct Alt {
     const float *A, *W, *bias, *R, *ln_gamma, *ln_beta;
@@ -164,12 +169,26 @@ const char* gemm_split_instance_name(const GemmParams& p);
 // the same GEMM on PRE-SPLIT operands (gemm_planes.hip): GemmParams::Ap / Wp (/ Cp), staged by LDS-DMA; same bits as the kernels above
 bool gemm_planes_supported(const GemmParams& p);
 hipError_t launch_gemm_planes(GemmParams p, hipStream_t s);
+const char* gemm_planes_instance_name();
+const char* layernorm_planes_instance_name(int d, int kind);   // kind 1: three bf16 terms, 2: two fp16 terms
+// the same on TWO fp16 terms and THREE products per fp32 product (gemm_h2.hip): GemmParams::Ap / Wp as H2 planes, cscale (/ Cp, cp_scale)
+bool gemm_h2_supported(const GemmParams& p);
+hipError_t launch_gemm_h2(GemmParams p, hipStream_t s);
+const char* gemm_h2_instance_name(const GemmParams& p);
+// x [M][ld] fp32 -> H2 planes (fp16 [K/32][2][rows][32]) of x * 2^e, e = row_exp[m] (or the one exponent `e` when row_exp is null)
+hipError_t launch_split_h2(const float* x, int ld, unsigned short* planes, long long rows, int M, int K, const int* row_exp, int e,
+                           hipStream_t s);
+// per row n of w [N][K]: ew[n] = the exponent that puts max|w[n][:]| into [2^13, 2^14) (0 for a zero row), l2[n] >= ||w[n][:]||_2
+hipError_t launch_h2_row_stats(const float* w, int N, int K, int* ew, float* l2, hipStream_t s);
 // x [M][ld] fp32 -> its three bf16 terms in P32 plane format (rows >= M: the buffer's row count); K % 32 == 0, ld % 4 == 0
 hipError_t launch_split_planes(const float* x, int ld, unsigned short* planes, long long rows, int M, int K, hipStream_t s);
 // split-precision attention (attention_split.hip): dh = 64, fp32 in / out, QK^T and PV as six bf16 MFMA products per fp32 product
 bool attention_split_supported(int dh, int Lq, int Lk);
+// op != null: the output is written as the bf16 planes of the out-projection GEMM's A operand (GemmParams::Ap; row b * Lq + q, column
+// h * 64 + c of a buffer with o_rows rows) INSTEAD of fp32 o
 hipError_t launch_attention_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
-                                  int B, int nhead, int dh, int Lq, int Lk, float qscale, hipStream_t s);
+                                  int B, int nhead, int dh, int Lq, int Lk, float qscale, hipStream_t s,
+                                  unsigned short* op = nullptr, long long o_rows = 0, int h2 = 0, int h2_exp = 0);   // h2: two fp16 terms scaled by 2^h2_exp
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
 // with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)
@@ -282,6 +301,13 @@ hipError_t launch_conv_stack(const float* frames, const float* w1, const float* 
 // mean over P positions: x (M,P,C) -> y (M,C)
 hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);
+// the same values as the bf16 planes of the consuming GEMM's A operand (GemmParams::Ap; rows = the buffer's row count); d % 32 == 0
+hipError_t launch_interp_linear_planes(const float* x, unsigned short* yp, long long rows, int B, int N, int T, int d, hipStream_t s);
+hipError_t launch_layernorm_planes(const float* x, const float* g, const float* b, unsigned short* yp, long long rows, int M, int d,
+                                   float eps, hipStream_t s);
+// ... as the two fp16 terms of gemm_h2.hip, scaled by 2^e
+hipError_t launch_layernorm_h2(const float* x, const float* g, const float* b, unsigned short* yp, long long rows, int M, int d,
+                               float eps, int e, hipStream_t s);
 // Hann-windowed real-DFT basis [2*(n_fft/2+1)][n_fft]: row 2f = w[k] cos(2 pi f k / n_fft), row 2f+1 = -w[k] sin(..),
 // w = np.hanning(n_fft) (symmetric); evaluated in double precision, rounded once
 hipError_t launch_stft_basis(float* basis, int n_fft, hipStream_t s);

@@ -2,6 +2,7 @@
 // the one-off weight packers.  None of these has arithmetic intensity worth the matrix cores; they are
 // written for coalesced 16-byte accesses along the contiguous axis and 64-lane wavefront reductions.
 #include "kernels.h"
+#include "split_terms.h"
 #include <cstdio>
 
 namespace {
@@ -14,10 +15,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // nn.LayerNorm (model.py:143,162-163 and the norm1/norm2 of TransformerEncoderLayer): one wavefront per
 // row, the row held in registers (VEC float4 per lane), two-pass mean / biased variance like ATen.
-template <int VEC, bool STATS_ONLY = false>
+// PLANES (round 5): the normalised row is written as the three bf16 terms of the consuming GEMM's A operand (plane format of
+// gemm_planes.hip, `rows` = the buffer's row count) instead of fp32 -- the same values, cut by split_terms.h's split: 6 bytes per
+// element instead of 4, and the GEMM no longer splits them in every column tile.  d % 32 == 0.
+// PLANES = 2: as the two fp16 terms of gemm_h2.hip, scaled by `pscale` = 2^e, the static exponent of this LayerNorm site
+// (sqrt(d - 1) |gamma| + |beta| <= 2^(14 - e): no overflow whatever the input).
+template <int VEC, bool STATS_ONLY = false, int PLANES = 0>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gam,
                                                         const float* __restrict__ bet, float* __restrict__ y,
-                                                        int M, int d, float eps) {
+                                                        int M, int d, float eps, long long rows = 0, float pscale = 1.0f) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -59,7 +65,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-      *reinterpret_cast<f32x4*>(yr + col) = o;
+      if (PLANES == 2) {
+        unsigned h[2], l[2];
+        split_pair_h2(f32x2{o[0], o[1]} * pscale, h[0], l[0]);
+        split_pair_h2(f32x2{o[2], o[3]} * pscale, h[1], l[1]);
+        char* dst = reinterpret_cast<char*>(y) + (((size_t)(col >> 5) * 2) * rows + row) * 64 + (col & 31) * 2;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(dst + (size_t)rows * 64) = u32x2{l[0], l[1]};
+      } else if (PLANES == 1) {                    // 4 consecutive columns = 8 bytes of each term; 8 lanes fill a chunk's 64-byte line
+        unsigned h[2], m[2], l[2];
+        split_pair(f32x2{o[0], o[1]}, h[0], m[0], l[0]);
+        split_pair(f32x2{o[2], o[3]}, h[1], m[1], l[1]);
+        char* dst = reinterpret_cast<char*>(y) + (((size_t)(col >> 5) * 3) * rows + row) * 64 + (col & 31) * 2;
+        const size_t ts = (size_t)rows * 64;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(dst + ts) = u32x2{m[0], m[1]};
+        *reinterpret_cast<u32x2*>(dst + 2 * ts) = u32x2{l[0], l[1]};
+      } else {
+        *reinterpret_cast<f32x4*>(yr + col) = o;
+      }
     }
   }
 }
@@ -136,8 +160,9 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
 
 // F.interpolate(mode='linear', align_corners=False) along time (model.py:114-116); index arithmetic in
 // fp32 exactly as ATen's area_pixel_compute_source_index.
+template <bool PLANES>
 __global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                            int B, int N, int T, int d, float scale) {
+                                                            int B, int N, int T, int d, float scale, long long rows) {
   const int dq = d >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)B * T * dq) return;
@@ -157,7 +182,20 @@ __global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restr
   const float w0 = 1.0f - w1;
   const f32x4 a = *reinterpret_cast<const f32x4*>(x + ((size_t)b * N + i0) * d + 4 * c4);
   const f32x4 c = *reinterpret_cast<const f32x4*>(x + ((size_t)b * N + i1) * d + 4 * c4);
-  *reinterpret_cast<f32x4*>(y + bt * d + 4 * c4) = w0 * a + w1 * c;
+  const f32x4 o = w0 * a + w1 * c;
+  if (PLANES) {                                    // see layernorm_kernel
+    unsigned h[2], m[2], l[2];
+    split_pair(f32x2{o[0], o[1]}, h[0], m[0], l[0]);
+    split_pair(f32x2{o[2], o[3]}, h[1], m[1], l[1]);
+    const int col = 4 * c4;
+    char* dst = reinterpret_cast<char*>(y) + (((size_t)(col >> 5) * 3) * rows + bt) * 64 + (col & 31) * 2;
+    const size_t ts = (size_t)rows * 64;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h[0], h[1]};
+    *reinterpret_cast<u32x2*>(dst + ts) = u32x2{m[0], m[1]};
+    *reinterpret_cast<u32x2*>(dst + 2 * ts) = u32x2{l[0], l[1]};
+  } else {
+    *reinterpret_cast<f32x4*>(y + bt * d + 4 * c4) = o;
+  }
 }
 
 // Profiling aid: keeps the stream busy for `us` microseconds so the host can queue a whole forward behind
@@ -239,10 +277,44 @@ hipError_t launch_layernorm(const float* x, const float* g, const float* b, floa
   return hipGetLastError();
 }
 
+hipError_t launch_layernorm_planes(const float* x, const float* g, const float* b, unsigned short* yp, long long rows, int M, int d,
+                                   float eps, hipStream_t s) {
+  if (M <= 0 || d <= 0 || (d & 31) || d > 2048 || rows < M) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+  const int vec = (d + 255) / 256;
+  float* y = reinterpret_cast<float*>(yp);
+  if (vec <= 1) hipLaunchKernelGGL((layernorm_kernel<1, false, 1>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, 1.0f);
+  else if (vec <= 2) hipLaunchKernelGGL((layernorm_kernel<2, false, 1>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, 1.0f);
+  else if (vec <= 4) hipLaunchKernelGGL((layernorm_kernel<4, false, 1>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, 1.0f);
+  else hipLaunchKernelGGL((layernorm_kernel<8, false, 1>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, 1.0f);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm_h2(const float* x, const float* g, const float* b, unsigned short* yp, long long rows, int M, int d,
+                               float eps, int e, hipStream_t s) {
+  if (M <= 0 || d <= 0 || (d & 31) || d > 2048 || rows < M || e < -120 || e > 120) return hipErrorInvalidValue;
+  const dim3 grid((M + 3) / 4), block(256);
+  const int vec = (d + 255) / 256;
+  float* y = reinterpret_cast<float*>(yp);
+  const float sc = ldexpf(1.0f, e);
+  if (vec <= 1) hipLaunchKernelGGL((layernorm_kernel<1, false, 2>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, sc);
+  else if (vec <= 2) hipLaunchKernelGGL((layernorm_kernel<2, false, 2>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, sc);
+  else if (vec <= 4) hipLaunchKernelGGL((layernorm_kernel<4, false, 2>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, sc);
+  else hipLaunchKernelGGL((layernorm_kernel<8, false, 2>), grid, block, 0, s, x, g, b, y, M, d, eps, rows, sc);
+  return hipGetLastError();
+}
+
 const char* layernorm_instance_name(int d, bool stats_only) {
   static thread_local char buf[48];
   const int vec = (d + 255) / 256;
-  snprintf(buf, sizeof buf, "layernorm_kernel<%d, %s>", vec <= 1 ? 1 : vec <= 2 ? 2 : vec <= 4 ? 4 : 8, stats_only ? "true" : "false");
+  snprintf(buf, sizeof buf, "layernorm_kernel<%d, %s, 0>", vec <= 1 ? 1 : vec <= 2 ? 2 : vec <= 4 ? 4 : 8, stats_only ? "true" : "false");
+  return buf;
+}
+
+const char* layernorm_planes_instance_name(int d, int kind) {
+  static thread_local char buf[48];
+  const int vec = (d + 255) / 256;
+  snprintf(buf, sizeof buf, "layernorm_kernel<%d, false, %d>", vec <= 1 ? 1 : vec <= 2 ? 2 : vec <= 4 ? 4 : 8, kind);
   return buf;
 }
 
@@ -283,8 +355,16 @@ hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStre
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s) {
   if (d & 3) return hipErrorInvalidValue;
   const size_t n = (size_t)B * T * (d / 4);
-  hipLaunchKernelGGL(interp_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, B, N, T, d,
-                     (float)N / (float)T);
+  hipLaunchKernelGGL(interp_linear_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, B, N, T, d,
+                     (float)N / (float)T, 0LL);
+  return hipGetLastError();
+}
+
+hipError_t launch_interp_linear_planes(const float* x, unsigned short* yp, long long rows, int B, int N, int T, int d, hipStream_t s) {
+  if ((d & 31) || rows < (long long)B * T) return hipErrorInvalidValue;
+  const size_t n = (size_t)B * T * (d / 4);
+  hipLaunchKernelGGL(interp_linear_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, reinterpret_cast<float*>(yp), B,
+                     N, T, d, (float)N / (float)T, rows);
   return hipGetLastError();
 }
 

@@ -29,3 +29,19 @@ __device__ __forceinline__ void split_pair(const f32x2 x, unsigned& hi, unsigned
 }
 
 }  // namespace
+
+// ---- two fp16 terms ("H2", round 5) ---------------------------------------------------------------------------------------------
+// x' = x * 2^e (e: a power-of-two scale that brings the tensor into fp16's range, exact), hi = rn_f16(x'), lo = rn_f16(x' - hi):
+// x' = hi + lo + r with |r| <= 2^-22 |x'| while lo is a normal fp16 number (|x'| >= 2^-3) and |r| <= 2^-25 absolutely below
+// that.  Three fp16 products (hi, lo) (lo, hi) (hi, hi), each exact in fp32, stand for one fp32 product: HALF the matrix work of
+// the three-term bf16 split, at an error below the fp32 accumulation's own (gemm_h2.hip).  The subtraction is exact.
+namespace {
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_h2(const f32x2 x, unsigned& hi, unsigned& lo) {
+  const f16x2 h = __builtin_convertvector(x, f16x2);                   // round to nearest even
+  const f32x2 r = x - __builtin_convertvector(h, f32x2);               // exact
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);                                // the first value in the low half (the k order of an MFMA operand)
+  lo = __builtin_bit_cast(unsigned, l);
+}
+}  // namespace

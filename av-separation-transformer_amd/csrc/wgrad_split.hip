@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_split_kernel(const WgradSplitPar
   }
   GemmParams q{};   // float4 rows (K % 4 == 0 is a precondition of this kernel)
   q.C = out; q.M = p.N; q.N = p.K; q.ldc = p.K; q.act = ACT_NONE;
+  q.W = p.x;   // the epilogue reads (and discards) K floats from W when there is no bias: a readable buffer, never the null page
   gemm_epilogue<2, 2>(q, acc, m0, n0, wm * 32, wn * 32, fr, fq);
 }
 

@@ -157,6 +157,41 @@ int avsep_op_split_planes(const float* x, int ld, uint16_t* planes, int64_t rows
 int avsep_op_linear_planes(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* bias,
                            const float* residual, float* y, uint16_t* yp, int64_t y_rows, int M, int N, int K, int act,
                            void* stream);
+/* The producers of such planes inside the forward, as ops (each writes exactly avsep_op_split_planes of what its fp32 twin writes,
+ * bit for bit): nn.LayerNorm (avsep_op_layernorm; d % 32 == 0), F.interpolate(mode="linear") (avsep_op_interp_linear; d % 32 == 0) and
+ * the split-precision attention (avsep_op_attention_split; dh = 64; output row b * Lq + q, column h * 64 + c of a (B * Lq, nhead * 64)
+ * matrix).  /root/reference/src/av_separation/model.py:48-52,114-116,143,155,162-163. */
+int avsep_op_layernorm_planes(const float* x, const float* gamma, const float* beta, uint16_t* yp, int64_t rows, int M, int d, float eps,
+                              void* stream);
+int avsep_op_interp_linear_planes(const float* x, uint16_t* yp, int64_t rows, int B, int N, int T, int d, void* stream);
+int avsep_op_attention_split_planes(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* op, int64_t rows,
+                                    int B, int nhead, int dh, int Lq, int Lk, void* stream);
+/* TWO fp16 terms, THREE products per fp32 product (csrc/gemm_h2.hip, round 5): what the d_model >= 512 forward runs wherever a GEMM's
+ * input has a static bound from the weights alone (LayerNorm outputs, act(LayerNorm(x) W^T + b), self-attention outputs) -- half the
+ * matrix work of the three-term bf16 kernels at an error at or below the fp32 MFMA GEMM's own.  Operands are stored scaled by powers
+ * of two (exact) that put them under 2^14 (fp16's range): H2 planes = fp16 [K/32][2][rows][32], element (m, k) of term t (0 = hi =
+ * rn16(x 2^e), 1 = lo = rn16(x 2^e - hi)) at ((k/32 * 2 + t) * rows + m) * 32 + k % 32.
+ *   avsep_op_h2_row_stats   per row n of w (N, K): ew[n] = the exponent that puts max|w[n][:]| into [2^13, 2^14) (0 for a zero row),
+ *                           l2[n] >= ||w[n][:]||_2 (for the bounds avsep_finalize_weights derives the activations' exponents from)
+ *   avsep_op_split_h2       x (M, K; row stride ld) -> H2 planes of x 2^e, e = row_exp[m], or the one exponent `e` with row_exp null.
+ *                           The caller guarantees |x| 2^e <= 65504 (a value beyond becomes inf).
+ *   avsep_op_linear_h2      y = act((sum_k x'_k w'_k) * cscale[n] + bias[n]) + residual, cscale[n] = 2^-(ex + ew[n]); as fp32 (y) and / or
+ *                           as the H2 planes of y 2^yp_exp (yp / y_rows; N % 32 == 0, no residual, not sigmoid).  N even (N % 4 != 0: the mask
+ *                           head's epilogue needs avsep_op_mask_head's operands and is reached through the forward only).
+ *                           A row computed alone has the bits it has inside any batch (64 x 64 and 256 x 128 kernels, same products, same order).
+ *   avsep_op_layernorm_h2, avsep_op_attention_split_h2     the forward's producers of such planes: exactly avsep_op_split_h2(e) of what
+ *                           avsep_op_layernorm / avsep_op_attention_split write.
+ * NORMWISE accuracy: an element below 2^-40 of its tensor's bound is lost (the three-term bf16 kernels keep every element to 24 bits).
+ * Non-finite inputs give non-finite outputs.  nn.Linear, nn.LayerNorm, nn.MultiheadAttention: /root/reference/src/av_separation/model.py:48-52,155-164,194-199. */
+int avsep_op_h2_row_stats(const float* w, int N, int K, int32_t* ew, float* l2, void* stream);
+int avsep_op_split_h2(const float* x, int ld, uint16_t* planes, int64_t rows, int M, int K, const int32_t* row_exp, int e, void* stream);
+int avsep_op_linear_h2(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* cscale, const float* bias,
+                       const float* residual, float* y, uint16_t* yp, int64_t y_rows, int yp_exp, int M, int N, int K, int act,
+                       void* stream);
+int avsep_op_layernorm_h2(const float* x, const float* gamma, const float* beta, uint16_t* yp, int64_t rows, int M, int d, float eps, int e,
+                          void* stream);
+int avsep_op_attention_split_h2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* op, int64_t rows,
+                                int e, int B, int nhead, int dh, int Lq, int Lk, void* stream);
 int avsep_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                        float eps, void* stream);
 /* y = act(LayerNorm(x) W^T + b), the pair every pre-norm block of the model is made of (model.py:48-52 norm_first

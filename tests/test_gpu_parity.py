@@ -282,6 +282,8 @@ def test_full_batch_properties_big_configs(golden, dev, wl):
     assert maxabs(sliced(mk, 7), g["masks.slice"]) < MASK_TOL
     assert maxabs(sliced(sp, 7), g["separated.slice"]) < MASK_TOL * scale
     assert abs(mk.astype(np.float64).sum() - g["masks.sum"]) < 1e-6 * g["masks.abssum"]
+    # (The full batch and the 17-clip slice run the pre-split GEMM -- bf16 planes written by LayerNorm / attention / FFN-1 / the
+    # resize, csrc/gemm_planes.hip, round 5 --, the 1- and 3-clip slices the kernels that split in flight: same bits, asserted above.)
 
 
 def test_data_writes_are_picked_up_after_invalidate_or_mode_change(dev, golden):
@@ -787,6 +789,244 @@ def test_op_linear_split_precision(lib, dev, M, N, K, act, res):
                                      y2.data_ptr(), 1, N, K, act, _stream()) == 0
     assert torch.equal(y2[0], y1[m])
     assert lib.avsep_op_linear_split(x.data_ptr(), w.data_ptr(), None, None, y1.data_ptr(), 4, 6, 32, 0, _stream()) == -1   # N % 4
+
+
+def _planes_of(lib, x, rows=None):
+    """avsep_op_split_planes of a (M, K) fp32 tensor: int16 view of the bf16 planes, (K/32, 3, rows, 32)"""
+    M, K = x.shape
+    rows = rows or M
+    P = torch.zeros(K // 32, 3, rows, 32, dtype=torch.int16, device=x.device)
+    assert lib.avsep_op_split_planes(x.data_ptr(), x.stride(0), P.data_ptr(), rows, M, K, _stream()) == 0, lib.avsep_last_error()
+    return P
+
+
+def test_plane_format_is_the_documented_one(lib, dev):
+    """include/avsep.h: element (m, k) of term t sits at ((k/32 * 3 + t) * rows + m) * 32 + k % 32; hi = the upper 16 bits of x,
+    mid = the upper 16 bits of x - hi, lo = the upper 16 bits of x - hi - mid (truncation), hi + mid + lo == x exactly; rows of
+    the buffer beyond M are left alone."""
+    M, K, rows = 37, 96, 41
+    x = t(seeded.tensor(5, "x", (M, K), -7, 9), dev)
+    P = _planes_of(lib, x, rows)
+    terms = (P.to(torch.int32) << 16).view(torch.float32)            # bf16 bits -> fp32 values, (K/32, 3, rows, 32)
+    assert float(terms[:, :, M:].abs().max()) == 0.0
+    hi, mid, lo = (terms[:, j, :M].permute(1, 0, 2).reshape(M, K) for j in range(3))
+    assert torch.equal(hi, (x.view(torch.int32) & -65536).view(torch.float32))
+    assert torch.equal(mid, ((x - hi).view(torch.int32) & -65536).view(torch.float32))
+    assert torch.equal(hi.double() + mid.double() + lo.double(), x.double())
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(16064, 512, 512, 0, True), (3200, 1536, 512, 1, False), (4016, 512, 2048, 2, True),
+                                           (12300, 644, 544, 2, True), (515, 256, 64, 1, True), (300, 128, 32, 0, False),
+                                           (1, 512, 512, 2, True), (24600, 260, 64, 3, True)])
+def test_op_linear_planes(lib, dev, M, N, K, act, res):
+    """The pre-split GEMM (csrc/gemm_planes.hip: operands as bf16 planes cut once by their producer, staged by LDS-DMA) computes the
+    SAME BITS as the split-precision kernels that cut their operands in flight (avsep_op_linear_split), on every shape class --
+    ragged M and N, one chunk, many tiles per workgroup, a row view of a taller plane buffer --, so the forward may choose between
+    them by the row count; its plane-output epilogue writes exactly the planes of the fp32 result."""
+    x = t(seeded.tensor(29, "x", (M, K), -3, 5), dev)
+    w = t(seeded.tensor(29, "w", (N, K), -0.2, 0.2), dev)
+    b = t(seeded.tensor(29, "b", (N,), -1, 1), dev)
+    r = t(seeded.tensor(29, "r", (M, N), -2, 2), dev) if res else None
+    rp = r.data_ptr() if res else None
+    y0 = torch.full((M, N), float("nan"), device=dev)
+    y1 = torch.full((M, N), float("nan"), device=dev)
+    assert lib.avsep_op_linear_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), rp, y0.data_ptr(), M, N, K, act, _stream()) == 0
+    # the A planes live in a buffer of more rows, and the GEMM reads a view that starts 3 rows in (the forward's half batches)
+    xx = torch.cat([torch.full((3, K), 1e30, device=dev), x, torch.full((2, K), -1e30, device=dev)])
+    xp, wp = _planes_of(lib, xx), _planes_of(lib, w)
+    xview = xp.data_ptr() + 3 * 32 * 2
+    assert lib.avsep_op_linear_planes(xview, M + 5, wp.data_ptr(), N, b.data_ptr(), rp, y1.data_ptr(), None, 0, M, N, K, act, _stream()) == 0, \
+        lib.avsep_last_error()
+    assert torch.equal(y0, y1)
+    if not res and N % 32 == 0 and act != 3:
+        yp = torch.zeros(N // 32, 3, M + 2, 32, dtype=torch.int16, device=dev)
+        assert lib.avsep_op_linear_planes(xview, M + 5, wp.data_ptr(), N, b.data_ptr(), None, None, yp.data_ptr(), M + 2, M, N, K, act,
+                                          _stream()) == 0, lib.avsep_last_error()
+        assert torch.equal(yp, _planes_of(lib, y0, M + 2))
+    assert lib.avsep_op_linear_planes(xview, M - 1, wp.data_ptr(), N, None, None, y1.data_ptr(), None, 0, M, N, K, 0, _stream()) == -1   # rows < M
+
+
+def test_plane_producers_write_the_planes_of_their_fp32_twins(lib, dev):
+    """LayerNorm, the linear resize and the split-precision attention, writing bf16 planes for the GEMM that consumes them
+    (what the d_model >= 512 forward runs from 48 tiles of 256 x 128 on): exactly avsep_op_split_planes of the fp32 op's output."""
+    M, d = 1003, 512
+    x = t(seeded.tensor(31, "x", (M, d), -3, 5), dev)
+    g = t(seeded.tensor(31, "g", (d,), 0.5, 1.5), dev)
+    be = t(seeded.tensor(31, "b", (d,), -0.5, 0.5), dev)
+    y = torch.empty(M, d, device=dev)
+    assert lib.avsep_op_layernorm(x.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), M, d, 1e-5, _stream()) == 0
+    yp = torch.zeros(d // 32, 3, M + 4, 32, dtype=torch.int16, device=dev)
+    assert lib.avsep_op_layernorm_planes(x.data_ptr(), g.data_ptr(), be.data_ptr(), yp.data_ptr(), M + 4, M, d, 1e-5, _stream()) == 0
+    assert torch.equal(yp, _planes_of(lib, y, M + 4))
+    B, N, T = 3, 50, 251
+    v = t(seeded.tensor(33, "v", (B * N, d), -2, 2), dev)
+    u = torch.empty(B * T, d, device=dev)
+    assert lib.avsep_op_interp_linear(v.data_ptr(), u.data_ptr(), B, N, T, d, _stream()) == 0
+    up = torch.zeros(d // 32, 3, B * T, 32, dtype=torch.int16, device=dev)
+    assert lib.avsep_op_interp_linear_planes(v.data_ptr(), up.data_ptr(), B * T, B, N, T, d, _stream()) == 0
+    assert torch.equal(up, _planes_of(lib, u))
+    for (B, h, Lq, Lk) in ((2, 8, 251, 251), (3, 2, 130, 129), (1, 2, 40, 300)):
+        dm = 64 * h
+        q = t(seeded.tensor(35, "q", (B * Lq, dm), -1, 1), dev)
+        kv = t(seeded.tensor(35, "kv", (B * Lk, 2 * dm), -1, 1), dev)
+        o = torch.empty(B * Lq, dm, device=dev)
+        assert lib.avsep_op_attention_split(q.data_ptr(), dm, kv.data_ptr(), 2 * dm, kv.data_ptr() + 4 * dm, 2 * dm, o.data_ptr(), dm,
+                                            B, h, 64, Lq, Lk, _stream()) == 0
+        op = torch.zeros(dm // 32, 3, B * Lq + 1, 32, dtype=torch.int16, device=dev)
+        assert lib.avsep_op_attention_split_planes(q.data_ptr(), dm, kv.data_ptr(), 2 * dm, kv.data_ptr() + 4 * dm, 2 * dm, op.data_ptr(),
+                                                   B * Lq + 1, B, h, 64, Lq, Lk, _stream()) == 0
+        assert torch.equal(op, _planes_of(lib, o, B * Lq + 1)), (B, h, Lq, Lk)
+
+
+def _h2_exp(bound):
+    """the exponent e with bound * 2^e <= 2^14 (csrc/avsep_api.hip h2_exponent)"""
+    import math
+    return 14 - math.frexp(bound * (1.0 + 1e-5))[1] if bound > 0 else 0
+
+
+def _h2_planes(lib, x, e, rows=None, row_exp=None):
+    M, K = x.shape
+    rows = rows or M
+    P = torch.zeros(K // 32, 2, rows, 32, dtype=torch.int16, device=x.device)
+    assert lib.avsep_op_split_h2(x.data_ptr(), x.stride(0), P.data_ptr(), rows, M, K, row_exp.data_ptr() if row_exp is not None else None,
+                                 e, _stream()) == 0, lib.avsep_last_error()
+    return P
+
+
+def _h2_weight(lib, w):
+    """what avsep_finalize_weights does per weight: row exponents, row norms, the scaled planes"""
+    N, K = w.shape
+    ew = torch.zeros(N, dtype=torch.int32, device=w.device)
+    l2 = torch.zeros(N, device=w.device)
+    assert lib.avsep_op_h2_row_stats(w.data_ptr(), N, K, ew.data_ptr(), l2.data_ptr(), _stream()) == 0
+    return _h2_planes(lib, w, 0, row_exp=ew), ew, l2
+
+
+def test_h2_plane_format_and_row_statistics(lib, dev):
+    """include/avsep.h: H2 planes = fp16 [K/32][2][rows][32] of x 2^e -- hi = rn16(x 2^e), lo = rn16(x 2^e - hi), hi + lo within 2^-22 of
+    x 2^e; a weight row's exponent puts its largest magnitude into [2^13, 2^14) and its reported norm is not below the true one."""
+    M, K = 37, 96
+    x = t(seeded.tensor(7, "x", (M, K), -7, 9), dev)
+    e = _h2_exp(9.0)
+    P = _h2_planes(lib, x, e, rows=M + 3)
+    terms = P.view(torch.float16).float()                              # (K/32, 2, rows, 32)
+    assert float(terms[:, :, M:].abs().max()) == 0.0
+    hi, lo = (terms[:, j, :M].permute(1, 0, 2).reshape(M, K) for j in range(2))
+    xs = x * 2.0 ** e
+    assert torch.equal(hi, xs.half().float()) and torch.equal(lo, (xs - hi).half().float())
+    assert float(((hi.double() + lo.double()) - xs.double()).abs().max()) <= 2.0 ** -22 * float(xs.abs().max())
+    w = t(seeded.tensor(7, "w", (50, K), -0.3, 0.3), dev)
+    w[3] = 0.0
+    w[4] *= 1e-20
+    w[5] *= 1e20
+    _, ew, l2 = _h2_weight(lib, w)
+    mx = (w.double().abs().max(dim=1).values * 2.0 ** ew.double()).cpu()
+    assert int(ew[3]) == 0 and bool(((mx >= 2.0 ** 13) & (mx < 2.0 ** 14))[torch.arange(50) != 3].all())
+    assert bool((l2.double() >= w.double().norm(dim=1)).all()) and bool((l2.double() <= w.double().norm(dim=1) * (1 + 1e-5) + 1e-30).all())
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(16064, 512, 512, 0, True), (3200, 1536, 512, 1, False), (4016, 512, 2048, 2, True),
+                                           (12300, 644, 544, 2, True), (515, 256, 64, 1, True), (300, 128, 32, 0, False),
+                                           (251, 2048, 512, 1, False), (1, 512, 512, 2, True), (24600, 260, 64, 3, True)])
+def test_op_linear_h2(lib, dev, M, N, K, act, res):
+    """The two-term fp16 GEMM (csrc/gemm_h2.hip: three fp16 MFMA products per fp32 product; what the d_model >= 512 forward runs for
+    every Linear whose input has a static bound).  Operands as avsep_finalize_weights prepares them: x scaled by ONE power of two
+    from a bound on the whole tensor (here 8x its true maximum -- the static bounds overshoot), w by a power of two per row.
+    Against float64 the error must sit at the fp32-MFMA GEMM's level -- the gate of test_op_linear_split_precision: 2x that kernel's
+    error on the same operands + 2e-7 of max|y|, 4e-6 absolutely --; a row computed alone (64 x 64 kernel) has the bits it has inside
+    the full problem (256 x 128 kernel from 48 of its tiles on); the plane output is exactly avsep_op_split_h2 of the fp32 output."""
+    x = t(seeded.tensor(41, "x", (M, K), -3, 5), dev)
+    w = t(seeded.tensor(41, "w", (N, K), -0.2, 0.2), dev)
+    b = t(seeded.tensor(41, "b", (N,), -1, 1), dev)
+    r = t(seeded.tensor(41, "r", (M, N), -2, 2), dev) if res else None
+    rp = r.data_ptr() if res else None
+    ref = x.double() @ w.double().t() + b.double()
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.nn.functional.gelu(ref), 3: torch.sigmoid(ref)}[act]
+    if res:
+        ref = ref + r.double()
+    ex = _h2_exp(8.0 * float(x.abs().max()))
+    xp = _h2_planes(lib, x, ex, rows=M + 5)
+    wp, ew, _ = _h2_weight(lib, w)
+    cs = torch.ldexp(torch.ones(N, device=dev), -(ew + ex))
+    y0 = torch.full((M, N), float("nan"), device=dev)
+    y1 = torch.full((M, N), float("nan"), device=dev)
+    assert lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), rp, y0.data_ptr(), M, N, K, act, _stream()) == 0
+    assert lib.avsep_op_linear_h2(xp.data_ptr(), M + 5, wp.data_ptr(), N, cs.data_ptr(), b.data_ptr(), rp, y1.data_ptr(), None, 0, 0,
+                                  M, N, K, act, _stream()) == 0, lib.avsep_last_error()
+    assert torch.isfinite(y1).all()
+    scale = float(ref.abs().max())
+    e0 = float((y0.double() - ref).abs().max()) / scale
+    e1 = float((y1.double() - ref).abs().max()) / scale
+    assert e1 < 2.0 * e0 + 2e-7, (e0, e1)
+    assert e1 < 4e-6, (e0, e1)
+    m = M // 2                                                    # one row alone: the bits it has inside the full problem
+    y2 = torch.full((1, N), float("nan"), device=dev)
+    x2p = _h2_planes(lib, x[m:m + 1].contiguous(), ex)
+    r2 = r[m:m + 1].contiguous() if res else None
+    assert lib.avsep_op_linear_h2(x2p.data_ptr(), 1, wp.data_ptr(), N, cs.data_ptr(), b.data_ptr(), r2.data_ptr() if res else None,
+                                  y2.data_ptr(), None, 0, 0, 1, N, K, act, _stream()) == 0
+    assert torch.equal(y2[0], y1[m])
+    if not res and N % 32 == 0 and act != 3:
+        ey = _h2_exp(4.0 * float(y1.abs().max()))
+        yp = torch.zeros(N // 32, 2, M + 2, 32, dtype=torch.int16, device=dev)
+        assert lib.avsep_op_linear_h2(xp.data_ptr(), M + 5, wp.data_ptr(), N, cs.data_ptr(), b.data_ptr(), None, None, yp.data_ptr(), M + 2, ey,
+                                      M, N, K, act, _stream()) == 0, lib.avsep_last_error()
+        assert torch.equal(yp, _h2_planes(lib, y1, ey, rows=M + 2))
+    assert lib.avsep_op_linear_h2(xp.data_ptr(), M - 1, wp.data_ptr(), N, cs.data_ptr(), None, None, y1.data_ptr(), None, 0, 0, M, N, K, 0,
+                                  _stream()) == -1                                                                  # rows < M
+
+
+def test_h2_wide_dynamic_range_and_extreme_scales(lib, dev):
+    """The two-term scheme is accurate NORMWISE: with magnitudes from 1e-6 to 1e3 inside every row of x and weight rows from 1e-12
+    to 1e12 the error stays below 2^-19 of sum_k |x_k| |w_k| (three representation / dropped-term remainders of 2^-22 each plus the
+    fp32 accumulation; measured 1.1e-6) -- an fp32 dot product's own bound is K 2^-24 = 3e-5 of it."""
+    M, N, K = 700, 512, 512
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g) * 3.0)).to(dev)
+    w = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, K, generator=g) * 1.5) * 10.0 ** torch.randint(-12, 13, (N, 1), generator=g).float()).to(dev)
+    ex = _h2_exp(float(x.abs().max()))
+    xp = _h2_planes(lib, x, ex)
+    wp, ew, _ = _h2_weight(lib, w)
+    cs = torch.ldexp(torch.ones(N, device=dev), -(ew + ex))
+    y = torch.full((M, N), float("nan"), device=dev)
+    assert lib.avsep_op_linear_h2(xp.data_ptr(), M, wp.data_ptr(), N, cs.data_ptr(), None, None, y.data_ptr(), None, 0, 0, M, N, K, 0,
+                                  _stream()) == 0, lib.avsep_last_error()
+    ref = x.double() @ w.double().t()
+    mag = x.double().abs() @ w.double().abs().t()
+    assert torch.isfinite(y).all()
+    assert float(((y.double() - ref).abs() / mag).max()) < 2.0 ** -19
+
+
+def test_h2_producers_write_the_planes_of_their_fp32_twins(lib, dev):
+    """LayerNorm and the split-precision attention writing H2 planes: exactly avsep_op_split_h2 (with the site's exponent) of the fp32
+    op's output -- and the LayerNorm site's STATIC exponent (from sqrt(d - 1) |gamma| + |beta| alone) holds for the worst input there
+    is, rows whose variance sits in ONE element: nothing overflows fp16."""
+    M, d = 1003, 512
+    x = t(seeded.tensor(43, "x", (M, d), -3, 5), dev)
+    x[:64] = 0.0
+    x[torch.arange(64), torch.arange(64) * 7] = 1.0e4               # one-hot rows: |xhat| reaches sqrt(d - 1)
+    g = t(seeded.tensor(43, "g", (d,), -1.5, 1.5), dev)
+    be = t(seeded.tensor(43, "b", (d,), -0.5, 0.5), dev)
+    e = _h2_exp(float(((d - 1) ** 0.5 * g.abs() + be.abs()).max()))
+    y = torch.empty(M, d, device=dev)
+    assert lib.avsep_op_layernorm(x.data_ptr(), g.data_ptr(), be.data_ptr(), y.data_ptr(), M, d, 1e-5, _stream()) == 0
+    assert float(y.abs().max()) * 2.0 ** e <= 2.0 ** 14 and float(y[:64].abs().max()) > 15.0
+    yp = torch.zeros(d // 32, 2, M + 4, 32, dtype=torch.int16, device=dev)
+    assert lib.avsep_op_layernorm_h2(x.data_ptr(), g.data_ptr(), be.data_ptr(), yp.data_ptr(), M + 4, M, d, 1e-5, e, _stream()) == 0
+    assert torch.isfinite(yp.view(torch.float16).float()).all()
+    assert torch.equal(yp, _h2_planes(lib, y, e, rows=M + 4))
+    for (B, h, Lq, Lk) in ((2, 8, 251, 251), (3, 2, 130, 129), (1, 2, 40, 300)):
+        dm = 64 * h
+        q = t(seeded.tensor(45, "q", (B * Lq, dm), -1, 1), dev)
+        kv = t(seeded.tensor(45, "kv", (B * Lk, 2 * dm), -1, 1), dev)
+        o = torch.empty(B * Lq, dm, device=dev)
+        assert lib.avsep_op_attention_split(q.data_ptr(), dm, kv.data_ptr(), 2 * dm, kv.data_ptr() + 4 * dm, 2 * dm, o.data_ptr(), dm,
+                                            B, h, 64, Lq, Lk, _stream()) == 0
+        eo = _h2_exp(1.0)                                               # a convex combination of value rows: |o| <= max|v| <= 1
+        op = torch.zeros(dm // 32, 2, B * Lq + 1, 32, dtype=torch.int16, device=dev)
+        assert lib.avsep_op_attention_split_h2(q.data_ptr(), dm, kv.data_ptr(), 2 * dm, kv.data_ptr() + 4 * dm, 2 * dm, op.data_ptr(),
+                                               B * Lq + 1, eo, B, h, 64, Lq, Lk, _stream()) == 0
+        assert torch.equal(op, _h2_planes(lib, o, eo, rows=B * Lq + 1)), (B, h, Lq, Lk)
 
 
 @pytest.mark.parametrize("M", [3, 300, 20000])
