@@ -345,6 +345,268 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(const GemmParams pin) {
 #undef H2_MMA_D
 }
 
+// ---- the same tile with the fragments one chunk ahead ----------------------------------------------------------------------------
+// With half the MFMAs per chunk the barrier, the first fragments' LDS latency behind it and the DMA issue weigh twice as much
+// (gemm_h2_kernel: ~57 % of the matrix pipe).  Here a chunk's fragments are ALL in registers before its first MFMA -- requested
+// right behind the previous chunk's barrier, into a second register set (2 x 64 fragment + 64 accumulator registers) --, so the
+// step is: barrier (everyone's fragments of this chunk have arrived: its buffer is free; everyone's DMA of the next chunk has
+// landed), request the next chunk's fragments, then 48 MFMAs from registers with the DMA of the chunk after next between them.
+// Reads and DMA both get a whole chunk period.  The two register sets alternate in a loop unrolled by two: K % 64 == 0.
+// The last chunk of a tile requests nothing (the epilogue wants the registers); the next tile's first fragments follow the epilogue.
+__global__ __launch_bounds__(512, 1) void gemm_h2_kernel2(const GemmParams pin) {
+  GemmParams p = pin;
+  constexpr int BM = 256, BN = 128, WBN = 4;
+  constexpr int APL = BM * 64, WPL = BN * 64;
+  constexpr int BUF = 2 * APL + 2 * WPL;                                   // 48 KB
+  extern __shared__ __attribute__((aligned(1024))) char ldsh[];           // 2 x BUF
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + BN - 1) / BN;
+  const int ntiles = ((p.M + BM - 1) / BM) * nbn;
+  int tile, tile_end, tile_step;
+  {
+    const int G = gridDim.x, b = blockIdx.x;
+    if (p.no_xcd_remap) {
+      tile = b; tile_end = ntiles; tile_step = G;
+    } else {
+      const int xcd = b & 7, q = ntiles >> 3, r = ntiles & 7;
+      const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      tile = start + (b >> 3);
+      tile_end = start + q + (xcd < r ? 1 : 0);
+      tile_step = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    }
+  }
+  if (tile >= tile_end) return;                                            // block-uniform
+
+  const int lr = lane >> 2;
+  const int lslot = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) << 4;
+  auto tile_rows = [&](int t) {
+    const int bm = t / nbn, bn = t - bm * nbn;
+    H2Tile r;
+    r.a0 = (unsigned)min(bm * BM + 16 * wave + lr, p.M - 1) * 64u + lslot;
+    r.a1 = (unsigned)min(bm * BM + 16 * (wave + 8) + lr, p.M - 1) * 64u + lslot;
+    r.w0 = (unsigned)min(bn * BN + 16 * wave + lr, p.N - 1) * 64u + lslot;
+    r.w1 = r.w0;
+    return r;
+  };
+  const size_t a_ts = (size_t)p.a_rows * 64, w_ts = (size_t)p.w_rows * 64;
+  // piece q = 0 .. 3: A (term q / 2, row block wave + 8 (q % 2)); 4, 5: W (term q - 4, row block wave)
+#define K2_PIECE(kc, T, buf, q)                                                                                                  \
+  {                                                                                                                              \
+    char* lb_ = ldsh + (buf) * BUF;                                                                                              \
+    if ((q) < 4) {                                                                                                               \
+      const int t_ = (q) >> 1, k_ = (q) & 1;                                                                                     \
+      const char* as_ = reinterpret_cast<const char*>(p.Ap) + ((size_t)(kc) * 2 + t_) * a_ts;                                    \
+      __builtin_amdgcn_global_load_lds((gptr_t)(as_ + (k_ ? T.a1 : T.a0)), (lptr_t)(lb_ + t_ * APL + (wave + 8 * k_) * 1024), 16, 0, 0); \
+    } else {                                                                                                                     \
+      const int t_ = (q) - 4;                                                                                                    \
+      const char* ws_ = reinterpret_cast<const char*>(p.Wp) + ((size_t)(kc) * 2 + t_) * w_ts;                                    \
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws_ + T.w0), (lptr_t)(lb_ + 2 * APL + t_ * WPL + wave * 1024), 16, 0, 0);        \
+    }                                                                                                                            \
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_fo[4], w_fo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 64 + 16 * i + fr;
+    a_fo[i] = r * 64 + ((fq ^ ((0 - (r >> 2)) & 3)) << 4);
+    const int c = wn * 64 + 16 * i + fr;
+    w_fo[i] = 2 * APL + c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
+  }
+  const int nk = p.K >> 5;                                                 // even (launcher)
+
+  int f_tile = tile, f_kc = 0;                                             // fetch cursor: two chunks ahead of the products
+  H2Tile f_rows = tile_rows(tile);
+#define K2_ADVANCE                                   \
+  if (++f_kc == nk) {                                \
+    f_kc = 0;                                        \
+    if (f_tile + tile_step < tile_end) {             \
+      f_tile += tile_step;                           \
+      f_rows = tile_rows(f_tile);                    \
+    }                                                \
+  }
+#define K2_ALL_PIECES(buf) _Pragma("unroll") for (int q = 0; q < 6; ++q) K2_PIECE(f_kc, f_rows, buf, q)
+  K2_ALL_PIECES(0)
+  K2_ADVANCE
+  K2_ALL_PIECES(1)
+  K2_ADVANCE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  struct Frags { f16x8 a_hi[4], a_lo[4], w_hi[4], w_lo[4]; };
+#define K2_READ(F, buf)                                                                        \
+  {                                                                                            \
+    const char* rb_ = ldsh + (buf) * BUF;                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+      F.a_hi[i] = *reinterpret_cast<const f16x8*>(rb_ + a_fo[i]);                              \
+      F.w_lo[i] = *reinterpret_cast<const f16x8*>(rb_ + WPL + w_fo[i]);                        \
+    }                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+      F.a_lo[i] = *reinterpret_cast<const f16x8*>(rb_ + APL + a_fo[i]);                        \
+      F.w_hi[i] = *reinterpret_cast<const f16x8*>(rb_ + w_fo[i]);                              \
+    }                                                                                          \
+  }
+#define K2_FENCE __builtin_amdgcn_sched_barrier(0);
+#define K2_MMA(fwp, fap)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                 \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
+  // a product with the DMA pieces q0, q0 + 1, q0 + 2 of this step's fetch (-> buffer buf) behind its MFMAs 5, 10 and 15
+#define K2_MMA_D(fwp, fap, buf, q0)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0);                   \
+    const int idx_ = i * 4 + j;                                                                               \
+    if (idx_ % 5 == 4) { K2_FENCE K2_PIECE(l_kc, l_rows, buf, (q0) + idx_ / 5) K2_FENCE }                     \
+  }
+  // one chunk: its fragments are in CUR (buffer B); NXT receives the next chunk's (buffer B ^ 1) unless `last`
+#define K2_STEP(CUR, NXT, B, last)                                                             \
+  {                                                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+    __syncthreads();                                                                           \
+    if (!(last)) K2_READ(NXT, (B) ^ 1)                                                         \
+    const int l_kc = f_kc;                                                                     \
+    const H2Tile l_rows = f_rows;                                                              \
+    K2_ADVANCE                                                                                 \
+    K2_FENCE                                                                                   \
+    K2_MMA(CUR.w_lo, CUR.a_hi)        /* (hi, lo) */                                           \
+    K2_MMA_D(CUR.w_hi, CUR.a_lo, B, 0) /* (lo, hi) */                                          \
+    K2_MMA_D(CUR.w_hi, CUR.a_hi, B, 3) /* (hi, hi) */                                          \
+  }
+
+  Frags f0, f1;
+  f32x4 acc[4][4];
+  K2_READ(f0, 0)
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 2; kc < nk; kc += 2) {
+      K2_STEP(f0, f1, 0, false)
+      K2_STEP(f1, f0, 1, false)
+    }
+    K2_STEP(f0, f1, 0, false)                                             // the tile's last two chunks, peeled: the very last requests nothing
+    K2_STEP(f1, f0, 1, true)
+    {
+      const int bm = tile / nbn, bn = tile - bm * nbn;
+      if (p.Cp) h2_planes_epilogue<WBN>(p, acc, bm * BM + wm * 64, bn * BN + wn * 64, fr, fq);
+      if (p.C) {
+        h2_descale<WBN>(p, acc, bn * BN + wn * 64, fq);
+        gemm_epilogue<4, WBN>(p, acc, bm * BM, bn * BN, wm * 64, wn * 64, fr, fq);
+      }
+    }
+    tile += tile_step;
+    if (tile >= tile_end) break;
+    K2_READ(f0, 0)                                                         // certified by the last step's barrier
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // no DMA may outlive the workgroup's LDS
+#undef K2_PIECE
+#undef K2_ADVANCE
+#undef K2_ALL_PIECES
+#undef K2_READ
+#undef K2_FENCE
+#undef K2_MMA
+#undef K2_MMA_D
+#undef K2_STEP
+}
+
+// ---- 128 x 128 tile, 256 threads, TWO workgroups per CU --------------------------------------------------------------------------
+// With three products per chunk a 512-thread workgroup alone on its CU spends as long at its barrier, its first fragments and its DMA
+// instructions as in its MFMAs; two independent 4-wave workgroups per CU (2 x 2 waves of 64 x 64, 2 x 32 KB of LDS each) cover each
+// other's -- the same eight waves per CU, no shared barrier.  One tile per workgroup (the CU's other workgroup covers prologue and
+// epilogue), the next chunk's DMA issued at the top of the chunk.  Same three products in the same order per element: same bits.
+__global__ __launch_bounds__(256, 2) void gemm_h2_mid_kernel(const GemmParams pin) {
+  GemmParams p = pin;
+  constexpr int B = 128, PL = B * 64, BUF = 4 * PL;                        // 32 KB per stage: [A hi|lo][W hi|lo]
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = (p.N + B - 1) / B;
+  const int tile = xcd_tile(p);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int m0 = bm * B, n0 = bn * B;
+  // DMA: 32 pieces of 1 KiB per chunk, eight per wave: row blocks wave and wave + 4 of both terms of both operands
+  const int lr = lane >> 2;
+  const int lslot = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) << 4;
+  const unsigned a_off0 = (unsigned)min(m0 + 16 * wave + lr, p.M - 1) * 64u + lslot;
+  const unsigned a_off1 = (unsigned)min(m0 + 16 * (wave + 4) + lr, p.M - 1) * 64u + lslot;
+  const unsigned w_off0 = (unsigned)min(n0 + 16 * wave + lr, p.N - 1) * 64u + lslot;
+  const unsigned w_off1 = (unsigned)min(n0 + 16 * (wave + 4) + lr, p.N - 1) * 64u + lslot;
+  const size_t a_ts = (size_t)p.a_rows * 64, w_ts = (size_t)p.w_rows * 64;
+  // piece q (0 .. 7) of chunk kc -> buffer buf: operand q / 4, term (q / 2) % 2, row block wave + 4 (q % 2)
+#define HM_PIECE(kc, buf, q)                                                                                             \
+  {                                                                                                                      \
+    char* lb_ = lds + (buf) * BUF + (((q) >> 1) & 1) * PL + ((q) >> 2) * 2 * PL + (wave + 4 * ((q) & 1)) * 1024;          \
+    if ((q) < 4) {                                                                                                       \
+      const char* as_ = reinterpret_cast<const char*>(p.Ap) + ((size_t)(kc) * 2 + (((q) >> 1) & 1)) * a_ts;               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(as_ + (((q) & 1) ? a_off1 : a_off0)), (lptr_t)lb_, 16, 0, 0);            \
+    } else {                                                                                                             \
+      const char* ws_ = reinterpret_cast<const char*>(p.Wp) + ((size_t)(kc) * 2 + (((q) >> 1) & 1)) * w_ts;               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws_ + (((q) & 1) ? w_off1 : w_off0)), (lptr_t)lb_, 16, 0, 0);            \
+    }                                                                                                                    \
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_fo[4], w_fo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 64 + 16 * i + fr;
+    a_fo[i] = r * 64 + ((fq ^ ((0 - (r >> 2)) & 3)) << 4);
+    const int c = wn * 64 + 16 * i + fr;
+    w_fo[i] = 2 * PL + c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K >> 5;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) HM_PIECE(0, 0, q)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#define HM_FENCE __builtin_amdgcn_sched_barrier(0);
+#define HM_MMA(fwp, fap)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
+  // a product with DMA pieces q0 .. q0 + 3 of the next chunk behind its MFMAs 4, 8, 12 and 16 (block-uniform `more`)
+#define HM_MMA_D(fwp, fap, q0)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {           \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0);               \
+    if (j == 3 && more) { HM_FENCE HM_PIECE(kc + 1, (kc + 1) & 1, (q0) + i) HM_FENCE }                    \
+  }
+  for (int kc = 0; kc < nk; ++kc) {
+    const bool more = kc + 1 < nk;                                         // the barrier that ended chunk kc - 1 freed the other buffer
+    const char* rb = lds + (kc & 1) * BUF;
+    f16x8 a_hi[4], a_lo[4], w_hi[4], w_lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_hi[i] = *reinterpret_cast<const f16x8*>(rb + a_fo[i]);
+      w_lo[i] = *reinterpret_cast<const f16x8*>(rb + PL + w_fo[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_lo[i] = *reinterpret_cast<const f16x8*>(rb + PL + a_fo[i]);
+      w_hi[i] = *reinterpret_cast<const f16x8*>(rb + w_fo[i]);
+    }
+    HM_FENCE
+    HM_MMA_D(w_lo, a_hi, 0) /* (hi, lo) */
+    HM_MMA_D(w_hi, a_lo, 4) /* (lo, hi) */
+    HM_MMA(w_hi, a_hi)      /* (hi, hi) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef HM_PIECE
+#undef HM_FENCE
+#undef HM_MMA
+#undef HM_MMA_D
+  if (p.Cp) h2_planes_epilogue<4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
+  if (p.C) {
+    h2_descale<4>(p, acc, n0 + wn * 64, fq);
+    gemm_epilogue<4, 4>(p, acc, m0, n0, wm * 64, wn * 64, fr, fq);
+  }
+}
+
 // ---- small problems: 64 x 64 tile, one tile per workgroup, 2 x 2 waves of 32 x 32 (three workgroups per CU) -------------------------
 // The same three products in the same order per element: a row has the same bits here as in the 256-row kernel, so the choice
 // between them may look at the row count (and the forward computes the same bits at every batch size).
@@ -508,6 +770,7 @@ static int h2_variant(const GemmParams& p) {
   const long t128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   int v = t128 >= (p.split_t2_min > 0 ? p.split_t2_min : 128) ? 128 : 64;
 #ifdef AVSEP_DEV
+  if (const char* e = getenv("AVSEP_H2_T2MIN")) v = t128 >= atoi(e) ? 128 : 64;                      // developer A/B
   if (const char* e = getenv("AVSEP_H2_TILE")) v = atoi(e) == 64 || atoi(e) == 128 ? atoi(e) : v;   // developer A/B
 #endif
   return v;
@@ -539,11 +802,41 @@ static hipError_t launch_h2_big(const GemmParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+static hipError_t launch_h2_big2(const GemmParams& p, hipStream_t s) {
+  constexpr int BUF = 2 * 256 * 64 + 2 * 128 * 64;
+  static bool raised[64] = {};
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!raised[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+    if (attr != hipSuccess) return attr;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return hipErrorInvalidDevice;
+    cus[dev] = n;
+    raised[dev] = true;
+  }
+  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  const long grid = tiles < cus[dev] ? tiles : cus[dev];
+  hipLaunchKernelGGL(gemm_h2_kernel2, dim3((unsigned)grid), dim3(512), 2 * BUF, s, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_gemm_h2(GemmParams p, hipStream_t s) {
   if (!gemm_h2_supported(p) || p.M <= 0 || p.N <= 0 || p.K <= 0) return hipErrorInvalidValue;
   p.nbn_magic = 0;
   if (!p.W) p.W = reinterpret_cast<const float*>(p.Wp);   // gemm_tile.h's epilogue reads N floats from W when there is no bias (discarded)
-  if (h2_variant(p) == 128) return launch_h2_big<128>(p, s);
+  if (h2_variant(p) == 128) {
+#ifdef AVSEP_DEV
+    if (getenv("AVSEP_H2_KERNEL2") && !(p.K & 63)) return launch_h2_big2(p, s);   // developer A/B
+    if (getenv("AVSEP_H2_MID")) {
+      const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+      hipLaunchKernelGGL(gemm_h2_mid_kernel, dim3((unsigned)tiles), dim3(256), 0, s, p);
+      return hipGetLastError();
+    }
+#endif
+    return launch_h2_big<128>(p, s);
+  }
   const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   hipLaunchKernelGGL(gemm_h2_small_kernel, dim3((unsigned)tiles), dim3(256), 0, s, p);
   return hipGetLastError();
