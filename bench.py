@@ -38,9 +38,31 @@ import torch  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (spec)
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (spec; 16x the fp32 MFMA's)
-# the split-precision GEMM (csrc/gemm_split.hip) executes SIX bf16 MFMA products per algorithmic fp32 product
-SPLIT_KERNEL, SPLIT_PRODUCTS = "gemm_split_kernel", 6
 HBM_PEAK_GBS = 8000.0
+
+
+def kernel_pipe(name):
+    """(pipe, matrix products executed per algorithmic fp32 product, peak TFLOP/s) of a kernel instance, by its name as
+    rocprofv3 prints it.  The two-term fp16 GEMM (csrc/gemm_h2.hip) executes THREE fp16 MFMA products per fp32 product, the
+    three-term bf16 kernels (gemm_split.hip, gemm_planes.hip, attention_split.hip, wgrad_split.hip) SIX bf16 ones -- both on
+    the 16-bit matrix pipe (2.5 PFLOP/s dense) --, every other matrix kernel one fp32 MFMA; None: no matrix work (HBM-bound)."""
+    if name.startswith("gemm_h2"):
+        return ("fp16 MFMA, 3 products per fp32 product", 3, BF16_MATRIX_PEAK_TFLOPS)
+    if name.startswith(("gemm_split", "gemm_planes", "attention_split", "wgrad_split")):
+        return ("bf16 MFMA, 6 products per fp32 product", 6, BF16_MATRIX_PEAK_TFLOPS)
+    if name.startswith(("gemm_", "attention", "attn_", "conv_stack", "wgrad")):
+        return ("fp32 MFMA", 1, FP32_MATRIX_PEAK_TFLOPS)
+    return None
+
+
+def path_floor(kernels, iters):
+    """Seconds per forward that the step's kernels would take at the peak of the pipe each one actually runs on: executed matrix
+    flops / that pipe's dense peak for the matrix kernels, algorithmic bytes / HBM peak for the rest.  floor / measured <= 1."""
+    t = 0.0
+    for k in kernels:
+        pipe = kernel_pipe(k["name"])
+        t += (k["flops"] * pipe[1] / (pipe[2] * 1e12) if pipe else k["bytes"] / (HBM_PEAK_GBS * 1e9)) / iters
+    return t
 
 WORKLOADS = {
     # name: model kwargs, dataset kwargs, per-GPU batch          (SURVEY.md §8 config table)
@@ -472,9 +494,11 @@ def main():
     launches_per_fwd = dom["calls"] / prof_iters
     # The split-precision GEMM runs on the bf16 matrix pipe: it is priced by the bf16 MFMA flops it EXECUTES (6 per algorithmic
     # fp32 product) against the bf16 dense peak; its algorithmic rate and that rate over the fp32 matrix peak are kept beside it.
-    split_dom = dom["name"].startswith(SPLIT_KERNEL)
-    dom_peak = BF16_MATRIX_PEAK_TFLOPS if split_dom else FP32_MATRIX_PEAK_TFLOPS
-    dom_exec = dom["tflops"] * (SPLIT_PRODUCTS if split_dom else 1)
+    dom_pipe = kernel_pipe(dom["name"]) or ("fp32 MFMA", 1, FP32_MATRIX_PEAK_TFLOPS)
+    split_dom = dom_pipe[1] > 1
+    SPLIT_PRODUCTS = dom_pipe[1]
+    dom_peak = dom_pipe[2]
+    dom_exec = dom["tflops"] * SPLIT_PRODUCTS
     roofline = {
         "bound": "mfma", "kernel": dom["name"],
         "achieved": round(dom_exec, 3), "peak": dom_peak, "unit": "TFLOP/s",
@@ -486,9 +510,14 @@ def main():
         "path_tflops_per_gpu": round(value / world * gflop_clip / 1e3, 3),
         "path_frac": round(value / world * gflop_clip / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
     }
+    floor_s = path_floor(kernels, prof_iters) if not a.no_profile else None
+    if floor_s:
+        # every kernel of the step at the peak of the pipe it runs on (16-bit matrix pipe: executed products; fp32 matrix pipe;
+        # HBM for the row kernels): a fraction <= 1 whatever the arithmetic
+        roofline["path_floor_ms"] = round(floor_s * 1e3, 4)
+        roofline["path_floor_frac"] = round(floor_s / (ms_step * 1e-3), 4)
     if split_dom:
-        roofline["matrix_pipe"] = ("bf16 MFMA (v_mfma_f32_16x16x32_bf16): fp32 operands as three bf16 terms, six products per fp32 "
-                                   "product, fp32 accumulation; `achieved` counts the executed bf16 flops")
+        roofline["matrix_pipe"] = (dom_pipe[0] + ", fp32 accumulation; `achieved` counts the EXECUTED 16-bit flops")
         roofline["algorithmic_tflops"] = round(dom["tflops"], 3)
         roofline["algorithmic_over_fp32_matrix_peak"] = round(dom["tflops"] / FP32_MATRIX_PEAK_TFLOPS, 4)
         roofline["path_frac_note"] = ("path_frac = algorithmic fp32 flops of the whole step over the FP32 matrix peak (SURVEY.md "
@@ -552,7 +581,8 @@ def main():
         "metric": metric_string(mk, dk, R),
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if mk["d_model"] < 512 else "f32 (nn.Linear and attention products as 6 bf16 MFMA products per fp32 product, fp32 accumulation)",
+        "dtype": "f32" if mk["d_model"] < 512 else ("f32 (nn.Linear products as 3 fp16 MFMA products per fp32 product where the input has a static "
+                                                     "bound, else 6 bf16 products like the attention's; fp32 accumulation)"),
         "data": "synthetic",
         "config": {"workload": f"{a.workload}: SyntheticAVDataset {S}-speaker, F={F}, T={T}, N={N}, {H}x{W} lips, "
                                f"d_model={mk['d_model']}, nhead={mk['nhead']}, {mk['num_encoder_layers']}+"
@@ -654,15 +684,56 @@ def also_forward(av, dev, name, steps=20, rounds=5, warmup=4):
         worst, _ = timed_rounds(None, dev, rounds, lambda: run_steps(steps, 2))
         run_steps(2, 1)
         single, _ = timed_rounds(None, dev, rounds, lambda: run_steps(steps, 1))
+        # per-kernel leg (in-library HIP-event profiler, one stream): the dominant kernel against the peak of the pipe it runs
+        # on, and the whole step's floor on the pipes actually used
+        st0 = sets[0]
+        with torch.cuda.stream(st0["stream"]):
+            model.run_static(st0["mixed"], st0["lips"], st0["masks"], st0["sep"], graph=False)
+            st0["stream"].synchronize()
+            model.profile_begin()
+            model.run_static(st0["mixed"], st0["lips"], st0["masks"], st0["sep"], graph=False)
+            st0["stream"].synchronize()
+            kernels = model.profile_end()
+            model.run_static(st0["mixed"], st0["lips"], st0["masks"], st0["sep"], graph=True)
+            st0["stream"].synchronize()
+        # one clip at a time (the reference's own evaluation calls the model at B = 1, demo.py:31-64): the latency a drop-in sees
+        one = dict(mixed=st0["mixed"][:1].contiguous(), lips=st0["lips"][:1].contiguous(), masks=torch.empty(1, T, S, F, device=dev),
+                   sep=torch.empty(1, T, S, F, device=dev))
+        def run_one(n):
+            with torch.cuda.stream(st0["stream"]):
+                for _ in range(n):
+                    model.run_static(one["mixed"], one["lips"], one["masks"], one["sep"], graph=True, slot=0)
+        run_one(3)
+        torch.cuda.synchronize()
+        b1, _ = timed_rounds(None, dev, rounds, lambda: run_one(steps))
+        b1_equal = bool(torch.equal(one["masks"][0], sets[0]["masks"][0]))         # the clip alone has the bits it has inside the batch
     gflop = flops_per_clip(F, T, N, H, W, mk["d_model"], mk["num_encoder_layers"], mk["num_fusion_layers"], S) / 1e9
-    el, el1 = median(worst), median(single)
+    el2, el1 = median(worst), median(single)
+    inflight = 2 if el2 <= el1 else 1                                                 # the faster of the two is the line's value
+    el = min(el2, el1)
     value = B * steps / el
-    out = {"metric": metric_string(mk, dk, 2), "value": round(value, 2), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 4),
-           "steps": steps, "rounds": rounds, "batch_per_gpu": B, "gflop_per_clip": round(gflop, 4),
+    for k in kernels:
+        k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+    dom = max(kernels, key=lambda k: k["ms"])
+    pipe = kernel_pipe(dom["name"]) or ("fp32 MFMA", 1, FP32_MATRIX_PEAK_TFLOPS)
+    floor_s = path_floor(kernels, 1)
+    out = {"metric": metric_string(mk, dk, inflight), "value": round(value, 2), "unit": "clips/s", "ms_per_step": round(el / steps * 1e3, 4),
+           "steps": steps, "rounds": rounds, "batch_per_gpu": B, "gflop_per_clip": round(gflop, 4), "steps_in_flight": inflight,
+           "two_steps_in_flight": {"value": round(B * steps / el2, 2), "ms_per_step": round(el2 / steps * 1e3, 4)},
+           "roofline": {"bound": "mfma", "kernel": dom["name"], "matrix_pipe": pipe[0],
+                        "achieved": round(dom["tflops"] * pipe[1], 2), "peak": pipe[2], "unit": "TFLOP/s (executed)",
+                        "frac": round(dom["tflops"] * pipe[1] / pipe[2], 4), "algorithmic_tflops": round(dom["tflops"], 2),
+                        "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches_per_step": dom["calls"],
+                        "share_of_kernel_time": round(dom["ms"] / sum(k["ms"] for k in kernels), 4),
+                        "path_floor_ms": round(floor_s * 1e3, 4), "path_floor_frac": round(floor_s / (el / steps), 4),
+                        "path_floor_of": "every kernel at the peak of the pipe it runs on: executed 16-bit matrix flops / 2.5 PFLOP/s, "
+                                         "fp32 matrix flops / 157.3 TFLOP/s, row kernels' bytes / 8 TB/s"},
            "path_frac": round(value * gflop / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
-           "path_frac_of": "fp32 matrix peak (algorithmic fp32 flops; d_model >= 512: the Linear layers run as split-precision bf16 "
-                           "MFMA products, so the fraction is not bounded by 1)",
+           "path_frac_of": "fp32 matrix peak (algorithmic fp32 flops; d_model >= 512: the Linear layers run as split-precision 16-bit "
+                           "MFMA products, so the fraction is not bounded by 1 -- roofline.path_floor_frac is)",
            "one_step_at_a_time": {"value": round(B * steps / el1, 2), "ms_per_step": round(el1 / steps * 1e3, 4)},
+           "one_clip_at_a_time": {"ms_per_forward": round(median(b1) / steps * 1e3, 4), "clips_per_s": round(steps / median(b1), 1),
+                                  "bit_equal_to_the_clip_inside_the_batch": b1_equal},
            "slots_bit_equal": same, "masks_in_unit_interval": bool(float(sets[0]["masks"].min()) >= 0.0 and
                                                                    float(sets[0]["masks"].max()) <= 1.0),
            "note": "short line inside the default run: the workload's own model and per-GPU batch, hipGraph replay, both in-flight "
