@@ -296,6 +296,63 @@ def make_trained_cfg1(outdir):
           f"SNR in {in_snr:.2f} out {out_snr:.2f} dB")
 
 
+def make_trained_d512(outdir):
+    """a reference-TRAINED d_model = 512 model, so that trained LayerNorm / attention / FFN weights (and masks
+    that saturate) reach the split-precision kernels of the d_model >= 512 path (the other d = 512 fixtures are seeded-uniform).
+    BASELINE config 3's shapes (nhead 8, 2 s @ 16 kHz: T = 251, 50 lip frames 32 x 32, 2 speakers) with 1 + 1 layers -- one audio
+    encoder layer, one visual encoder layer, one fusion layer, the decoder: every kind of GEMM site of the path once, 10.8 M
+    parameters --, after the reference's OWN `quick_train` (/root/reference/demo.py:83-113 called as it is: DataLoader(batch 8,
+    shuffle), Adam, clip 1.0, SeparationLoss(0.5), train mode, dropout 0.1) for 60 steps.  Matrices on the bfloat16 grid AFTER
+    training like trained_cfg1 (the reference produced the stored outputs with exactly those weights; vectors -- biases, LayerNorm /
+    BatchNorm parameters and statistics -- full float32).  Stored: weights, SyntheticAVDataset items 0, 1 as inputs, full
+    (separated, masks) in float32 and from the float64 copy, every stage tap as strided slices + float64 checksums, the losses."""
+    sys.path.insert(0, "/root/reference")
+    import demo as refdemo
+    c = dict(F=257, d=512, h=8, Le=1, Lf=1, S=2, seed=43, full=False)
+    dkw = dict(sample_rate=16000, duration=2.0, num_frames=25, frame_h=32, frame_w=32, speaker_freqs=(220.0, 440.0))
+    torch.manual_seed(8765)
+    mk = dict(freq_bins=c["F"], d_model=c["d"], nhead=c["h"], num_encoder_layers=c["Le"], num_fusion_layers=c["Lf"],
+              num_speakers=c["S"], dropout=0.1)
+    m = ref.AVSeparationTransformer(**mk)
+    ds = ref.SyntheticAVDataset(num_samples=200, n_fft=512, hop_length=128, **dkw)
+    losses = refdemo.quick_train(m, ds, torch.device("cpu"), steps=60, lr=3e-4)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    c["T"], c["N"], c["H"], c["W"] = int(ds[0]["mixed_spec"].shape[-1]), int(ds[0]["lip_frames"].shape[0]), 32, 32
+    out = {"config": np.array(json.dumps(c)), "losses": np.array(losses)}
+    for k, v in sd.items():
+        if k.endswith(".pe") or k.endswith("num_batches_tracked"):
+            continue
+        a = v.numpy()
+        if a.ndim >= 2:
+            u = a.view(np.uint32).astype(np.uint64)
+            u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)          # round to nearest even, keep 16 bits
+            out["wh." + k] = u
+            sd[k] = torch.from_numpy((u.astype(np.uint32) << 16).view(np.float32).reshape(a.shape).copy())
+        else:
+            out["w." + k] = a.copy()
+    mq = ref.AVSeparationTransformer(**mk)
+    mq.load_state_dict(sd)
+    mq.eval()
+    items = [ds[i] for i in (0, 1)]
+    mixed = torch.stack([x["mixed_spec"] for x in items])
+    lips = torch.stack([x["lip_frames"] for x in items])
+    with torch.no_grad():
+        sep, masks = mq(mixed, lips)
+        m64 = ref.AVSeparationTransformer(**mk)
+        m64.load_state_dict(sd)
+        sep64, masks64 = m64.double().eval()(mixed.double(), lips.double())
+    taps = hooked_taps(mq, mixed, lips)
+    out["in.mixed"], out["in.lips"] = mixed.numpy(), lips.numpy()
+    pack_outputs(out, c, taps, sep.contiguous().numpy(), masks.contiguous().numpy(),
+                 sep64.contiguous().numpy(), masks64.contiguous().numpy())
+    out["separated"], out["masks"] = sep.contiguous().numpy(), masks.contiguous().numpy()
+    out["masks64"] = masks64.contiguous().numpy().astype(np.float64)
+    path = os.path.join(outdir, "trained_d512.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB loss {losses[0]:.2f}->{losses[-1]:.2f} "
+          f"masks[{masks.min():.5f},{masks.max():.5f}] fp32-vs-fp64 masks {np.abs(masks.double() - masks64).max():.2e}")
+
+
 def make_dataset(outdir):
     out = {}
     small = dict(num_samples=8, sample_rate=8000, duration=0.496, n_fft=128, hop_length=128, num_frames=5,
@@ -450,13 +507,15 @@ def main():
         make_trained(a.out)
     if a.only in (None, "trained_cfg1"):
         make_trained_cfg1(a.out)
+    if a.only in (None, "trained_d512"):
+        make_trained_d512(a.out)
     if a.only in (None, "dataset"):
         make_dataset(a.out)
     if a.only in (None, "losses"):
         make_losses(a.out)
     if a.only in (None, "eval"):
         make_eval(a.out)
-    if a.only is None or a.only.startswith("train"):
+    if a.only is None or (a.only.startswith("train") and not a.only.startswith("trained")):
         make_train(a.out, a.only)
 
 

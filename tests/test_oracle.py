@@ -98,6 +98,27 @@ def test_oracles_on_the_reference_trained_config1_model(golden):
     assert float(g["eval.out_snr"]) - float(g["eval.in_snr"]) > 35.0     # the README's +37 dB recipe (README.md:61-65)
 
 
+def test_oracle_on_the_reference_trained_d512_model(golden):
+    """trained_d512: BASELINE config 3's shapes with 1 + 1 layers after the reference's own quick_train, the
+    fixture that brings TRAINED weights to the d_model >= 512 split-precision kernels: the torch CPU port (the checker of the GPU test)
+    against the reference's full outputs, the loss trajectory and the masks' saturation for the record."""
+    import torch
+    from oracle import torch_cpu
+    g = golden("trained_d512")
+    c = g["config"]
+    assert c["d"] == 512 and c["h"] == 8 and c["Le"] == 1 and c["Lf"] == 1 and c["T"] == 251
+    state = golden_state(g)
+    mixed, lips = golden_inputs(g)
+    scale = max(1.0, float(np.abs(mixed).max()))
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}
+    sp, mk = torch_cpu.forward(st, torch.from_numpy(mixed), torch.from_numpy(lips), c["h"], c["S"])
+    assert maxabs(mk.contiguous().numpy(), g["masks"]) < 2e-6
+    assert maxabs(sp.contiguous().numpy(), g["separated"]) < 2e-6 * scale
+    assert maxabs(g["masks"], g["masks64"]) < 2e-6
+    assert float(g["losses"][0]) > -2.0 and float(g["losses"][-1]) < -30.0
+    assert float(g["masks"].min()) < 1e-3 and float(g["masks"].max()) > 0.999
+
+
 def test_seeded_generator_known_answers():
     # splitmix64 reference values (seed 0): published test vector of the algorithm
     z = seeded.splitmix64(0, 3)
