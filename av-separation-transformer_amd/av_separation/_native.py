@@ -19,7 +19,7 @@ LIB_PATH = DEV_LIB_PATH if _want == "dev" else (_want or os.path.join(_LIBDIR, "
 
 # every symbol include/avsep.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "avsep_abi_version", "avsep_last_error", "avsep_build_id", "avsep_create", "avsep_destroy", "avsep_set_weight",
+    "avsep_abi_version", "avsep_last_error", "avsep_build_id", "avsep_create", "avsep_create_ex", "avsep_destroy", "avsep_set_weight",
     "avsep_finalize_weights", "avsep_workspace_bytes", "avsep_forward", "avsep_forward_graph",
     "avsep_audio_encoder", "avsep_visual_encoder", "avsep_fusion", "avsep_decoder",
     "avsep_set_debug_taps", "avsep_set_split_precision", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_linear_split", "avsep_op_split_planes", "avsep_op_linear_planes", "avsep_op_layernorm_planes", "avsep_op_interp_linear_planes", "avsep_op_attention_split_planes", "avsep_op_h2_row_stats", "avsep_op_split_h2", "avsep_op_linear_h2", "avsep_op_layernorm_h2", "avsep_op_attention_split_h2", "avsep_op_layernorm", "avsep_op_ln_linear",
@@ -74,6 +74,7 @@ def _open(path):
     lib.avsep_last_error.restype = C.c_char_p
     lib.avsep_build_id.restype = C.c_char_p
     lib.avsep_create.argtypes = [C.POINTER(AvsepConfig), C.POINTER(p)]
+    lib.avsep_create_ex.argtypes = [C.POINTER(AvsepConfig), C.c_uint32, C.POINTER(p)]
     lib.avsep_destroy.argtypes = [p]
     lib.avsep_destroy.restype = None
     lib.avsep_set_weight.argtypes = [p, C.c_char_p, fp, C.POINTER(i64), i]

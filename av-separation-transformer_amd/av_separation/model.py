@@ -516,7 +516,15 @@ class AVSeparationTransformer(_Tracked):
     """``model(mixed_spec (B,F,T), lip_frames (B,N,H,W)) -> (separated, masks)``, each (B,S,F,T)."""
 
     def __init__(self, freq_bins: int = 257, d_model: int = 256, nhead: int = 4, num_encoder_layers: int = 2,
-                 num_fusion_layers: int = 2, num_speakers: int = 2, dropout: float = 0.1):
+                 num_fusion_layers: int = 2, num_speakers: int = 2, dropout: float = 0.1, *, split_precision: bool = True):
+        """The reference's constructor (model.py:240-249) plus ONE keyword-only option of the MI355X path:
+
+        split_precision (d_model >= 512 only; no effect below): True (default) runs the Linear layers and the long-sequence
+        attention of the fused eval forward as split-precision products on the 16-bit matrix pipe -- fp32-equivalent results
+        (every golden inside the same tolerance), 1.9x the fp32-MFMA kernels' throughput at BASELINE config 3 (11.9 k against
+        5.9 k clips/s), the same bits at every batch size; False keeps the fp32 MFMA kernels, which are still ~20 % faster for
+        ONE clip at a time (config 3: 0.84 ms against 1.05 ms per forward; profiles/r05_ab_small_batches.txt) -- the setting
+        for a latency deployment that calls the model with 1-2 clips.  ``set_split_precision`` switches later."""
         super().__init__()
         self.freq_bins, self.d_model, self.nhead = freq_bins, d_model, nhead
         self.num_speakers = num_speakers
@@ -529,6 +537,7 @@ class AVSeparationTransformer(_Tracked):
                                          dropout=dropout)
         self._engine = _Engine(self, "", freq_bins, d_model, nhead, num_encoder_layers, num_fusion_layers,
                                num_speakers)
+        self._engine.split_precision = bool(split_precision)
         self._graph = False
 
     # -- options of the MI355X path (not part of the reference API)
@@ -555,9 +564,10 @@ class AVSeparationTransformer(_Tracked):
 
     def set_split_precision(self, on: bool = True):
         """The split-precision GEMM / attention kernels of the fused eval forward on (default) or off (include/avsep.h
-        avsep_set_split_precision).  They only ever apply to d_model >= 512 models and are fp32-equivalent; they win from 8-16
-        clips per forward on and LOSE at 1-4 clips, and the library never looks at the batch size by itself (same bits at every
-        batch size under either setting): a latency deployment of a d_model >= 512 model calls ``set_split_precision(False)``."""
+        avsep_set_split_precision; the constructor's ``split_precision`` keyword sets the initial value).  They only ever apply to
+        d_model >= 512 models and are fp32-equivalent; they win from 2-4 clips per forward on and are ~20 % slower than the fp32
+        MFMA kernels for ONE clip at a time; the library never looks at the batch size by itself (same bits at every batch size
+        under either setting): a latency deployment of a d_model >= 512 model passes ``split_precision=False``."""
         self._engine.set_split_precision(on)
         for eng in self.__dict__.get("_slot_engines", {}).values():
             eng.set_split_precision(on)

@@ -1364,6 +1364,15 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   return on_exception();
 }
 
+int avsep_create_ex(const avsep_config* cfg, uint32_t flags, avsep_ctx** out) try {
+  if (flags & ~(uint32_t)AVSEP_CREATE_FP32_MATRIX) return fail(AVSEP_EINVAL, "unknown creation flag");
+  RCK(avsep_create(cfg, out));
+  if (flags & AVSEP_CREATE_FP32_MATRIX) (*out)->split_gemm = false;
+  return AVSEP_OK;
+} catch (...) {
+  return on_exception();
+}
+
 void avsep_destroy(avsep_ctx* c) {
   if (!c) return;
   // Work of this context may still be in flight: on its own two streams, and on every caller stream a graph was

@@ -610,10 +610,15 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_mid_kernel(const GemmParams pi
 // ---- small problems: 64 x 64 tile, one tile per workgroup, 2 x 2 waves of 32 x 32 (three workgroups per CU) -------------------------
 // The same three products in the same order per element: a row has the same bits here as in the 256-row kernel, so the choice
 // between them may look at the row count (and the forward computes the same bits at every batch size).
+// A three-slot ring, the DMA two chunks ahead (three workgroups per CU still fit): a tile alone on its CU (one clip: 4 x 24 tiles for the QKV projection) used to pay one
+// L2 round trip PER CHUNK (issue -> wait -> barrier with 12 MFMAs in between: 9 us for 251 x 1536 x 512); now three chunks' fetches
+// are in flight behind the one being multiplied (a four-slot ring -- two workgroups per CU -- was slower on the mid-size problems).  Counted s_waitcnt vmcnt (four DMA instructions per wave and chunk) and a RAW
+// s_barrier: __syncthreads() would drain the DMA queue (cdna_hip_programming.md, Pipelining across barriers).
 __global__ __launch_bounds__(256, 3) void gemm_h2_small_kernel(const GemmParams pin) {
   GemmParams p = pin;
-  constexpr int B = 64, PL = B * 64, BUF = 4 * PL;                         // 16 KB per stage: [A hi|lo][W hi|lo]
-  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+  constexpr int B = 64, PL = B * 64, BUF = 4 * PL;                         // 16 KB per slot: [A hi|lo][W hi|lo]
+  constexpr int NST = 3;
+  __shared__ __attribute__((aligned(1024))) char lds[NST * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -652,11 +657,17 @@ __global__ __launch_bounds__(256, 3) void gemm_h2_small_kernel(const GemmParams 
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nk = p.K >> 5;
   issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (nk > 1) issue(1, 1);
+  int slot = 0;                                                            // kc % 3
   for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);                          // block-uniform; the barrier that ended chunk kc - 1 freed that buffer
-    const char* rb = lds + (kc & 1) * BUF;
+    // chunk kc has landed once at most the DMA of the chunk behind it is outstanding (block-uniform choice of the literal)
+    if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this wave's fragment reads of chunk kc - 1 are home
+    __builtin_amdgcn_s_barrier();                                         // every wave's share of chunk kc is in LDS; slot (kc - 1) % 3 is free
+    if (kc + 2 < nk) issue(kc + 2, slot == 0 ? 2 : slot - 1);
+    const char* rb = lds + slot * BUF;
+    slot = slot == 2 ? 0 : slot + 1;
     f16x8 a_hi[2], a_lo[2], w_hi[2], w_lo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -672,8 +683,6 @@ __global__ __launch_bounds__(256, 3) void gemm_h2_small_kernel(const GemmParams 
     H2S_MMA(w_hi, a_lo) /* (lo, hi) */
     H2S_MMA(w_hi, a_hi) /* (hi, hi) */
 #undef H2S_MMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
   // epilogue on the 32 x 32 wave tile: a 4 x 2 accumulator view padded with the two row blocks this wave does not own is not worth
   // a second code path -- the 2 x 2 forms of the same functions

@@ -58,6 +58,13 @@ const char* avsep_build_id(void);
 
 /* One context per device & model.  Allocates (hipMalloc) the packed-weight arena. */
 int avsep_create(const avsep_config* cfg, avsep_ctx** out);
+/* avsep_create with creation-time options (round 5): AVSEP_CREATE_FP32_MATRIX = the d_model >= 512 forward on the fp32
+ * MFMA kernels from the start (what avsep_set_split_precision(ctx, 0) switches to later) -- the choice for a deployment that
+ * calls the model with ONE or two clips at a time, where those kernels are still ~20 % faster (config 3, one clip: 0.84 ms against
+ * 1.05 ms per forward); from 2-4 clips on the default split-precision kernels win (64 clips: 1.9x).  Same results within the
+ * reference tolerance either way, and under either setting the same bits at every batch size. */
+#define AVSEP_CREATE_FP32_MATRIX 1u
+int avsep_create_ex(const avsep_config* cfg, uint32_t flags, avsep_ctx** out);
 void avsep_destroy(avsep_ctx* ctx);
 
 /* The weight ABI is the reference's state_dict: `key` is a reference state_dict key
@@ -102,12 +109,13 @@ int avsep_fusion(avsep_ctx* ctx, const float* audio, const float* visual, float*
 int avsep_decoder(avsep_ctx* ctx, const float* fused, const float* mixed, float* masks_btsf,
                   float* separated_btsf, void* ws, size_t ws_bytes, int B, int T, void* stream);
 
-/* Split-precision kernels (csrc/gemm_split.hip, attention_split.hip) of this context's forwards on (1, the default) or off (0).
- * They apply to d_model >= 512 models only (weights with N, K >= 512; attention at 128 keys or more), are fp32-equivalent
- * (see avsep_op_linear_split) and 1.3-1.45x faster from 8-16 clips per forward on -- but SLOWER than the fp32 MFMA kernels
- * at 1-4 clips (profiles/r04_ab_split_small_batches.txt: 1.40 ms against 0.84 ms for one clip of config 3).  The choice never
- * looks at the batch size by itself (a model computes the same bits at every batch size under either setting), so a latency
- * deployment turns them off here.  Captured graphs of the other setting are dropped. */
+/* Split-precision kernels (csrc/gemm_h2.hip, gemm_planes.hip, gemm_split.hip, attention_split.hip) of this context's forwards on
+ * (1, the default) or off (0).  They apply to d_model >= 512 models only (weights with N, K >= 512; attention at 128 keys or more)
+ * and are fp32-equivalent (see avsep_op_linear_h2 / avsep_op_linear_split): 1.9x the fp32 MFMA kernels' throughput at config 3's
+ * 64 clips per forward, ahead from 2-4 clips on -- and still ~20 % SLOWER for ONE clip at a time (profiles/r05_ab_small_batches.txt:
+ * 1.05 ms against 0.84 ms for one clip of config 3; round 4: 1.40 ms).  The choice never looks at the batch size by itself (a model
+ * computes the same bits at every batch size under either setting): a latency deployment creates its context with
+ * AVSEP_CREATE_FP32_MATRIX (avsep_create_ex) or turns them off here.  Captured graphs of the other setting are dropped. */
 int avsep_set_split_precision(avsep_ctx* ctx, int enable);
 /* Debug/parity taps.  After avsep_set_debug_taps(ctx, 1), avsep_workspace_bytes() reserves a tap area and
  * every eager forward/stage call copies its stage-boundary activations there; avsep_read_tap() copies one

@@ -22,11 +22,18 @@ def test_public_names_match_reference_init():
 
 
 def test_constructor_signatures():
-    def sig(cls):
-        return [(p.name, p.default) for p in inspect.signature(cls.__init__).parameters.values()][1:]
+    def sig(cls):   # the reference's parameters: everything that can be passed positionally
+        return [(p.name, p.default) for p in inspect.signature(cls.__init__).parameters.values()
+                if p.kind is not inspect.Parameter.KEYWORD_ONLY][1:]
     assert sig(AVSeparationTransformer) == [("freq_bins", 257), ("d_model", 256), ("nhead", 4),
                                             ("num_encoder_layers", 2), ("num_fusion_layers", 2),
                                             ("num_speakers", 2), ("dropout", 0.1)]
+    # the one option of the MI355X path is keyword-only and defaults to the fast setting (a constructor argument, not a
+    # method the caller has to discover)
+    extra = [(p.name, p.default) for p in inspect.signature(AVSeparationTransformer.__init__).parameters.values()
+             if p.kind is inspect.Parameter.KEYWORD_ONLY]
+    assert extra == [("split_precision", True)]
+    assert AVSeparationTransformer(split_precision=False)._engine.split_precision is False
     assert sig(AudioEncoder) == [("freq_bins", 257), ("d_model", 256), ("nhead", 4), ("num_layers", 2), ("dropout", 0.1)]
     assert sig(VisualEncoder) == [("d_model", 256), ("nhead", 4), ("num_layers", 2), ("dropout", 0.1)]
     assert sig(CrossModalFusion) == [("d_model", 256), ("nhead", 4), ("num_layers", 2), ("dropout", 0.1)]
