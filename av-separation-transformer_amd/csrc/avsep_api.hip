@@ -133,6 +133,11 @@ struct avsep_ctx {
   struct H2Site { unsigned short* wp; float* cscale; int* ew; float* l2; int eA, N, K; };
   std::unordered_map<const float*, H2Site> h2;
   bool use_h2 = true;
+  // ... and the fused conv stack's conv2 / conv3 (conv_stack_h2_kernel), every model size: weights as H2 planes + row exponents
+  ConvH2 conv_h2{};
+  unsigned short *c2_h = nullptr, *c3_h = nullptr;
+  float *c2_sc = nullptr, *c3_sc = nullptr, *c2_l2 = nullptr, *c3_l2 = nullptr;
+  int *c2_ew = nullptr, *c3_ew = nullptr;
   // streams / events for the audio || visual fork-join and graph replay
   int device = 0;                                  // the device the context (arena, streams, events, graphs) lives on
   hipStream_t side = nullptr;                      // eager forwards: the visual branch's stream
@@ -187,6 +192,9 @@ void layout_arena(avsep_ctx* c, F&& take) {
   c->c1_w = take(9 * 32); c->c1_b = take(32);
   c->c2_w = take(64 * 9 * 32); c->c2_b = take(64);
   c->c3_w = take(128 * 9 * 64); c->c3_b = take(128);
+  c->c2_h = reinterpret_cast<unsigned short*>(take(64 * 9 * 32)); c->c3_h = reinterpret_cast<unsigned short*>(take(128 * 9 * 64));   // 4 B per weight
+  c->c2_sc = take(64); c->c3_sc = take(128); c->c2_l2 = take(64); c->c3_l2 = take(128);
+  c->c2_ew = reinterpret_cast<int*>(take(64)); c->c3_ew = reinterpret_cast<int*>(take(128));
   c->fp_w = take((size_t)d * 128); c->fp_b = take(d);
   c->v_pe = take((size_t)PE_MAX_LEN * d);
   enc(c->v_layers);
@@ -891,8 +899,9 @@ int visual_front(avsep_ctx* c, const Workspace& w, const float* lips, int B, int
   if (fused) {
     const double fl = 2.0 * Mv * ((double)H1 * W1 * 32 * 9 + (double)H2 * W2 * 64 * 288 + (double)H3 * W3 * 128 * 576);
     hipError_t e = hipSuccess;
-    int r = profiled(c, conv_stack_instance_name(Mv, H, W), fl, 4.0 * Mv * ((double)H * W + 128), s, [&] {
-      e = launch_conv_stack(lips, c->c1_w, c->c1_b, c->c2_w, c->c2_b, c->c3_w, c->c3_b, w.pool, Mv, H, W, s);
+    int r = profiled(c, conv_stack_instance_name(Mv, H, W, c->conv_h2.w2h != nullptr), fl, 4.0 * Mv * ((double)H * W + 128), s, [&] {
+      e = launch_conv_stack(lips, c->c1_w, c->c1_b, c->c2_w, c->c2_b, c->c3_w, c->c3_b, w.pool, Mv, H, W, s,
+                            c->conv_h2.w2h ? &c->conv_h2 : nullptr);
       return e == hipErrorNotSupported ? hipSuccess : e;
     });
     RCK(r);
@@ -1209,7 +1218,39 @@ int h2_exponent(double bound) {
   const int e = 14 - ex;
   return e > 100 ? 100 : e < -100 ? -100 : e;
 }
+// conv2 / conv3 of the fused conv stack on two fp16 terms: weight planes + the constants of the per-pass activation bounds
+int conv_h2_prepare(avsep_ctx* c, hipStream_t s) {
+  c->conv_h2 = ConvH2{};
+  if (!c->ok_visual || dev_env("AVSEP_CONV_FP32")) return AVSEP_OK;
+  HCK(launch_h2_row_stats(c->c2_w, 64, 9 * 32, c->c2_ew, c->c2_l2, s));
+  HCK(launch_h2_row_stats(c->c3_w, 128, 9 * 64, c->c3_ew, c->c3_l2, s));
+  HCK(launch_pack_conv_h2(c->c2_w, c->c2_ew, c->c2_h, c->c2_sc, 64, 32, s));
+  HCK(launch_pack_conv_h2(c->c3_w, c->c3_ew, c->c3_h, c->c3_sc, 128, 64, s));
+  HCK(hipStreamSynchronize(s));
+  std::vector<float> w1(9 * 32), b1(32), l2(64), b2(64);
+  HCK(hipMemcpy(w1.data(), c->c1_w, w1.size() * 4, hipMemcpyDeviceToHost));
+  HCK(hipMemcpy(b1.data(), c->c1_b, b1.size() * 4, hipMemcpyDeviceToHost));
+  HCK(hipMemcpy(l2.data(), c->c2_l2, l2.size() * 4, hipMemcpyDeviceToHost));
+  HCK(hipMemcpy(b2.data(), c->c2_b, b2.size() * 4, hipMemcpyDeviceToHost));
+  double s1 = 0, b1m = 0, l2m = 0, b2m = 0;
+  for (int ch = 0; ch < 32; ++ch) {
+    double t = 0;
+    for (int k = 0; k < 9; ++k) t += std::fabs((double)w1[k * 32 + ch]);   // packed [9][32]
+    s1 = std::max(s1, t);
+    b1m = std::max(b1m, std::fabs((double)b1[ch]));
+  }
+  for (int n = 0; n < 64; ++n) { l2m = std::max(l2m, (double)l2[n]); b2m = std::max(b2m, std::fabs((double)b2[n])); }
+  if (!std::isfinite(s1) || !std::isfinite(b1m) || !std::isfinite(l2m) || !std::isfinite(b2m)) return AVSEP_OK;   // fp32 kernel
+  ConvH2 h{};
+  h.w2h = c->c2_h; h.w3h = c->c3_h; h.sc2 = c->c2_sc; h.sc3 = c->c3_sc;
+  h.s1max = (float)(s1 * (1.0 + 1e-6)); h.b1max = (float)(b1m * (1.0 + 1e-6));
+  h.l2max2 = (float)(l2m * (1.0 + 1e-6)); h.b2max = (float)(b2m * (1.0 + 1e-6));
+  c->conv_h2 = h;
+  return AVSEP_OK;
+}
+
 int h2_prepare(avsep_ctx* c, hipStream_t s) {
+  RCK(conv_h2_prepare(c, s));
   if (c->h2.empty()) return AVSEP_OK;
   const int d = c->d;
   for (auto& kv : c->h2) HCK(launch_h2_row_stats(kv.first, kv.second.N, kv.second.K, kv.second.ew, kv.second.l2, s));

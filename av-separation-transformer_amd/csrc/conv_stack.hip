@@ -16,6 +16,7 @@
 // BatchNorm is folded into the conv weights/bias by the packer (avsep_api.hip).  Pixel stride in LDS is
 // C+4 floats so neighbouring positions fall on different banks for the b128 gathers.
 #include "kernels.h"
+#include "split_terms.h"
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
@@ -40,6 +41,14 @@ struct ConvStackParams {
   // instead of integer divisions of ~25 VALU instructions each (fp32 MFMA and VALU do not overlap on a SIMD)
   unsigned mg_p1, mg_w1, mg_p2, mg_w2, mg_p3, mg_w3;
   unsigned long long* dbg;  // developer diagnostics (AVSEP_CONV_DBG): per-workgroup phase clock sums, null otherwise
+  // Two fp16 terms, three products (conv_stack_h2_kernel; round 5): conv2 / conv3 weights as H2 planes [Co][9][2][Ci] (row n scaled by
+  // 2^ew[n]), sc2 / sc3 [Co] = 2^-ew[n], and the constants the per-pass activation exponents are derived from
+  const unsigned short* w2h;
+  const unsigned short* w3h;
+  const float* sc2;
+  const float* sc3;
+  float s1max, b1max;       // max_c sum_k |w1[k][c]|, max_c |b1[c]|: |conv1 out| <= max|frame| s1max + b1max
+  float l2max2, b2max;      // max_n ||w2[n]||_2, max_n |b2[n]|: |conv2 out| <= sqrt(288) max|a1| l2max2 + b2max
 };
 
 // m / d for 0 <= m < 2^16, 1 <= d < 2^16 with mg = floor(2^32 / d) + 1 (exact: m * d < 2^32); mg == 0 <=> d == 1
@@ -359,11 +368,385 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
   }
 }
 
+// RB2 / RB3: 16-row MFMA blocks of the conv2 / conv3 output rows, COMPILE-TIME so the accumulator arrays stay in
+// registers with no per-block predication (a runtime "if (i < rb)" around each MFMA made hipcc shuffle the whole
+// accumulator file through v_accvgpr moves: 300k VALU instructions per wave, 10x slower).  Rows past the valid
+// range read row 0's window and are simply not stored.
+// NW = wavefronts per workgroup (4 or 8).  With 8, two waves share each SIMD so one wave's LDS gathers / weight
+// loads / barriers hide behind the other's MFMAs: conv2 rows are split in two halves (waves 0-3 / 4-7, each wave
+// still owning 16 output channels), conv3 gives every wave 16 of the 128 channels.
+// ---- conv2 / conv3 on the 16-bit matrix pipe (round 5) ---------------------------------------------------------------------------
+// The same kernel with the two implicit GEMMs as TWO-TERM fp16 products (gemm_h2.hip's scheme: three v_mfma_f32_16x16x32_f16 per fp32
+// product block instead of eight v_mfma_f32_16x16x4_f32 -- 48 matrix cycles per tap and row block instead of 256): the only
+// matrix-bound kernel of the 32-clip step.  The LDS images hold hi | lo fp16 planes per pixel where they held
+// fp32 -- the SAME bytes per pixel (32 channels: 64 + 64 B, 64 channels: 128 + 128 B, + 16 B pad), so frame strides, halo and the
+// fragment addresses are the fp32 kernel's; a fragment is 8 channels of one term.  Scaling: the weights carry a power of two per
+// output channel (packer); the activations ONE power of two per pass and image, from bounds that need one reduction only -- the
+// largest |pixel| of the pass's raw frames (taken while they are staged): |conv1 out| <= max|frame| s1max + b1max,
+// |conv2 out| <= sqrt(288) bound1 l2max2 + b2max (Cauchy-Schwarz over the 3 x 3 x 32 window).
+template <int G, int RB2, int RB3MAX, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_stack_h2_kernel(const ConvStackParams p) {
+  constexpr int NT = 64 * NW;
+  constexpr int RSPLIT = NW / 4;                       // conv2 row halves
+  constexpr int RB2MAX = (RB2 + RSPLIT - 1) / RSPLIT;  // conv2 row blocks per wave
+  constexpr int CB3 = 8 / NW;                          // conv3 16-channel blocks per wave
+  constexpr int RAWN = 5;                              // raw-frame prefetch registers per thread (G*H*W <= RAWN*NT)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* a1 = lds;                         // G x (2*H2+1) x (2*W2+1) x C1P
+  float* a2 = lds + G * p.a1_frame;        // G x (2*H3+1) x (2*W3+1) x C2P
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 15;
+  const int q = lane >> 4;
+  const int P1 = p.H1 * p.W1, P2 = p.H2 * p.W2, P3 = p.H3 * p.W3;
+  // row strides (pixels) of the haloed images: a stride-2 3x3 window over Ho outputs touches halo rows 0..2*Ho,
+  // so 2*Ho+1 rows/cols are enough (one halo line less than H+2 for even sizes: leaves LDS for the other stream)
+  const int s1w = 2 * p.W2 + 1, s2w = 2 * p.W3 + 1;
+
+  // zero both images once: the halo is never written again
+  for (int i = tid * 4; i < G * (p.a1_frame + p.a2_frame); i += 4 * NT)
+    *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ngroups = (p.Mv + G - 1) / G;
+
+  // per-lane LDS base offsets of the 3x3 window origin of each output row (row = 16*rb + c)
+  const int cb2 = wave & 3;                 // conv2 column block of this wave
+  const int rb2_0 = (wave >> 2) * RB2MAX;   // first conv2 row block of this wave
+  // (and, for conv2, where the lane's output position lands in the a2 image: pass-invariant, so computed once here and
+  // not in every pass's epilogue; -1 = no such position)
+  int base2[RB2MAX], dst2[RB2MAX], base3[RB3MAX];
+  bool g2[RB2MAX];                                     // this lane's conv2 position belongs to the pass's second frame
+#pragma unroll
+  for (int i = 0; i < RB2MAX; ++i) {
+    const int mu = 16 * (rb2_0 + i) + c;
+    const int m = mu < G * P2 ? mu : 0;
+    const int g = qdiv(m, p.mg_p2), pos = m - g * P2;
+    const int y = qdiv(pos, p.mg_w2), x = pos - y * p.W2;
+    base2[i] = g * p.a1_frame + ((2 * y) * s1w + 2 * x) * C1P + 4 * q;
+    dst2[i] = mu < G * P2 ? g * p.a2_frame + ((y + 1) * s2w + (x + 1)) * C2P + 16 * cb2 + 4 * q : -1;
+    g2[i] = g > 0;
+  }
+#pragma unroll
+  for (int i = 0; i < RB3MAX; ++i) {
+    int m = 16 * i + c;
+    m = m < G * P3 ? m : 0;
+    const int g = qdiv(m, p.mg_p3), pos = m - g * P3;
+    const int y = qdiv(pos, p.mg_w3), x = pos - y * p.W3;
+    base3[i] = g * p.a2_frame + ((2 * y) * s2w + 2 * x) * C2P + 4 * q;
+  }
+  // weights of this wave's output channels: conv2 col-block cb2, conv3 col-blocks CB3*wave .. CB3*wave+CB3-1
+  const int ch3 = 16 * CB3 * wave + c;      // first conv3 channel of this lane
+  const f32x4 bias2v = *reinterpret_cast<const f32x4*>(p.b2 + 16 * cb2 + 4 * q);
+  const float bias3_0 = p.b3[ch3], bias3_1 = p.b3[ch3 + (CB3 > 1 ? 16 : 0)];
+
+  // conv1 as MFMA operands: weights of channel 16cb + c for the taps k = 4s + q (zero beyond the 9th), bias of the four
+  // channels 16cb + 4q .. +3 this lane's accumulator holds
+  float w1a[2][3];
+  f32x4 b1c[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int k = 4 * s3 + q;
+      w1a[cb][s3] = k < 9 ? p.w1[k * C1 + 16 * cb + c] : 0.0f;
+    }
+    b1c[cb] = *reinterpret_cast<const f32x4*>(p.b1 + 16 * cb + 4 * q);
+  }
+
+  // Raw frames are staged through LDS: the next pass's G*H*W pixels are fetched into registers (RAWN coalesced
+  // loads per thread) while this pass runs on the matrix cores, so conv1 never waits on HBM.
+  float* raw = lds + G * (p.a1_frame + p.a2_frame);
+  const int HW = p.H * p.W, nraw = G * HW;
+  float rawv[RAWN];
+  auto fetch_raw = [&](int grp) {
+    const float* src = p.frames + (size_t)grp * G * HW;
+    const int valid = min(G, p.Mv - grp * G) * HW;
+#pragma unroll
+    for (int k = 0; k < RAWN; ++k) {
+      const int i = tid + k * NT;
+      rawv[k] = i < valid ? src[i] : 0.0f;
+    }
+  };
+  if ((int)blockIdx.x < ngroups) fetch_raw(blockIdx.x);
+
+  // conv1's gather is pass-invariant too: which raw pixels feed this lane's three MFMA steps of each of its 16-pixel blocks,
+  // and where the block's output lands in a1.  When one sweep of U blocks per wave covers the pass (G * P1 <= 16 U NW pixels:
+  // the 32 x 32 lips of configs 1-4) the offsets are computed ONCE; larger frames recompute them per pass as before.
+  constexpr int U1 = 4;                                  // blocks in flight per wave
+  const int npb1 = (G * P1 + 15) >> 4;                   // 16-pixel blocks of a pass
+  const bool c1_once = npb1 <= U1 * NW;                  // workgroup-uniform
+  int c1_src[U1][3], c1_dst[U1], c1_g[U1];              // raw offset per step (-1 = outside the frame / beyond tap 8)
+  auto conv1_coords = [&](int pb, int (&src)[3], int& dst, int& g) {
+    const int px = 16 * pb + c;
+    const bool in = px < G * P1;                         // also false for blocks beyond npb1
+    const int pxc = in ? px : 0;
+    g = qdiv(pxc, p.mg_p1);
+    const int pos = pxc - g * P1;
+    const int y = qdiv(pos, p.mg_w1), x = pos - y * p.W1;
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int k = 4 * s3 + q;                          // tap index of this lane in MFMA step s3
+      const int ky = k / 3, kx = k - 3 * ky;
+      const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
+      const bool ok = k < 9 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      src[s3] = ok ? g * (p.H * p.W) + iy * p.W + ix : -1;
+    }
+    dst = in ? g * p.a1_frame + ((y + 1) * s1w + (x + 1)) * C1P + 4 * q : -1;
+  };
+  if (c1_once) {
+#pragma unroll
+    for (int u = 0; u < U1; ++u) conv1_coords(wave + u * NW, c1_src[u], c1_dst[u], c1_g[u]);
+  }
+
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int f0 = grp * G;
+    const unsigned long long t0 = cs_tick(p);
+    __syncthreads();   // previous pass done with a1/a2/raw (and the zero fill on the first pass)
+    float fmx[G];                                        // per FRAME: a frame's bits must not depend on the frame it shares a pass with
+#pragma unroll
+    for (int g = 0; g < G; ++g) fmx[g] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RAWN; ++k) {
+      const int i = tid + k * NT;
+      if (i < nraw) raw[i] = rawv[k];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (i >= g * HW && i < (g + 1) * HW) fmx[g] = fmaxf(fmx[g], fabsf(rawv[k]));
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) fmx[g] = fmaxf(fmx[g], __shfl_xor(fmx[g], off));
+      if (lane == 0) raw[nraw + G * wave + g] = fmx[g];  // G * NW floats behind the staged pixels
+    }
+    __syncthreads();
+    // per-frame exponents of the two images (wave-uniform arithmetic on each frame's largest |pixel|)
+    float e1s[G], e2s[G], d1s[G], d2s[G];                // 2^e1, 2^e2 and their inverses
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float m = 0.0f;
+#pragma unroll
+      for (int w_ = 0; w_ < NW; ++w_) m = fmaxf(m, raw[nraw + G * w_ + g]);
+      const float bound1 = m * p.s1max + p.b1max;
+      const float bound2 = 16.9706f * bound1 * p.l2max2 + p.b2max;            // sqrt(288) rounded up
+      auto expo = [](float bnd) {                                              // e with bnd 2^e <= 2^14 (0 for a zero bound)
+        const int ex = (int)((__float_as_uint(bnd * 1.0001f) >> 23) & 255u) - 126;   // bnd < 2^ex
+        const int e = bnd > 0.0f ? 14 - ex : 0;
+        return e > 100 ? 100 : e < -100 ? -100 : e;
+      };
+      const int e1 = expo(bound1), e2 = expo(bound2);
+      e1s[g] = ldexpf(1.0f, e1); d1s[g] = ldexpf(1.0f, -e1);
+      e2s[g] = ldexpf(1.0f, e2); d2s[g] = ldexpf(1.0f, -e2);
+    }
+    if (grp + (int)gridDim.x < ngroups) fetch_raw(grp + gridDim.x);
+    const unsigned long long t1 = cs_tick(p);
+
+    // ---------------- phase 1: conv1 + BN + ReLU on the matrix cores -> a1 interior ---------------------
+    // Cin = 1: K = 9 taps, zero-extended to 12 = three 16x16x4 MFMA steps.  Operands swapped like the GEMM epilogue's:
+    // A = weights (lane: channel 16cb + (lane&15), k = 4s + (lane>>4)), B = the 3x3 window gathered from the raw
+    // frame (lane: output pixel lane&15 of a 16-pixel block, same k), C = bias, so lane (pixel, q) ends up with the
+    // four consecutive channels 16cb + 4q .. +3 of its pixel: one ds_write_b128 per block into the channels-last image.
+    // The MFMA is a k-ordered fma chain starting from C, i.e. bias, tap 0, tap 1, ... -- bit-identical to the VALU
+    // loop it replaces (which took 7.8 of a pass's 28 us with the matrix pipes idle: in-kernel phase clocks).
+    {
+      constexpr int U = U1;                               // blocks in flight per wave: independent gather -> MFMA -> store chains
+      for (int pb0 = wave; pb0 < npb1; pb0 += U * NW) {   // wave-uniform trip count
+        float xv[U][3], sc1[U];
+        int dst[U];
+        bool pin[U], live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          int src[3], g;
+          if (c1_once) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) src[s3] = c1_src[u][s3];
+            dst[u] = c1_dst[u]; g = c1_g[u];
+          } else {
+            conv1_coords(pb0 + u * NW, src, dst[u], g);
+          }
+          pin[u] = dst[u] >= 0;
+#pragma unroll
+          for (int s3 = 0; s3 < 3; ++s3) xv[u][s3] = src[s3] >= 0 ? raw[src[s3] >= 0 ? src[s3] : 0] : 0.0f;
+          live[u] = pin[u] && (f0 + g < p.Mv);
+          sc1[u] = G > 1 && g ? e1s[G - 1] : e1s[0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x4 acc = b1c[cb];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[cb][s3], xv[u][s3], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = live[u] ? fmaxf(acc[e], 0.0f) * sc1[u] : 0.0f;
+            if (pin[u]) {                                // channels 16cb + 4q .. +3: 8 bytes of the hi plane, 8 of the lo plane
+              unsigned h[2], l[2];
+              split_pair_h2(f32x2{acc[0], acc[1]}, h[0], l[0]);
+              split_pair_h2(f32x2{acc[2], acc[3]}, h[1], l[1]);
+              char* px = reinterpret_cast<char*>(a1) + (size_t)(dst[u] - 4 * q) * 4 + (16 * cb + 4 * q) * 2;
+              *reinterpret_cast<u32x2*>(px) = u32x2{h[0], h[1]};
+              *reinterpret_cast<u32x2*>(px + 64) = u32x2{l[0], l[1]};
+            }
+          }
+      }
+    }
+    __syncthreads();
+    const unsigned long long t2 = cs_tick(p);
+
+    // ---------------- phase 2: conv2 implicit GEMM on two fp16 terms, wave owns output channels [16*cb2, +16) -----
+    {
+      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+      f32x4 acc[RB2MAX];
+#pragma unroll
+      for (int i = 0; i < RB2MAX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // weights one whole tap ahead: the hi and lo fragments of this lane's channel (16 bytes each)
+      const char* w2b = reinterpret_cast<const char*>(p.w2h) + (size_t)(16 * cb2 + c) * 9 * 128 + 16 * q;
+      f16x8 wch = *reinterpret_cast<const f16x8*>(w2b), wcl = *reinterpret_cast<const f16x8*>(w2b + 64), wnh = wch, wnl = wcl;
+      const char* a1b = reinterpret_cast<const char*>(a1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int toff = (ky * s1w + kx) * C1P * 4;
+        if (tap + 1 < 9) {
+          wnh = *reinterpret_cast<const f16x8*>(w2b + (tap + 1) * 128);
+          wnl = *reinterpret_cast<const f16x8*>(w2b + (tap + 1) * 128 + 64);
+        }
+        f16x8 fh[RB2MAX], fl[RB2MAX];
+#pragma unroll
+        for (int i = 0; i < RB2MAX; ++i) {                // the fp32 kernel's two gathers: bytes [16q, +16) of the hi and of the lo plane
+          fh[i] = *reinterpret_cast<const f16x8*>(a1b + (size_t)(base2[i] - 4 * q) * 4 + toff + 16 * q);
+          fl[i] = *reinterpret_cast<const f16x8*>(a1b + (size_t)(base2[i] - 4 * q) * 4 + toff + 64 + 16 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < RB2MAX; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcl, fh[i], acc[i], 0, 0, 0);   // D[channel][position]
+#pragma unroll
+        for (int i = 0; i < RB2MAX; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wch, fl[i], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB2MAX; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wch, fh[i], acc[i], 0, 0, 0);
+        wch = wnh; wcl = wnl;
+      }
+      // true scale, bias + ReLU, then the a2 image's scale and the two fp16 terms: lane (position c, q) holds channels 16 cb2 + 4q .. +3
+      const f32x4 s2v = *reinterpret_cast<const f32x4*>(p.sc2 + 16 * cb2 + 4 * q);
+#pragma unroll
+      for (int i = 0; i < RB2MAX; ++i) {
+        if (dst2[i] >= 0) {
+          f32x4 v;
+          const float din = G > 1 && g2[i] ? d1s[G - 1] : d1s[0], eout = G > 1 && g2[i] ? e2s[G - 1] : e2s[0];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[i][r] * din * s2v[r] + bias2v[r], 0.0f) * eout;
+          unsigned h[2], l[2];
+          split_pair_h2(f32x2{v[0], v[1]}, h[0], l[0]);
+          split_pair_h2(f32x2{v[2], v[3]}, h[1], l[1]);
+          char* px = reinterpret_cast<char*>(a2) + (size_t)(dst2[i] - 16 * cb2 - 4 * q) * 4 + (16 * cb2 + 4 * q) * 2;
+          *reinterpret_cast<u32x2*>(px) = u32x2{h[0], h[1]};
+          *reinterpret_cast<u32x2*>(px + 128) = u32x2{l[0], l[1]};
+        }
+      }
+    }
+    __syncthreads();
+    const unsigned long long t3 = cs_tick(p);
+
+    // ---------------- phase 3: conv3 implicit GEMM on two fp16 terms + average pool ------------------------------
+    {
+      typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+      f32x4 acc0[RB3MAX], acc1[RB3MAX];
+#pragma unroll
+      for (int i = 0; i < RB3MAX; ++i) acc0[i] = acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // per tap and channel: hi[64] | lo[64] fp16 = 256 bytes; two k-steps of 32 channels
+      const char* w3b0 = reinterpret_cast<const char*>(p.w3h) + (size_t)ch3 * 9 * 256 + 16 * q;
+      const char* w3b1 = w3b0 + (size_t)(CB3 > 1 ? 16 : 0) * 9 * 256;
+      f16x8 wc0[4], wc1[4], wn0[4], wn1[4];                // [k-step 0 hi, k-step 1 hi, k-step 0 lo, k-step 1 lo]
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        wc0[s] = *reinterpret_cast<const f16x8*>(w3b0 + (s & 1) * 64 + (s >> 1) * 128);
+        wc1[s] = *reinterpret_cast<const f16x8*>(w3b1 + (s & 1) * 64 + (s >> 1) * 128);
+        wn0[s] = wc0[s]; wn1[s] = wc1[s];
+      }
+      const char* a2b = reinterpret_cast<const char*>(a2);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int toff = (ky * s2w + kx) * C2P * 4;
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            wn0[s] = *reinterpret_cast<const f16x8*>(w3b0 + (tap + 1) * 256 + (s & 1) * 64 + (s >> 1) * 128);
+            if constexpr (CB3 > 1) wn1[s] = *reinterpret_cast<const f16x8*>(w3b1 + (tap + 1) * 256 + (s & 1) * 64 + (s >> 1) * 128);
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          f16x8 fh[RB3MAX], fl[RB3MAX];
+#pragma unroll
+          for (int i = 0; i < RB3MAX; ++i) {
+            fh[i] = *reinterpret_cast<const f16x8*>(a2b + (size_t)(base3[i] - 4 * q) * 4 + toff + 64 * ks + 16 * q);
+            fl[i] = *reinterpret_cast<const f16x8*>(a2b + (size_t)(base3[i] - 4 * q) * 4 + toff + 128 + 64 * ks + 16 * q);
+          }
+#pragma unroll
+          for (int i = 0; i < RB3MAX; ++i) {                // D[position][channel]: (hi, lo), (lo, hi), (hi, hi)
+            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], wc0[2 + ks], acc0[i], 0, 0, 0);
+            if constexpr (CB3 > 1) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], wc1[2 + ks], acc1[i], 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < RB3MAX; ++i) {
+            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], wc0[ks], acc0[i], 0, 0, 0);
+            if constexpr (CB3 > 1) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], wc1[ks], acc1[i], 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < RB3MAX; ++i) {
+            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], wc0[ks], acc0[i], 0, 0, 0);
+            if constexpr (CB3 > 1) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], wc1[ks], acc1[i], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          wc0[s] = wn0[s];
+          if constexpr (CB3 > 1) wc1[s] = wn1[s];
+        }
+      }
+      const float sc3_0 = p.sc3[ch3], sc3_1 = p.sc3[ch3 + (CB3 > 1 ? 16 : 0)];   // the channel's 2^-ew; the frame's 2^-e2 below
+      // bias + ReLU, then the mean over each frame's P3 positions (rows g*P3 .. (g+1)*P3-1)
+      const float invp = 1.0f / (float)P3;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < RB3MAX; ++i) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * i + 4 * q + r;
+            const bool in = (m >= g * P3) && (m < (g + 1) * P3);
+            s0 += in ? fmaxf(acc0[i][r] * d2s[g] * sc3_0 + bias3_0, 0.0f) : 0.0f;
+            s1 += in ? fmaxf(acc1[i][r] * d2s[g] * sc3_1 + bias3_1, 0.0f) : 0.0f;
+          }
+        }
+        s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        if (q == 0 && f0 + g < p.Mv) {
+          p.pooled[(size_t)(f0 + g) * C3 + ch3] = s0 * invp;
+          if constexpr (CB3 > 1) p.pooled[(size_t)(f0 + g) * C3 + ch3 + 16] = s1 * invp;
+        }
+      }
+    }
+    if (p.dbg) {
+      const unsigned long long t4 = cs_tick(p);
+      ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += 1;
+    }
+  }
+  if (p.dbg && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) p.dbg[(size_t)blockIdx.x * 8 + i] = ph[i];
+  }
+}
+
 inline int conv_out(int x) { return (x - 1) / 2 + 1; }
 
-template <int G, int RB2, int RB3, int NW>
+template <int G, int RB2, int RB3, int NW, bool H2 = false>
 hipError_t launch_cs_nw(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) {
-  auto kern = conv_stack_kernel<G, RB2, RB3, NW>;
+  if (!H2 && p.w2h) return launch_cs_nw<G, RB2, RB3, NW, true>(p, lds_bytes + 64, s);   // + the per-wave, per-frame |pixel| maxima behind the raw frames (G * NW floats)
+  auto kern = H2 ? conv_stack_h2_kernel<G, RB2, RB3, NW> : conv_stack_kernel<G, RB2, RB3, NW>;
   // the instance's dynamic-LDS ceiling is raised (to the hardware's 160 KiB) once PER DEVICE, not on every launch: the
   // library keeps contexts on several devices in one process (avsep_ctx::device), and a failure is not latched
   static bool raised[64] = {};
@@ -416,8 +799,35 @@ hipError_t launch_cs(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) 
 
 }  // namespace
 
+// conv weights [Co][9][Ci] fp32 (BN folded, tap-major) -> H2 planes [Co][9][2][Ci] fp16 with row n scaled by 2^ew[n]; sc[n] = 2^-ew[n]
+namespace {
+__global__ __launch_bounds__(256) void pack_conv_h2_kernel(const float* __restrict__ w, const int* __restrict__ ew,
+                                                           unsigned short* __restrict__ wh, float* __restrict__ sc, int Co, int Ci) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;                      // one thread per (channel, tap, pair of input channels)
+  const int half = Ci >> 1;
+  if (idx >= Co * 9 * half) return;
+  const int k2 = idx % half, tap = (idx / half) % 9, n = idx / (9 * half);
+  const float scl = ldexpf(1.0f, ew[n]);
+  const float* src = w + ((size_t)n * 9 + tap) * Ci + 2 * k2;
+  unsigned h, l;
+  split_pair_h2(f32x2{src[0] * scl, src[1] * scl}, h, l);
+  unsigned* dst = reinterpret_cast<unsigned*>(wh) + ((size_t)n * 9 + tap) * Ci + k2;   // 2 Ci fp16 = Ci dwords per (channel, tap)
+  dst[0] = h;
+  dst[half] = l;
+  if (tap == 0 && k2 == 0) sc[n] = ldexpf(1.0f, -ew[n]);
+}
+}  // namespace
+
+hipError_t launch_pack_conv_h2(const float* w, const int* ew, unsigned short* wh, float* sc, int Co, int Ci, hipStream_t s) {
+  if (!w || !ew || !wh || !sc || Co <= 0 || Ci <= 0 || (Ci & 1)) return hipErrorInvalidValue;
+  const int n = Co * 9 * (Ci >> 1);
+  hipLaunchKernelGGL(pack_conv_h2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, ew, wh, sc, Co, Ci);
+  return hipGetLastError();
+}
+
 // The instance launch_conv_stack() picks, spelled as rocprofv3 prints it ("conv_stack_kernel" when the frame does not fit).
-const char* conv_stack_instance_name(int Mv, int H, int W) {
+const char* conv_stack_instance_name(int Mv, int H, int W, bool h2) {
+  const bool g_conv_h2_name = h2 && dev_env("AVSEP_CONV_FP32") == nullptr;
   static thread_local char buf[48];
   const int H1 = conv_out(H), W1 = conv_out(W), H2 = conv_out(H1), W2 = conv_out(W1), H3 = conv_out(H2), W3 = conv_out(W2);
   const int P2 = H2 * W2, P3 = H3 * W3;
@@ -439,7 +849,7 @@ const char* conv_stack_instance_name(int Mv, int H, int W) {
     else if (r2 <= 12 && r3 <= 4) { g = 1; a = 12; b = 4; }
   }
   if (!g) return "conv_stack_kernel";
-  snprintf(buf, sizeof buf, "conv_stack_kernel<%d, %d, %d, %d>", g, a, b, four ? 4 : 8);
+  snprintf(buf, sizeof buf, "conv_stack_%skernel<%d, %d, %d, %d>", g_conv_h2_name ? "h2_" : "", g, a, b, four ? 4 : 8);
   return buf;
 }
 
@@ -447,10 +857,15 @@ const char* conv_stack_instance_name(int Mv, int H, int W) {
 // (the caller then takes the unfused conv1 + implicit-GEMM path).
 hipError_t launch_conv_stack(const float* frames, const float* w1, const float* b1, const float* w2,
                              const float* b2, const float* w3, const float* b3, float* pooled, int Mv, int H,
-                             int W, hipStream_t s) {
+                             int W, hipStream_t s, const ConvH2* h2) {
   if (Mv <= 0 || H <= 0 || W <= 0) return hipErrorInvalidValue;
   ConvStackParams p{};
   p.frames = frames; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.pooled = pooled;
+  static const bool no_h2 = dev_env("AVSEP_CONV_FP32") != nullptr;   // developer A/B
+  if (h2 && h2->w2h && !no_h2) {
+    p.w2h = h2->w2h; p.w3h = h2->w3h; p.sc2 = h2->sc2; p.sc3 = h2->sc3;
+    p.s1max = h2->s1max; p.b1max = h2->b1max; p.l2max2 = h2->l2max2; p.b2max = h2->b2max;
+  }
   p.Mv = Mv; p.H = H; p.W = W;
   p.H1 = conv_out(H); p.W1 = conv_out(W);
   p.H2 = conv_out(p.H1); p.W2 = conv_out(p.W1);

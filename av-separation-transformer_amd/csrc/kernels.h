@@ -295,9 +295,17 @@ hipError_t launch_conv1_c1(const float* frames, const float* w9x32, const float*
                            int H, int W, int Ho, int Wo, hipStream_t s);
 // whole visual conv front-end (3 x conv+BN+ReLU + average pool) in one LDS-resident kernel; returns
 // hipErrorNotSupported when the frame size does not fit (callers fall back to the three launches above/below)
+// h2 (may be null: the fp32 MFMA kernel): conv2 / conv3 on two fp16 terms (conv_stack_h2_kernel) -- their weights as H2 planes
+// [Co][9][2][Ci] with row exponents, sc = 2^-ew, and the constants of the per-pass activation bounds (avsep_finalize_weights)
+struct ConvH2 {
+  const unsigned short *w2h, *w3h;
+  const float *sc2, *sc3;
+  float s1max, b1max, l2max2, b2max;
+};
 hipError_t launch_conv_stack(const float* frames, const float* w1, const float* b1, const float* w2,
                              const float* b2, const float* w3, const float* b3, float* pooled, int Mv, int H,
-                             int W, hipStream_t s);
+                             int W, hipStream_t s, const ConvH2* h2 = nullptr);
+hipError_t launch_pack_conv_h2(const float* w, const int* ew, unsigned short* wh, float* sc, int Co, int Ci, hipStream_t s);
 // mean over P positions: x (M,P,C) -> y (M,C)
 hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStream_t s);
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);
@@ -315,7 +323,7 @@ hipError_t launch_stft_basis(float* basis, int n_fft, hipStream_t s);
 // instance names as rocprofv3 prints them (namespace prefix and argument list stripped): the live profiler's table joins
 // profiles/*_kernel_stats.csv and profiles/pmc_hbm_traffic.json by string equality
 const char* layernorm_instance_name(int d, bool stats_only);
-const char* conv_stack_instance_name(int Mv, int H, int W);
+const char* conv_stack_instance_name(int Mv, int H, int W, bool h2 = false);   // h2: conv_stack_h2_kernel
 
 hipError_t launch_delay(unsigned us, hipStream_t s);
 hipError_t launch_stamp(unsigned long long* buf, int idx, hipStream_t s);   // profiling aid, see rowops.hip

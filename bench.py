@@ -50,6 +50,8 @@ def kernel_pipe(name):
         return ("fp16 MFMA, 3 products per fp32 product", 3, BF16_MATRIX_PEAK_TFLOPS)
     if name.startswith(("gemm_split", "gemm_planes", "attention_split", "wgrad_split")):
         return ("bf16 MFMA, 6 products per fp32 product", 6, BF16_MATRIX_PEAK_TFLOPS)
+    if name.startswith("conv_stack_h2"):
+        return ("fp16 MFMA, 3 products per fp32 product (conv2, conv3)", 3, BF16_MATRIX_PEAK_TFLOPS)
     if name.startswith(("gemm_", "attention", "attn_", "conv_stack", "wgrad")):
         return ("fp32 MFMA", 1, FP32_MATRIX_PEAK_TFLOPS)
     return None
