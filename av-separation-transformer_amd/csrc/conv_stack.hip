@@ -602,16 +602,17 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_h2_kernel(const ConvStackP
 #pragma unroll
       for (int i = 0; i < RB2MAX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       // weights one whole tap ahead: the hi and lo fragments of this lane's channel (16 bytes each)
-      const char* w2b = reinterpret_cast<const char*>(p.w2h) + (size_t)(16 * cb2 + c) * 9 * 128 + 16 * q;
-      f16x8 wch = *reinterpret_cast<const f16x8*>(w2b), wcl = *reinterpret_cast<const f16x8*>(w2b + 64), wnh = wch, wnl = wcl;
+      // fragment-order weights: (channel block cb2, tap, term) = one contiguous KiB, this lane's 16 bytes at lane * 16
+      const char* w2b = reinterpret_cast<const char*>(p.w2h) + (size_t)cb2 * 9 * 2048 + lane * 16;
+      f16x8 wch = *reinterpret_cast<const f16x8*>(w2b), wcl = *reinterpret_cast<const f16x8*>(w2b + 1024), wnh = wch, wnl = wcl;
       const char* a1b = reinterpret_cast<const char*>(a1);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int toff = (ky * s1w + kx) * C1P * 4;
         if (tap + 1 < 9) {
-          wnh = *reinterpret_cast<const f16x8*>(w2b + (tap + 1) * 128);
-          wnl = *reinterpret_cast<const f16x8*>(w2b + (tap + 1) * 128 + 64);
+          wnh = *reinterpret_cast<const f16x8*>(w2b + (tap + 1) * 2048);
+          wnl = *reinterpret_cast<const f16x8*>(w2b + (tap + 1) * 2048 + 1024);
         }
         f16x8 fh[RB2MAX], fl[RB2MAX];
 #pragma unroll
@@ -654,14 +655,14 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_h2_kernel(const ConvStackP
       f32x4 acc0[RB3MAX], acc1[RB3MAX];
 #pragma unroll
       for (int i = 0; i < RB3MAX; ++i) acc0[i] = acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // per tap and channel: hi[64] | lo[64] fp16 = 256 bytes; two k-steps of 32 channels
-      const char* w3b0 = reinterpret_cast<const char*>(p.w3h) + (size_t)ch3 * 9 * 256 + 16 * q;
-      const char* w3b1 = w3b0 + (size_t)(CB3 > 1 ? 16 : 0) * 9 * 256;
+      // fragment-order weights: (channel block, tap) = 4 KiB = [term][k-step][64 lanes][16 bytes]
+      const char* w3b0 = reinterpret_cast<const char*>(p.w3h) + (size_t)(CB3 * wave) * 9 * 4096 + lane * 16;
+      const char* w3b1 = w3b0 + (size_t)(CB3 > 1 ? 1 : 0) * 9 * 4096;
       f16x8 wc0[4], wc1[4], wn0[4], wn1[4];                // [k-step 0 hi, k-step 1 hi, k-step 0 lo, k-step 1 lo]
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        wc0[s] = *reinterpret_cast<const f16x8*>(w3b0 + (s & 1) * 64 + (s >> 1) * 128);
-        wc1[s] = *reinterpret_cast<const f16x8*>(w3b1 + (s & 1) * 64 + (s >> 1) * 128);
+        wc0[s] = *reinterpret_cast<const f16x8*>(w3b0 + (s & 1) * 1024 + (s >> 1) * 2048);
+        wc1[s] = *reinterpret_cast<const f16x8*>(w3b1 + (s & 1) * 1024 + (s >> 1) * 2048);
         wn0[s] = wc0[s]; wn1[s] = wc1[s];
       }
       const char* a2b = reinterpret_cast<const char*>(a2);
@@ -672,8 +673,8 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_h2_kernel(const ConvStackP
         if (tap + 1 < 9) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            wn0[s] = *reinterpret_cast<const f16x8*>(w3b0 + (tap + 1) * 256 + (s & 1) * 64 + (s >> 1) * 128);
-            if constexpr (CB3 > 1) wn1[s] = *reinterpret_cast<const f16x8*>(w3b1 + (tap + 1) * 256 + (s & 1) * 64 + (s >> 1) * 128);
+            wn0[s] = *reinterpret_cast<const f16x8*>(w3b0 + (tap + 1) * 4096 + (s & 1) * 1024 + (s >> 1) * 2048);
+            if constexpr (CB3 > 1) wn1[s] = *reinterpret_cast<const f16x8*>(w3b1 + (tap + 1) * 4096 + (s & 1) * 1024 + (s >> 1) * 2048);
           }
         }
 #pragma unroll
@@ -799,7 +800,11 @@ hipError_t launch_cs(const ConvStackParams& p, size_t lds_bytes, hipStream_t s) 
 
 }  // namespace
 
-// conv weights [Co][9][Ci] fp32 (BN folded, tap-major) -> H2 planes [Co][9][2][Ci] fp16 with row n scaled by 2^ew[n]; sc[n] = 2^-ew[n]
+// conv weights [Co][9][Ci] fp32 (BN folded, tap-major) -> H2 terms in FRAGMENT order, row n scaled by 2^ew[n]; sc[n] = 2^-ew[n].
+// A wave's weight fragment (16 channels x 32 input channels of one tap and term: lane c + 16 q holds channel c's inputs 8q .. 8q+7) is
+// one contiguous KiB -- [Co/16][9][2 terms][Ci/32 k-steps][64 lanes][8] fp16 -- so every load instruction of the kernel reads whole
+// cache lines (with [Co][9][2][Ci] a lane group fetched 64 bytes per channel row: half of every line, 33 GB/s per CU where the L2
+// serves 66-73).
 namespace {
 __global__ __launch_bounds__(256) void pack_conv_h2_kernel(const float* __restrict__ w, const int* __restrict__ ew,
                                                            unsigned short* __restrict__ wh, float* __restrict__ sc, int Co, int Ci) {
@@ -811,9 +816,13 @@ __global__ __launch_bounds__(256) void pack_conv_h2_kernel(const float* __restri
   const float* src = w + ((size_t)n * 9 + tap) * Ci + 2 * k2;
   unsigned h, l;
   split_pair_h2(f32x2{src[0] * scl, src[1] * scl}, h, l);
-  unsigned* dst = reinterpret_cast<unsigned*>(wh) + ((size_t)n * 9 + tap) * Ci + k2;   // 2 Ci fp16 = Ci dwords per (channel, tap)
-  dst[0] = h;
-  dst[half] = l;
+  const int k = 2 * k2, ks = k >> 5, q = (k & 31) >> 3, e2 = (k & 7) >> 1;        // k-step, lane group, dword inside the lane's 16 bytes
+  const int nks = Ci >> 5;
+  // dword index: ((((n / 16) * 9 + tap) * 2 + term) * nks + ks) * 64 lanes * 4 dwords + (16 q + n % 16) * 4 + e2
+  const size_t f0 = ((((size_t)(n >> 4) * 9 + tap) * 2 + 0) * nks + ks) * 256 + ((16 * q + (n & 15)) << 2) + e2;
+  unsigned* dst = reinterpret_cast<unsigned*>(wh);
+  dst[f0] = h;
+  dst[f0 + (size_t)nks * 256] = l;
   if (tap == 0 && k2 == 0) sc[n] = ldexpf(1.0f, -ew[n]);
 }
 }  // namespace
