@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "avsep_abi_version", "avsep_last_error", "avsep_build_id", "avsep_create", "avsep_create_ex", "avsep_destroy", "avsep_set_weight",
     "avsep_finalize_weights", "avsep_workspace_bytes", "avsep_forward", "avsep_forward_graph",
     "avsep_audio_encoder", "avsep_visual_encoder", "avsep_fusion", "avsep_decoder",
-    "avsep_set_debug_taps", "avsep_set_split_precision", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_linear_split", "avsep_op_split_planes", "avsep_op_linear_planes", "avsep_op_layernorm_planes", "avsep_op_interp_linear_planes", "avsep_op_attention_split_planes", "avsep_op_h2_row_stats", "avsep_op_split_h2", "avsep_op_linear_h2", "avsep_op_layernorm_h2", "avsep_op_attention_split_h2", "avsep_op_layernorm", "avsep_op_ln_linear",
+    "avsep_set_debug_taps", "avsep_set_split_precision", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_linear_split", "avsep_op_split_planes", "avsep_op_linear_planes", "avsep_op_layernorm_planes", "avsep_op_interp_linear_planes", "avsep_op_attention_split_planes", "avsep_op_h2_row_stats", "avsep_op_split_h2", "avsep_op_linear_h2", "avsep_op_interp_linear_h2", "avsep_op_layernorm_h2", "avsep_op_attention_split_h2", "avsep_op_layernorm", "avsep_op_ln_linear",
     "avsep_op_attention", "avsep_op_attention_split", "avsep_op_interp_linear", "avsep_stft_basis_floats", "avsep_stft_basis", "avsep_op_stft_mag",
     # training ops
     "avsep_op_linear_ex", "avsep_op_attention_train", "avsep_op_attention_bwd", "avsep_op_transpose",
@@ -107,7 +107,8 @@ def _open(path):
     lib.avsep_op_attention_split_planes.argtypes = [fp, i, fp, i, fp, i, p, i64, i, i, i, i, i, p]
     lib.avsep_op_h2_row_stats.argtypes = [fp, i, i, p, fp, p]
     lib.avsep_op_split_h2.argtypes = [fp, i, p, i64, i, i, p, i, p]
-    lib.avsep_op_linear_h2.argtypes = [p, i64, p, i64, fp, fp, fp, fp, p, i64, i, i, i, i, i, p]
+    lib.avsep_op_linear_h2.argtypes = [p, i64, p, i64, fp, fp, fp, fp, fp, p, i64, i, i, i, i, i, p]
+    lib.avsep_op_interp_linear_h2.argtypes = [fp, p, fp, i64, i, i, i, i, p]
     lib.avsep_op_layernorm_h2.argtypes = [fp, fp, fp, p, i64, i, i, C.c_float, i, p]
     lib.avsep_op_attention_split_h2.argtypes = [fp, i, fp, i, fp, i, p, i64, i, i, i, i, i, i, p]
     lib.avsep_set_split_precision.argtypes = [p, i]

@@ -75,6 +75,7 @@ struct Workspace {   // all float*, carved from the caller's buffer
   // attention outputs, FFN hidden activations, the resized visual stream -- written by their producers INSTEAD of the fp32 tensor.
   // rows_a / rows_v: row counts of the audio-length / frame-length buffers (the planes' slab height; a half-batch view keeps them)
   unsigned short *ln_p, *att_p, *ffn_p, *v_ln_p, *v_att_p, *v_ffn_p, *v_up_p;
+  float* v_up_rs;            // per-row descale of the resized visual stream's two-term planes (2^-e of each row)
   long long rows_a, rows_v;
   size_t floats;
 };
@@ -244,6 +245,7 @@ void layout_arena(avsep_ctx* c, F&& take) {
     for (auto* v : {&c->a_layers, &c->v_layers})
       for (auto& L : *v) { h2(L.wqkv, 3 * d, d); h2(L.wo, d, d); h2(L.w1, 4 * d, d); h2(L.w2, d, 4 * d); }
     for (auto& L : c->f_layers) { h2(L.wq, d, d); h2(L.w1, 4 * d, d); h2(L.w2, d, 4 * d); }   // wo: cross-attention output, no static bound
+    h2(c->wkv_all, c->Lf * 2 * d, d);   // its input (the resized visual stream) carries one power of two per ROW (eA stays 0)
     h2(c->d_w1, 2 * d, d);
     h2(c->d_w2, S * c->F, 2 * d);
   }
@@ -393,6 +395,7 @@ size_t carve(const avsep_ctx* c, Workspace* w, float* base, int B, int T, int N,
     t.ln_p = planes(Ma * d); t.att_p = planes(Ma * d); t.ffn_p = planes(Ma * 4 * d);
     t.v_ln_p = planes(Mv * d); t.v_att_p = planes(Mv * d); t.v_ffn_p = planes(Mv * 4 * d);
     t.v_up_p = planes(Ma * d);
+    t.v_up_rs = take(Ma);
     if (!base) t.ln_p = t.att_p = t.ffn_p = t.v_ln_p = t.v_att_p = t.v_ffn_p = t.v_up_p = nullptr;
   }
   t.rows_a = (long long)Ma;
@@ -936,7 +939,10 @@ int visual_front(avsep_ctx* c, const Workspace& w, const float* lips, int B, int
 // F.interpolate(mode="linear") of the frame sequence to the audio length (model.py:114-116): w.v_x -> w.v_up
 int visual_upsample(avsep_ctx* c, const Workspace& w, int B, int N, int T, hipStream_t s) {
   const int d = c->d;
-  if (planes_rows(c, w, B * T))                    // only the fusion K/V projection reads it: its planes instead of the fp32 tensor
+  if (c->Lf > 0 && h2_site(c, w, c->wkv_all))       // only the fusion K/V projection reads it: two fp16 terms, one power of two per row
+    return profiled(c, "interp_linear_h2_kernel<1>", 3.0 * B * T * d, 4.0 * B * d * (N + T), s,
+                    [&] { return launch_interp_linear_h2(w.v_x, w.v_up_p, w.v_up_rs, w.rows_a, B, N, T, d, s); });
+  if (planes_rows(c, w, B * T))                    // (bf16 path) its three bf16 planes instead of the fp32 tensor
     return profiled(c, "interp_linear_kernel<true>", 3.0 * B * T * d, 4.0 * B * d * (N + 1.5 * T), s,
                     [&] { return launch_interp_linear_planes(w.v_x, w.v_up_p, w.rows_a, B, N, T, d, s); });
   RCK(profiled(c, "interp_linear_kernel<false>", 3.0 * B * T * d, 4.0 * B * d * (N + T), s,
@@ -958,7 +964,9 @@ int fusion_kv(avsep_ctx* c, const Workspace& w, const float* visual, int B, int 
   if (c->Lf == 0) return AVSEP_OK;
   const int d = c->d, M = B * T, nkv = c->Lf * 2 * d;
   GemmParams p = linear_params(visual, d, c->wkv_all, d, c->bkv_all, w.kv_all, nkv, M, nkv, ACT_NONE);
-  if (visual == w.v_up && planes_rows(c, w, M)) {   // the full forward: visual_upsample() wrote planes, not w.v_up
+  if (visual == w.v_up && h2_site(c, w, c->wkv_all)) {   // the full forward: visual_upsample() wrote row-scaled two-term planes, not w.v_up
+    p.A = nullptr; p.Ap = w.v_up_p; p.a_rows = w.rows_a; p.h2 = 1; p.rscale = w.v_up_rs;
+  } else if (visual == w.v_up && planes_rows(c, w, M)) {   // (bf16 path) three bf16 planes
     p.A = nullptr; p.Ap = w.v_up_p; p.a_rows = w.rows_a;
   }
   RCK(run_gemm(c, p, s));
@@ -1946,14 +1954,20 @@ int avsep_op_split_h2(const float* x, int ld, uint16_t* planes, int64_t rows, in
   return AVSEP_OK;
 }
 
-int avsep_op_linear_h2(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* cscale, const float* bias,
-                       const float* residual, float* y, uint16_t* yp, int64_t y_rows, int yp_exp, int M, int N, int K, int act,
-                       void* stream) {
+int avsep_op_interp_linear_h2(const float* x, uint16_t* yp, float* rscale, int64_t rows, int B, int N, int T, int d, void* stream) {
+  if (!x || !yp || !rscale || B <= 0 || N <= 0 || T <= 0 || d <= 0 || d % 32 || d > 2048 || rows < (int64_t)B * T) return fail(AVSEP_EINVAL, "bad argument");
+  HCK(launch_interp_linear_h2(x, yp, rscale, rows, B, N, T, d, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_linear_h2(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* cscale, const float* rscale,
+                       const float* bias, const float* residual, float* y, uint16_t* yp, int64_t y_rows, int yp_exp, int M, int N, int K,
+                       int act, void* stream) {
   if (!xp || !wp || !cscale || (!y && !yp) || M <= 0 || N <= 0 || K <= 0) return fail(AVSEP_EINVAL, "bad argument");
   if (K % 32 || N % 2) return fail(AVSEP_EINVAL, "K must be a multiple of 32 and N even");
   if (act < 0 || act > 3 || yp_exp < -120 || yp_exp > 120) return fail(AVSEP_EINVAL, "unknown activation / exponent out of range");
   GemmParams p = linear_params(nullptr, K, nullptr, K, bias, y, N, M, N, act);
-  p.Ap = xp; p.a_rows = x_rows; p.Wp = wp; p.w_rows = w_rows; p.Cp = yp; p.c_rows = y_rows; p.cscale = cscale; p.h2 = 1;
+  p.Ap = xp; p.a_rows = x_rows; p.Wp = wp; p.w_rows = w_rows; p.Cp = yp; p.c_rows = y_rows; p.cscale = cscale; p.rscale = rscale; p.h2 = 1;
   p.cp_scale = std::ldexp(1.0f, yp_exp);
   if (residual) { p.R = residual; p.ldr = N; }
   if (!gemm_h2_supported(p)) return fail(AVSEP_EINVAL, "shape / epilogue not supported by the two-term GEMM");

@@ -161,6 +161,17 @@ __device__ __forceinline__ void h2_planes_epilogue(const GemmParams& p, const f3
 
 // fp32 output: the accumulators are brought back to true scale (acc * cscale[n], exact) and handed to gemm_tile.h's epilogues
 // (bias / activation / residual, or the mask head's two outputs) unchanged
+template <int WBM, int WBN>
+__device__ __forceinline__ void h2_descale_rows(const GemmParams& p, f32x4 (&acc)[WBM][WBN], int mbase, int fr) {
+  if (!p.rscale) return;                                                 // block-uniform
+#pragma unroll
+  for (int i = 0; i < WBM; ++i) {
+    const float rs = p.rscale[min(mbase + 16 * i + fr, p.M - 1)];          // lane (fr, fq) holds row 16 i + fr of its blocks
+#pragma unroll
+    for (int j = 0; j < WBN; ++j) acc[i][j] *= rs;
+  }
+}
+
 template <int WBN>
 __device__ __forceinline__ void h2_descale(const GemmParams& p, f32x4 (&acc)[4][WBN], int nbase, int fq) {
 #pragma unroll
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(const GemmParams pin) {
       if (p.Cp) h2_planes_epilogue<WBN>(p, acc, bm * BM + wm * 64, bn * BN + wn * (BN / 2), fr, fq);
       if (p.C) {
         h2_descale<WBN>(p, acc, bn * BN + wn * (BN / 2), fq);
+        h2_descale_rows<4, WBN>(p, acc, bm * BM + wm * 64, fr);
         gemm_epilogue<4, WBN>(p, acc, bm * BM, bn * BN, wm * 64, wn * (BN / 2), fr, fq);
       }
       tile += tile_step;
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel2(const GemmParams pin) 
       if (p.Cp) h2_planes_epilogue<WBN>(p, acc, bm * BM + wm * 64, bn * BN + wn * 64, fr, fq);
       if (p.C) {
         h2_descale<WBN>(p, acc, bn * BN + wn * 64, fq);
+        h2_descale_rows<4, WBN>(p, acc, bm * BM + wm * 64, fr);
         gemm_epilogue<4, WBN>(p, acc, bm * BM, bn * BN, wm * 64, wn * 64, fr, fq);
       }
     }
@@ -603,6 +616,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_mid_kernel(const GemmParams pi
   if (p.Cp) h2_planes_epilogue<4>(p, acc, m0 + wm * 64, n0 + wn * 64, fr, fq);
   if (p.C) {
     h2_descale<4>(p, acc, n0 + wn * 64, fq);
+    h2_descale_rows<4, 4>(p, acc, m0 + wm * 64, fr);
     gemm_epilogue<4, 4>(p, acc, m0, n0, wm * 64, wn * 64, fr, fq);
   }
 }
@@ -741,6 +755,7 @@ __global__ __launch_bounds__(256, 3) void gemm_h2_small_kernel(const GemmParams 
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i][j] *= s;
     }
+    h2_descale_rows<2, 2>(p, acc, m0 + wm * 32, fr);
     gemm_epilogue<2, 2>(p, acc, m0, n0, wm * 32, wn * 32, fr, fq);
   }
 }
@@ -765,7 +780,7 @@ bool gemm_h2_supported(const GemmParams& p) {
   const bool fast = !p.C2 && !(p.N & 3) && !(p.ldc & 3) && (!p.R || !(p.ldr & 3));
   const bool mask = p.C2 && p.X && !(p.N & 1) && !(p.ldc & 1) && !p.R;
   const bool c_ok = !p.C || fast || mask;
-  const bool cp_ok = !p.Cp || (!(p.N & 31) && p.c_rows >= p.M && !p.R && !p.C2 && p.act != ACT_SIGMOID && p.cp_scale > 0.0f);
+  const bool cp_ok = !p.Cp || (!(p.N & 31) && p.c_rows >= p.M && !p.R && !p.C2 && p.act != ACT_SIGMOID && p.cp_scale > 0.0f && !p.rscale);
   return p.Ap && p.Wp && p.cscale && (p.C || p.Cp) && c_ok && cp_ok && p.amode == AMODE_PLAIN && p.a_rows >= p.M && p.w_rows >= p.N &&
          !p.lnx_c1 && !p.ln_gamma && !p.ln_stats && p.ksplit <= 1 && p.mag_F == 0 && p.drop_p <= 0.0f && !(p.K & 31) &&
          p.alt.M <= 0 && !p.epi_general;

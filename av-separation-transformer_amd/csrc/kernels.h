@@ -141,6 +141,7 @@ struct GemmParams {
   // Two-term fp16 planes (gemm_h2.hip): operands stored scaled by powers of two -- cscale[n] = 2^-(eA + ew[n]) brings an accumulator
   // back to true scale (exact), cp_scale = 2^eC is the scale of the plane OUTPUT (the consumer's static exponent).
   const float* cscale;
+  const float* rscale;   // per-ROW descale of an operand that carries one power of two per row (the resized visual stream), or null
   float cp_scale;
   int h2;              // 1: Ap / Wp / Cp hold two fp16 terms (gemm_h2.hip), 0: three bf16 terms (gemm_planes.hip)
 #ifdef AVSEP_DEV
@@ -311,6 +312,9 @@ hipError_t launch_avgpool(const float* x, float* y, int M, int P, int C, hipStre
 hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, int d, hipStream_t s);
 // the same values as the bf16 planes of the consuming GEMM's A operand (GemmParams::Ap; rows = the buffer's row count); d % 32 == 0
 hipError_t launch_interp_linear_planes(const float* x, unsigned short* yp, long long rows, int B, int N, int T, int d, hipStream_t s);
+// ... as two fp16 terms with one power of two per ROW (from the row's largest magnitude); rscale[row] = 2^-e for the GEMM's epilogue
+hipError_t launch_interp_linear_h2(const float* x, unsigned short* yp, float* rscale, long long rows, int B, int N, int T, int d,
+                                   hipStream_t s);
 hipError_t launch_layernorm_planes(const float* x, const float* g, const float* b, unsigned short* yp, long long rows, int M, int d,
                                    float eps, hipStream_t s);
 // ... as the two fp16 terms of gemm_h2.hip, scaled by 2^e

@@ -7,6 +7,8 @@
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -198,6 +200,70 @@ __global__ __launch_bounds__(256) void interp_linear_kernel(const float* __restr
   }
 }
 
+// The same resize as the two fp16 terms of the fusion K/V projection's operand (gemm_h2.hip), one WAVE per output row: the visual
+// stream has no static bound, so each row carries its own power of two -- from the row's largest magnitude, taken in registers
+// (a row of a clip alone has the exponent it has inside any batch) -- and rscale[row] = 2^-e brings the GEMM's accumulators back.
+template <int VEC>
+__global__ __launch_bounds__(256) void interp_linear_h2_kernel(const float* __restrict__ x, unsigned short* __restrict__ yp,
+                                                               float* __restrict__ rscale, long long rows, int B, int N, int T, int d,
+                                                               float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long bt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bt >= (long long)B * T) return;
+  const int t = (int)(bt % T), b = (int)(bt / T);
+  float src = fmaf(scale, (float)t + 0.5f, -0.5f);     // interp_linear_kernel's index arithmetic
+  src = src < 0.0f ? 0.0f : src;
+  int i0 = (int)src;
+  i0 = i0 < N - 1 ? i0 : N - 1;
+  const int i1 = i0 + 1 < N ? i0 + 1 : N - 1;
+  const float w1 = src - (float)i0;
+  const float w0 = 1.0f - w1;
+  const float* r0 = x + ((size_t)b * N + i0) * d;
+  const float* r1 = x + ((size_t)b * N + i1) * d;
+  f32x4 o[VEC][2];
+  float mx = 0.0f;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int col = (lane + 64 * v) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (col < d) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r0 + col + 4 * h), c = *reinterpret_cast<const f32x4*>(r1 + col + 4 * h);
+        o[v][h] = w0 * a + w1 * c;
+      } else {
+        o[v][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(o[v][h][e]));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  // e with mx 2^e in [2^13, 2^14) (0 for a zero row; clamped): the weight rows' rule (gemm_h2.hip h2_row_stats_kernel)
+  int e = 0;
+  if (mx > 0.0f && mx < 3.0e38f) {
+    const int ex = (int)((__float_as_uint(mx) >> 23) & 255u) - 126;        // mx < 2^ex
+    e = 14 - ex;
+    e = e > 100 ? 100 : e < -100 ? -100 : e;
+  }
+  const float sc = ldexpf(1.0f, e);
+  if (lane == 0) rscale[bt] = ldexpf(1.0f, -e);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int col = (lane + 64 * v) * 8;
+    if (col < d) {
+      unsigned h[4], l[4];
+      split_pair_h2(f32x2{o[v][0][0], o[v][0][1]} * sc, h[0], l[0]);
+      split_pair_h2(f32x2{o[v][0][2], o[v][0][3]} * sc, h[1], l[1]);
+      split_pair_h2(f32x2{o[v][1][0], o[v][1][1]} * sc, h[2], l[2]);
+      split_pair_h2(f32x2{o[v][1][2], o[v][1][3]} * sc, h[3], l[3]);
+      char* dst = reinterpret_cast<char*>(yp) + (((size_t)(col >> 5) * 2) * rows + bt) * 64 + (col & 31) * 2;
+      *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<u32x4*>(dst + (size_t)rows * 64) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+  }
+}
+
 // Profiling aid: keeps the stream busy for `us` microseconds so the host can queue a whole forward behind
 // it; the per-kernel HIP events of avsep_profile_* then see back-to-back kernels instead of launch gaps.
 __global__ void delay_kernel(unsigned us) {
@@ -357,6 +423,18 @@ hipError_t launch_interp_linear(const float* x, float* y, int B, int N, int T, i
   const size_t n = (size_t)B * T * (d / 4);
   hipLaunchKernelGGL(interp_linear_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, B, N, T, d,
                      (float)N / (float)T, 0LL);
+  return hipGetLastError();
+}
+
+hipError_t launch_interp_linear_h2(const float* x, unsigned short* yp, float* rscale, long long rows, int B, int N, int T, int d,
+                                   hipStream_t s) {
+  if ((d & 31) || d > 2048 || rows < (long long)B * T || !rscale) return hipErrorInvalidValue;
+  const long long nrow = (long long)B * T;
+  const dim3 grid((unsigned)((nrow + 3) / 4)), block(256);
+  const float sc = (float)N / (float)T;
+  if (d <= 512) hipLaunchKernelGGL(interp_linear_h2_kernel<1>, grid, block, 0, s, x, yp, rscale, rows, B, N, T, d, sc);
+  else if (d <= 1024) hipLaunchKernelGGL(interp_linear_h2_kernel<2>, grid, block, 0, s, x, yp, rscale, rows, B, N, T, d, sc);
+  else hipLaunchKernelGGL(interp_linear_h2_kernel<4>, grid, block, 0, s, x, yp, rscale, rows, B, N, T, d, sc);
   return hipGetLastError();
 }
 

@@ -183,7 +183,7 @@ int avsep_op_attention_split_planes(const float* q, int ldq, const float* k, int
  *                           l2[n] >= ||w[n][:]||_2 (for the bounds avsep_finalize_weights derives the activations' exponents from)
  *   avsep_op_split_h2       x (M, K; row stride ld) -> H2 planes of x 2^e, e = row_exp[m], or the one exponent `e` with row_exp null.
  *                           The caller guarantees |x| 2^e <= 65504 (a value beyond becomes inf).
- *   avsep_op_linear_h2      y = act((sum_k x'_k w'_k) * cscale[n] + bias[n]) + residual, cscale[n] = 2^-(ex + ew[n]); as fp32 (y) and / or
+ *   avsep_op_linear_h2      y = act((sum_k x'_k w'_k) * cscale[n] (* rscale[m]) + bias[n]) + residual, cscale[n] = 2^-(ex + ew[n]); as fp32 (y) and / or
  *                           as the H2 planes of y 2^yp_exp (yp / y_rows; N % 32 == 0, no residual, not sigmoid).  N even (N % 4 != 0: the mask
  *                           head's epilogue needs avsep_op_mask_head's operands and is reached through the forward only).
  *                           A row computed alone has the bits it has inside any batch (64 x 64 and 256 x 128 kernels, same products, same order).
@@ -193,9 +193,14 @@ int avsep_op_attention_split_planes(const float* q, int ldq, const float* k, int
  * Non-finite inputs give non-finite outputs.  nn.Linear, nn.LayerNorm, nn.MultiheadAttention: /root/reference/src/av_separation/model.py:48-52,155-164,194-199. */
 int avsep_op_h2_row_stats(const float* w, int N, int K, int32_t* ew, float* l2, void* stream);
 int avsep_op_split_h2(const float* x, int ld, uint16_t* planes, int64_t rows, int M, int K, const int32_t* row_exp, int e, void* stream);
-int avsep_op_linear_h2(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* cscale, const float* bias,
-                       const float* residual, float* y, uint16_t* yp, int64_t y_rows, int yp_exp, int M, int N, int K, int act,
-                       void* stream);
+int avsep_op_linear_h2(const uint16_t* xp, int64_t x_rows, const uint16_t* wp, int64_t w_rows, const float* cscale, const float* rscale,
+                       const float* bias, const float* residual, float* y, uint16_t* yp, int64_t y_rows, int yp_exp, int M, int N, int K,
+                       int act, void* stream);
+/* rscale (may be null): an operand WITHOUT a static bound carries one power of two per ROW, taken from the row itself by its producer --
+ * avsep_op_interp_linear_h2 = avsep_op_interp_linear as two-term planes of each row scaled into [2^13, 2^14), rscale[row] = the inverse
+ * (what the forward runs between the visual encoder and the fusion K/V projection) --, and the GEMM multiplies row m of its
+ * accumulators by rscale[m] (exact) beside cscale[n] = 2^-ew[n].  fp32 output only. */
+int avsep_op_interp_linear_h2(const float* x, uint16_t* yp, float* rscale, int64_t rows, int B, int N, int T, int d, void* stream);
 int avsep_op_layernorm_h2(const float* x, const float* gamma, const float* beta, uint16_t* yp, int64_t rows, int M, int d, float eps, int e,
                           void* stream);
 int avsep_op_attention_split_h2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* op, int64_t rows,

@@ -1000,7 +1000,7 @@ def test_op_linear_h2(lib, dev, M, N, K, act, res):
     y0 = torch.full((M, N), float("nan"), device=dev)
     y1 = torch.full((M, N), float("nan"), device=dev)
     assert lib.avsep_op_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), rp, y0.data_ptr(), M, N, K, act, _stream()) == 0
-    assert lib.avsep_op_linear_h2(xp.data_ptr(), M + 5, wp.data_ptr(), N, cs.data_ptr(), b.data_ptr(), rp, y1.data_ptr(), None, 0, 0,
+    assert lib.avsep_op_linear_h2(xp.data_ptr(), M + 5, wp.data_ptr(), N, cs.data_ptr(), None, b.data_ptr(), rp, y1.data_ptr(), None, 0, 0,
                                   M, N, K, act, _stream()) == 0, lib.avsep_last_error()
     assert torch.isfinite(y1).all()
     scale = float(ref.abs().max())
@@ -1012,16 +1012,16 @@ def test_op_linear_h2(lib, dev, M, N, K, act, res):
     y2 = torch.full((1, N), float("nan"), device=dev)
     x2p = _h2_planes(lib, x[m:m + 1].contiguous(), ex)
     r2 = r[m:m + 1].contiguous() if res else None
-    assert lib.avsep_op_linear_h2(x2p.data_ptr(), 1, wp.data_ptr(), N, cs.data_ptr(), b.data_ptr(), r2.data_ptr() if res else None,
+    assert lib.avsep_op_linear_h2(x2p.data_ptr(), 1, wp.data_ptr(), N, cs.data_ptr(), None, b.data_ptr(), r2.data_ptr() if res else None,
                                   y2.data_ptr(), None, 0, 0, 1, N, K, act, _stream()) == 0
     assert torch.equal(y2[0], y1[m])
     if not res and N % 32 == 0 and act != 3:
         ey = _h2_exp(4.0 * float(y1.abs().max()))
         yp = torch.zeros(N // 32, 2, M + 2, 32, dtype=torch.int16, device=dev)
-        assert lib.avsep_op_linear_h2(xp.data_ptr(), M + 5, wp.data_ptr(), N, cs.data_ptr(), b.data_ptr(), None, None, yp.data_ptr(), M + 2, ey,
+        assert lib.avsep_op_linear_h2(xp.data_ptr(), M + 5, wp.data_ptr(), N, cs.data_ptr(), None, b.data_ptr(), None, None, yp.data_ptr(), M + 2, ey,
                                       M, N, K, act, _stream()) == 0, lib.avsep_last_error()
         assert torch.equal(yp, _h2_planes(lib, y1, ey, rows=M + 2))
-    assert lib.avsep_op_linear_h2(xp.data_ptr(), M - 1, wp.data_ptr(), N, cs.data_ptr(), None, None, y1.data_ptr(), None, 0, 0, M, N, K, 0,
+    assert lib.avsep_op_linear_h2(xp.data_ptr(), M - 1, wp.data_ptr(), N, cs.data_ptr(), None, None, None, y1.data_ptr(), None, 0, 0, M, N, K, 0,
                                   _stream()) == -1                                                                  # rows < M
 
 
@@ -1038,7 +1038,7 @@ def test_h2_wide_dynamic_range_and_extreme_scales(lib, dev):
     wp, ew, _ = _h2_weight(lib, w)
     cs = torch.ldexp(torch.ones(N, device=dev), -(ew + ex))
     y = torch.full((M, N), float("nan"), device=dev)
-    assert lib.avsep_op_linear_h2(xp.data_ptr(), M, wp.data_ptr(), N, cs.data_ptr(), None, None, y.data_ptr(), None, 0, 0, M, N, K, 0,
+    assert lib.avsep_op_linear_h2(xp.data_ptr(), M, wp.data_ptr(), N, cs.data_ptr(), None, None, None, y.data_ptr(), None, 0, 0, M, N, K, 0,
                                   _stream()) == 0, lib.avsep_last_error()
     ref = x.double() @ w.double().t()
     mag = x.double().abs() @ w.double().abs().t()
@@ -1076,6 +1076,44 @@ def test_h2_producers_write_the_planes_of_their_fp32_twins(lib, dev):
         assert lib.avsep_op_attention_split_h2(q.data_ptr(), dm, kv.data_ptr(), 2 * dm, kv.data_ptr() + 4 * dm, 2 * dm, op.data_ptr(),
                                                B * Lq + 1, eo, B, h, 64, Lq, Lk, _stream()) == 0
         assert torch.equal(op, _h2_planes(lib, o, eo, rows=B * Lq + 1)), (B, h, Lq, Lk)
+
+
+def test_h2_row_scaled_operand(lib, dev):
+    """An operand WITHOUT a static bound (the resized visual stream in front of the fusion K/V projection): the resize kernel gives every
+    row its own power of two from the row's largest magnitude, the GEMM multiplies row m of its accumulators by rscale[m].  Rows
+    whose magnitudes differ by 1e12 keep the fp32 GEMM's accuracy relative to THEIR OWN scale; the planes are exactly
+    avsep_op_split_h2 with those row exponents of the fp32 resize."""
+    B, N, T, d, Nw = 3, 50, 251, 512, 1024
+    v = t(seeded.tensor(47, "v", (B * N, d), -2, 2), dev)
+    v *= (10.0 ** (torch.arange(B * N, device=dev) % 13 - 6).float()).unsqueeze(1)
+    v[7] = 0.0
+    u = torch.empty(B * T, d, device=dev)
+    assert lib.avsep_op_interp_linear(v.data_ptr(), u.data_ptr(), B, N, T, d, _stream()) == 0
+    up = torch.zeros(d // 32, 2, B * T, 32, dtype=torch.int16, device=dev)
+    rs = torch.full((B * T,), float("nan"), device=dev)
+    assert lib.avsep_op_interp_linear_h2(v.data_ptr(), up.data_ptr(), rs.data_ptr(), B * T, B, N, T, d, _stream()) == 0
+    e = torch.round(-torch.log2(rs)).to(torch.int32)
+    assert torch.equal(torch.ldexp(torch.ones_like(rs), -e), rs)                                   # powers of two
+    mx = u.abs().max(dim=1).values.double() * 2.0 ** e.double()
+    nz = u.abs().max(dim=1).values > 0
+    assert bool(((mx >= 2.0 ** 13) & (mx < 2.0 ** 14))[nz].all()) and bool((e[~nz] == 0).all())
+    assert torch.equal(up, _h2_planes(lib, u, 0, row_exp=e))
+    w = t(seeded.tensor(47, "w", (Nw, d), -0.2, 0.2), dev)
+    b = t(seeded.tensor(47, "b", (Nw,), -1e-6, 1e-6), dev)
+    wp, ew, _ = _h2_weight(lib, w)
+    cs = torch.ldexp(torch.ones(Nw, device=dev), -ew)
+    y = torch.full((B * T, Nw), float("nan"), device=dev)
+    assert lib.avsep_op_linear_h2(up.data_ptr(), B * T, wp.data_ptr(), Nw, cs.data_ptr(), rs.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, 0, 0,
+                                  B * T, Nw, d, 0, _stream()) == 0, lib.avsep_last_error()
+    ref = u.double() @ w.double().t() + b.double()
+    rowscale = u.double().abs().max(dim=1, keepdim=True).values.clamp_min(1e-30)
+    assert float(((y.double() - ref).abs() / rowscale).max()) < 4e-6                                # every row at its own scale
+    y1 = torch.full((1, Nw), float("nan"), device=dev)                                              # a row alone: same bits
+    m = 5 * T // 2
+    up1 = _h2_planes(lib, u[m:m + 1].contiguous(), 0, row_exp=e[m:m + 1].contiguous())
+    assert lib.avsep_op_linear_h2(up1.data_ptr(), 1, wp.data_ptr(), Nw, cs.data_ptr(), rs[m:m + 1].contiguous().data_ptr(), b.data_ptr(), None,
+                                  y1.data_ptr(), None, 0, 0, 1, Nw, d, 0, _stream()) == 0
+    assert torch.equal(y1[0], y[m])
 
 
 @pytest.mark.parametrize("M", [3, 300, 20000])

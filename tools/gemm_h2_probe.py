@@ -52,7 +52,7 @@ for M, N, K, act, res in shapes:
     def f_h2(i, env):
         for k in ("AVSEP_H2_KERNEL2", "AVSEP_H2_TILE", "AVSEP_H2_MID"): os.environ.pop(k, None)
         os.environ.update(env)
-        return lib.avsep_op_linear_h2(xp.data_ptr(), M, wp.data_ptr(), N, cs.data_ptr(), b.data_ptr(), rp, ys[i].data_ptr(), None, 0, 0, M, N, K, act, st)
+        return lib.avsep_op_linear_h2(xp.data_ptr(), M, wp.data_ptr(), N, cs.data_ptr(), None, b.data_ptr(), rp, ys[i].data_ptr(), None, 0, 0, M, N, K, act, st)
     envs = ({}, {"AVSEP_H2_MID": "1"}, {"AVSEP_H2_TILE": "64"})
     assert f_split() == 0
     for i, e in enumerate(envs): assert f_h2(i, e) == 0, lib.avsep_last_error()
