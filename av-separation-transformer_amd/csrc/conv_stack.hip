@@ -67,6 +67,22 @@ __device__ __forceinline__ unsigned long long cs_tick(const ConvStackParams& p) 
 // NW = wavefronts per workgroup (4 or 8).  With 8, two waves share each SIMD so one wave's LDS gathers / weight
 // loads / barriers hide behind the other's MFMAs: conv2 rows are split in two halves (waves 0-3 / 4-7, each wave
 // still owning 16 output channels), conv3 gives every wave 16 of the 128 channels.
+// The sum of one frame's post-ReLU conv3 outputs of one channel, in an order that depends on the position inside the frame only,
+// never on where the frame's rows start in the pass (first0 = g * P3): a frame must pool to the same bits as the first and as the
+// second frame of a pass, or a clip's output would depend on the parity of its first frame's index in the batch (odd frame counts).
+// Lane-quad q, slot r holds sum class k = (4q + r - first0) mod 16 = the positions k, k+16, k+32 ... of the frame, added in that
+// order by the caller; the 16 classes are then added in the order k = 0..15 (empty classes are +0, post-ReLU values are >= 0).
+__device__ __forceinline__ float pool_classes(const float (&u)[4], int first0, int lane) {
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int m16 = (k + first0) & 15, rk = m16 & 3;                    // wave-uniform
+    const float src = rk == 0 ? u[0] : rk == 1 ? u[1] : rk == 2 ? u[2] : u[3];
+    tot += __shfl(src, (lane & 15) + 16 * (m16 >> 2));
+  }
+  return tot;
+}
+
 template <int G, int RB2, int RB3MAX, int NW>
 __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackParams p) {
   constexpr int NT = 64 * NW;
@@ -338,19 +354,19 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_kernel(const ConvStackPara
       const float invp = 1.0f / (float)P3;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        float s0 = 0.f, s1 = 0.f;
+        float u0[4] = {0.f, 0.f, 0.f, 0.f}, u1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < RB3MAX; ++i) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = 16 * i + 4 * q + r;
             const bool in = (m >= g * P3) && (m < (g + 1) * P3);
-            s0 += in ? fmaxf(acc0[i][r] + bias3_0, 0.0f) : 0.0f;
-            s1 += in ? fmaxf(acc1[i][r] + bias3_1, 0.0f) : 0.0f;
+            u0[r] += in ? fmaxf(acc0[i][r] + bias3_0, 0.0f) : 0.0f;
+            u1[r] += in ? fmaxf(acc1[i][r] + bias3_1, 0.0f) : 0.0f;
           }
         }
-        s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
-        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        const float s0 = pool_classes(u0, g * P3, lane);
+        const float s1 = CB3 > 1 ? pool_classes(u1, g * P3, lane) : 0.f;
         if (q == 0 && f0 + g < p.Mv) {
           p.pooled[(size_t)(f0 + g) * C3 + ch3] = s0 * invp;
           if constexpr (CB3 > 1) p.pooled[(size_t)(f0 + g) * C3 + ch3 + 16] = s1 * invp;
@@ -712,19 +728,19 @@ __global__ __launch_bounds__(64 * NW) void conv_stack_h2_kernel(const ConvStackP
       const float invp = 1.0f / (float)P3;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        float s0 = 0.f, s1 = 0.f;
+        float u0[4] = {0.f, 0.f, 0.f, 0.f}, u1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < RB3MAX; ++i) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = 16 * i + 4 * q + r;
             const bool in = (m >= g * P3) && (m < (g + 1) * P3);
-            s0 += in ? fmaxf(acc0[i][r] * d2s[g] * sc3_0 + bias3_0, 0.0f) : 0.0f;
-            s1 += in ? fmaxf(acc1[i][r] * d2s[g] * sc3_1 + bias3_1, 0.0f) : 0.0f;
+            u0[r] += in ? fmaxf(acc0[i][r] * d2s[g] * sc3_0 + bias3_0, 0.0f) : 0.0f;
+            u1[r] += in ? fmaxf(acc1[i][r] * d2s[g] * sc3_1 + bias3_1, 0.0f) : 0.0f;
           }
         }
-        s0 += __shfl_xor(s0, 16); s0 += __shfl_xor(s0, 32);
-        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        const float s0 = pool_classes(u0, g * P3, lane);
+        const float s1 = CB3 > 1 ? pool_classes(u1, g * P3, lane) : 0.f;
         if (q == 0 && f0 + g < p.Mv) {
           p.pooled[(size_t)(f0 + g) * C3 + ch3] = s0 * invp;
           if constexpr (CB3 > 1) p.pooled[(size_t)(f0 + g) * C3 + ch3 + 16] = s1 * invp;

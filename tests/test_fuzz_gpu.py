@@ -52,13 +52,52 @@ def test_fuzz_inference_against_numpy_oracle(case):
     dev = torch.device("cuda:0")
     m = _model(dev, cfg, case).eval()
     mixed, lips = seeded.inputs(500 + case, dm["B"], cfg["freq_bins"], dm["T"], dm["N"], dm["H"], dm["W"])
+    x, l = torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev)
     with torch.no_grad():
-        sep, masks = m(torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev))
+        sep, masks = m(x, l)
+        for b in sorted({0, dm["B"] - 1}):                           # a clip alone: the bits it has inside the batch
+            s1, m1 = m(x[b:b + 1], l[b:b + 1])
+            assert torch.equal(m1, masks[b:b + 1]) and torch.equal(s1, sep[b:b + 1]), (b, cfg, dm)
     state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     rs, rm = onp.forward(state, mixed, lips, cfg["nhead"], cfg["num_speakers"])
     assert masks.shape == (dm["B"], cfg["num_speakers"], cfg["freq_bins"], dm["T"]), (cfg, dm)
     assert maxabs(masks.cpu().numpy(), rm) < 4e-6, (cfg, dm)
     assert maxabs(sep.cpu().numpy(), rs) < 4e-6 * max(1.0, float(np.abs(mixed).max())), (cfg, dm)
+
+
+def _draw_wide(rng):
+    """d_model >= 512: the split-precision path (two-term fp16 GEMMs with static exponents, three-term bf16 where there is no static
+    bound, split-precision attention at dh = 64 and 128+ keys), incl. head dims that keep the fp32 attention, odd S*F (fp32 mask
+    head), zero layers, and row counts on both sides of the 256 x 128 kernels' threshold"""
+    d = rng.choice([512, 512, 512, 640, 768, 1024])
+    h = rng.choice([x for x in (4, 8, 16) if d % x == 0 and (d // x) % 4 == 0 and d // x <= 128])
+    cfg = dict(freq_bins=rng.choice([257, rng.randint(40, 300)]), d_model=d, nhead=h, num_encoder_layers=rng.randint(0, 2),
+               num_fusion_layers=rng.randint(0, 2), num_speakers=rng.randint(1, 3))
+    big = rng.random() < 0.4
+    dims = dict(B=rng.randint(10, 14) if big else rng.randint(1, 4), T=rng.randint(200, 300) if big else rng.randint(1, 300),
+                N=rng.randint(1, 30), H=rng.randint(8, 40), W=rng.randint(8, 40))
+    return cfg, dims
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("AVSEP_FUZZ_WIDE", "12"))))
+def test_fuzz_wide_models_against_torch_cpu_port(case):
+    rng = random.Random(31000 + case)
+    cfg, dm = _draw_wide(rng)
+    dev = torch.device("cuda:0")
+    m = _model(dev, cfg, 300 + case).eval()
+    mixed, lips = seeded.inputs(1500 + case, dm["B"], cfg["freq_bins"], dm["T"], dm["N"], dm["H"], dm["W"])
+    x, l = torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev)
+    with torch.no_grad():
+        sep, masks = m(x, l)
+        for b in sorted({0, 1 % dm["B"], dm["B"] // 2, dm["B"] - 1}):  # a clip alone: the bits it has inside the batch (odd N: both frame parities)
+            s1, m1 = m(x[b:b + 1], l[b:b + 1])
+            assert torch.equal(m1, masks[b:b + 1]) and torch.equal(s1, sep[b:b + 1]), (b, cfg, dm)
+    state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    rs, rm = torch_cpu.forward(state, torch.from_numpy(mixed), torch.from_numpy(lips), cfg["nhead"], cfg["num_speakers"])
+    assert masks.shape == (dm["B"], cfg["num_speakers"], cfg["freq_bins"], dm["T"]), (cfg, dm)
+    assert torch.isfinite(masks).all() and torch.isfinite(sep).all(), (cfg, dm)
+    assert maxabs(masks.cpu().numpy(), rm.contiguous().numpy()) < 4e-6, (cfg, dm)
+    assert maxabs(sep.cpu().numpy(), rs.contiguous().numpy()) < 4e-6 * max(1.0, float(np.abs(mixed).max())), (cfg, dm)
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("AVSEP_FUZZ_TRAIN", "10"))))
