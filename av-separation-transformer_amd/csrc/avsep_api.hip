@@ -122,6 +122,7 @@ struct avsep_ctx {
   // count, so every batch size of a model computes the same bits; d_model = 256 models keep the fp32 MFMA everywhere (their
   // GEMMs are latency-bound: 128 x 128 tiles would leave the chip empty).
   bool split_gemm = true;
+  int split_min = 512;                             // smallest d_model (and weight N, K) of the split-precision rule
   // ... and with operands PRE-SPLIT (gemm_planes.hip; round 5): the weights' planes are cut once by avsep_finalize_weights (keyed by
   // the packed fp32 weight), the activations' by their producers, whenever a stage has enough rows for the 256 x 128 kernel
   // (planes_rows()).  Same bits as the in-flight split, so the choice may look at the row count.
@@ -216,9 +217,10 @@ void layout_arena(avsep_ctx* c, F&& take) {
   // planes of the weights the split-precision rule sends to the bf16 pipe (d_model >= 512: N >= 512 and K >= 512), PLAIN A operand
   c->wplanes.clear();
   c->wplane_sites.clear();
-  if (d >= 512) {
+  if (d >= c->split_min) {
+    const int smin = c->split_min;
     auto wp = [&](const float* w, int n, int k) {
-      if (n < 512 || k < 512 || (k & 31)) return;
+      if (n < smin || k < smin || (k & 31)) return;
       float* q = take(((size_t)n * k * 3 + 1) / 2);                  // 6 bytes per weight
       if (w) {
         c->wplanes[w] = reinterpret_cast<unsigned short*>(q);
@@ -233,7 +235,7 @@ void layout_arena(avsep_ctx* c, F&& take) {
     wp(c->d_w2, S * c->F, 2 * d);
     c->h2.clear();
     auto h2 = [&](const float* w, int n, int k) {
-      if (n < 512 || k < 512 || (k & 31)) return;
+      if (n < smin || k < smin || (k & 31)) return;
       avsep_ctx::H2Site t{};
       t.wp = reinterpret_cast<unsigned short*>(take((size_t)n * k));           // 4 bytes per weight
       t.cscale = take(n);
@@ -390,7 +392,7 @@ size_t carve(const avsep_ctx* c, Workspace* w, float* base, int B, int T, int N,
   t.v_up = take(Ma * d);
   t.kv_all = take(Ma * (size_t)c->Lf * 2 * d);
   t.f_q = take(Ma * d);
-  if (d >= 512 && !(d & 31)) {                                           // 6 bytes per element = 1.5 floats
+  if (d >= c->split_min && !(d & 31)) {                                           // 6 bytes per element = 1.5 floats
     auto planes = [&](size_t n) { return reinterpret_cast<unsigned short*>(take((n * 3 + 1) / 2)); };
     t.ln_p = planes(Ma * d); t.att_p = planes(Ma * d); t.ffn_p = planes(Ma * 4 * d);
     t.v_ln_p = planes(Mv * d); t.v_att_p = planes(Mv * d); t.v_ffn_p = planes(Mv * 4 * d);
@@ -481,7 +483,7 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
     bytes += (p.Ap ? rows * k * 2 : 0.0) + (double)p.N * k * 2 + (p.Cp ? rows * p.N * (p.C ? 6.0 : 2.0) : 0.0);   // 6 bytes per plane element
     return profiled(c, gemm_planes_instance_name(), flops, bytes, s, [&] { return launch_gemm_planes(pp, s); });
   }
-  if (c->split_gemm && c->d >= 512 && p.N >= 512 && p.K >= 512 && gemm_split_supported(p) &&       // see avsep_ctx::split_gemm
+  if (c->split_gemm && c->d >= c->split_min && p.N >= c->split_min && p.K >= c->split_min && gemm_split_supported(p) &&       // see avsep_ctx::split_gemm
       !(no_taps && p.amode == AMODE_TAPS3) && !(no_mask && p.C2)) {
     GemmParams ps = p;
     ps.split_t2_min = 48;                                          // several forwards in flight: see gemm_split.hip, "Which kernel"
@@ -495,12 +497,12 @@ int run_gemm(avsep_ctx* c, const GemmParams& p, hipStream_t s, int kalg = 0) {
 // may look at the row count.  Debug taps read fp32 tensors: a tapped forward takes the in-flight path.
 bool planes_rows(const avsep_ctx* c, const Workspace& w, int M) {
   static const bool off = dev_env("AVSEP_NO_PLANES") != nullptr;                                    // developer A/B
-  return c->use_planes && !off && c->split_gemm && c->d >= 512 && !(c->d & 31) && w.ln_p && !c->keep_taps && !c->wplanes.empty() &&
+  return c->use_planes && !off && c->split_gemm && c->d >= c->split_min && !(c->d & 31) && w.ln_p && !c->keep_taps && !c->wplanes.empty() &&
          (long)((M + 255) / 256) * 4 >= 48;
 }
 // The two-term fp16 site of weight W (gemm_h2.hip), or null: the model / the weight is not on that path.  Never looks at a row count.
 const avsep_ctx::H2Site* h2_site(const avsep_ctx* c, const Workspace& w, const float* W) {
-  if (!c->use_h2 || !c->split_gemm || c->d < 512 || !w.ln_p) return nullptr;
+  if (!c->use_h2 || !c->split_gemm || c->d < c->split_min || !w.ln_p) return nullptr;
   auto it = c->h2.find(W);
   return it == c->h2.end() ? nullptr : &it->second;
 }
@@ -529,7 +531,7 @@ int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk
   // (d_model >= 512), head width 64, sequences of 128 keys or more -- the domain of the LDS-staged fp32 kernel it replaces.
   // The rule looks at the model and the sequence lengths only, never at the batch size.
   static const bool no_split_attn = dev_env("AVSEP_NO_SPLIT_ATTN") != nullptr;                       // developer A/B
-  if (c->split_gemm && c->d >= 512 && Lk >= 128 && attention_split_supported(c->dh, Lq, Lk) && !no_split_attn)
+  if (c->split_gemm && c->d >= c->split_min && Lk >= 128 && attention_split_supported(c->dh, Lq, Lk) && !no_split_attn)
     return profiled(c, "attention_split_kernel<2>", flops, bytes, s, [&] {
       return launch_attention_split(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, 1.0f, s, op, o_rows, h2, h2_exp);
     });
@@ -539,7 +541,7 @@ int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk
 }
 bool attention_is_split(const avsep_ctx* c, int Lq, int Lk) {
   static const bool no_split_attn = dev_env("AVSEP_NO_SPLIT_ATTN") != nullptr;
-  return c->split_gemm && c->d >= 512 && Lk >= 128 && attention_split_supported(c->dh, Lq, Lk) && !no_split_attn;
+  return c->split_gemm && c->d >= c->split_min && Lk >= 128 && attention_split_supported(c->dh, Lq, Lk) && !no_split_attn;
 }
 
 GemmParams linear_params(const float* A, int lda, const float* W, int K, const float* bias, float* C, int ldc,
@@ -1381,6 +1383,7 @@ int avsep_create(const avsep_config* cfg, avsep_ctx** out) try {
   // big-tile GEMM: measured 2.7 % faster there, and every batch size of such a model then computes the same bits.
   // Developer A/B: AVSEP_NO_LNX=1 restores the in-kernel LayerNorm form of round 2, AVSEP_LNX=all takes every site.
   c->split_gemm = dev_env("AVSEP_NO_SPLIT") == nullptr;            // developer A/B: the fp32 MFMA GEMM everywhere
+  if (const char* e = dev_env("AVSEP_SPLIT_MIN")) c->split_min = atoi(e) >= 64 ? atoi(e) : 512;   // developer A/B: the rule's floor
   c->use_lnx = dev_env("AVSEP_NO_LNX") == nullptr && (gemm_ln_supported(c->d) || dev_env("AVSEP_LNX"));
   c->lnx_all = dev_env("AVSEP_LNX") && !strcmp(dev_env("AVSEP_LNX"), "all");
   size_t off = 0;

@@ -197,7 +197,9 @@ struct H2Tile {
   unsigned a0, a1, w0, w1;   // this lane's byte offsets inside a (chunk, term) slab: row * 64 + logical slot * 16
 };
 
-template <int BN>
+// V (developer ablations, timing only, AVSEP_H2_ABL; profiles/r05_gemm_h2_ablations.txt): 1 = the lo fragments alias the hi ones (half
+// the LDS reads), 2 = no DMA inside the loop, 4 = no MFMA, 8 = no epilogue
+template <int BN, int V = 0>
 __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(const GemmParams pin) {
   GemmParams p = pin;
   constexpr int BM = 256, WBN = BN / 32;
@@ -296,14 +298,16 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(const GemmParams pin) {
 #define H2_FENCE __builtin_amdgcn_sched_barrier(0);
 #define H2_MMA(fwp, fap)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < WBN; ++j)               \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
+      if constexpr (!(V & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0); \
+      else acc[i][j][0] += __builtin_bit_cast(f32x4, fwp[j])[0] * __builtin_bit_cast(f32x4, fap[i])[1];
   // a product with DMA pieces q0 .. q0 + NQ - 1 of this step's fetch (-> buffer par), one behind every (4 WBN / NQ)-th MFMA
 #define H2_MMA_D(fwp, fap, q0, NQ)                                                                            \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < WBN; ++j) {             \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0);                   \
+    if constexpr (!(V & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0); \
+    else acc[i][j][0] += __builtin_bit_cast(f32x4, fwp[j])[0] * __builtin_bit_cast(f32x4, fap[i])[1];         \
     constexpr int every_ = 4 * WBN / (NQ);                                                                    \
     const int idx_ = i * WBN + j;                                                                             \
-    if (idx_ % every_ == every_ - 1) { H2_FENCE H2_PIECE(l_kc, l_rows, par, (q0) + idx_ / every_) H2_FENCE }  \
+    if (!(V & 2) && idx_ % every_ == every_ - 1) { H2_FENCE H2_PIECE(l_kc, l_rows, par, (q0) + idx_ / every_) H2_FENCE }  \
   }
 
   int par = 0, kc = 0;
@@ -316,7 +320,15 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(const GemmParams pin) {
     f16x8 a_hi[4], a_lo[4], w_hi[WBN], w_lo[WBN];
     {
       const char* rb = ldsh + par * BUF;
-      H2_FRAG_A(0, a_hi) H2_FRAG_W(1, w_lo) H2_FRAG_A(1, a_lo) H2_FRAG_W(0, w_hi)
+      if constexpr (V & 1) {
+        H2_FRAG_A(0, a_hi) H2_FRAG_W(0, w_hi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_lo[i] = a_hi[i];
+#pragma unroll
+        for (int j = 0; j < WBN; ++j) w_lo[j] = w_hi[j];
+      } else {
+        H2_FRAG_A(0, a_hi) H2_FRAG_W(1, w_lo) H2_FRAG_A(1, a_lo) H2_FRAG_W(0, w_hi)
+      }
       H2_FENCE
       H2_MMA(w_lo, a_hi) /* (hi, lo) */
       H2_FENCE
@@ -331,11 +343,20 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(const GemmParams pin) {
     par ^= 1;
     if (++kc == nk) {                                                      // block-uniform
       const int bm = tile / nbn, bn = tile - bm * nbn;
-      if (p.Cp) h2_planes_epilogue<WBN>(p, acc, bm * BM + wm * 64, bn * BN + wn * (BN / 2), fr, fq);
-      if (p.C) {
-        h2_descale<WBN>(p, acc, bn * BN + wn * (BN / 2), fq);
-        h2_descale_rows<4, WBN>(p, acc, bm * BM + wm * 64, fr);
-        gemm_epilogue<4, WBN>(p, acc, bm * BM, bn * BN, wm * 64, wn * (BN / 2), fr, fq);
+      if constexpr (V & 8) {                                               // ablation: a never-taken store keeps the accumulators live
+        float t_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < WBN; ++j) t_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t_ == 12345.678f) p.C[tile] = t_;
+      } else {
+        if (p.Cp) h2_planes_epilogue<WBN>(p, acc, bm * BM + wm * 64, bn * BN + wn * (BN / 2), fr, fq);
+        if (p.C) {
+          h2_descale<WBN>(p, acc, bn * BN + wn * (BN / 2), fq);
+          h2_descale_rows<4, WBN>(p, acc, bm * BM + wm * 64, fr);
+          gemm_epilogue<4, WBN>(p, acc, bm * BM, bn * BN, wm * 64, wn * (BN / 2), fr, fq);
+        }
       }
       tile += tile_step;
       if (tile >= tile_end) break;
@@ -804,10 +825,10 @@ const char* gemm_h2_instance_name(const GemmParams& p) {
   return h2_variant(p) == 128 ? "gemm_h2_kernel<128>" : "gemm_h2_small_kernel";
 }
 
-template <int BN>
+template <int BN, int V = 0>
 static hipError_t launch_h2_big(const GemmParams& p, hipStream_t s) {
   constexpr int BUF = 2 * 256 * 64 + 2 * BN * 64;
-  auto kern = gemm_h2_kernel<BN>;
+  auto kern = gemm_h2_kernel<BN, V>;
   static bool raised[64] = {};
   static int cus[64] = {};
   int dev = 0;
@@ -853,6 +874,17 @@ hipError_t launch_gemm_h2(GemmParams p, hipStream_t s) {
   if (h2_variant(p) == 128) {
 #ifdef AVSEP_DEV
     if (getenv("AVSEP_H2_KERNEL2") && !(p.K & 63)) return launch_h2_big2(p, s);   // developer A/B
+    if (const char* e = getenv("AVSEP_H2_ABL")) {                                  // developer ablations (wrong results, timing only)
+      switch (atoi(e)) {
+        case 1: return launch_h2_big<128, 1>(p, s);
+        case 2: return launch_h2_big<128, 2>(p, s);
+        case 4: return launch_h2_big<128, 4>(p, s);
+        case 8: return launch_h2_big<128, 8>(p, s);
+        case 10: return launch_h2_big<128, 10>(p, s);
+        case 12: return launch_h2_big<128, 12>(p, s);
+        default: break;
+      }
+    }
     if (getenv("AVSEP_H2_MID")) {
       const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
       hipLaunchKernelGGL(gemm_h2_mid_kernel, dim3((unsigned)tiles), dim3(256), 0, s, p);
