@@ -65,14 +65,20 @@ def _scratch(M, Cc, like):
 
 
 # Split-precision GEMM (csrc/gemm_split.hip, avsep_op_linear_split_ex) for every Linear forward / activation-gradient GEMM whose
-# weight has N >= 512 and K >= 512 -- the rule of the inference forward.  OFF by default for the FORWARD GEMMs: the cfg4 step is 7.5 % faster with it
-# (profiles/r04_ab_train_split_gemm.txt) and the GEMM is as close to float64 as the fp32 MFMA one
-# (profiles/r04_gemm_split_error_stats.txt), but its roundings are DIFFERENT ones, so other pre-activations fall on the other
-# side of a ReLU's kink than in the reference's fp32 run: 4 of the 330 cfg4 gradient tensors (linear1.weight / norm2 of two
-# layers) then sit at 5-10x the reference's own fp32-vs-fp64 distance, above the 1.5x gate of
-# tests/test_train_gpu.py::test_train_forward_backward_matches_reference, which this round leaves as it is
-# (test_train_split_gemm_gradients pins what the switch does).  A module attribute, not an environment variable.
-SPLIT_GEMM = False
+# weight has N >= 512 and K >= 512 -- the rule of the inference forward.  ON by default since round 5: the cfg4 step is 7.5 % faster with
+# it (profiles/r04_ab_train_split_gemm.txt) and the GEMM is as close to float64 as the fp32 MFMA one
+# (profiles/r04_gemm_split_error_stats.txt).  Its roundings are DIFFERENT ones, so a few pre-activations within rounding of 0 fall on
+# the other side of a ReLU's kink than in the reference's fp32 run, and the gradient rows behind those units differ from the
+# reference's by whole terms, not by rounding (4 of the 330 cfg4 tensors then sit at 5-10x the reference's own fp32-vs-fp64
+# distance).  The gate of the default path is therefore KINK-AWARE (tests/test_train_gpu.py::
+# test_train_default_gradients_with_the_step_own_relu_decisions): the float64 oracle is re-run with the ReLU decisions THIS step made
+# (RELU_TAP below) and every gradient tensor is held to the unchanged 1.5x / 5e-5 gates against that.  With the switch off the step
+# follows the reference's fp32 decisions and test_train_forward_backward_matches_reference gates it against the reference's own
+# gradients, as before.  A module attribute, not an environment variable.
+SPLIT_GEMM = True
+# Test hook (tests/test_train_gpu.py, the kink-aware gradient gate): when a list is assigned, every ReLU Linear of a train-mode forward
+# without dropout appends (weight shape, y > 0) -- the ReLU decisions this step made, in call order.
+RELU_TAP = None
 # The activation-gradient GEMMs (dX = dY W) alone: they sit behind every ReLU decision of the step, so their rounding moves no
 # pre-activation across a kink -- the gradient gates hold unchanged with them on the split-precision kernels (ON by default).
 SPLIT_GEMM_DGRAD = True
@@ -354,6 +360,8 @@ class LinearFn(torch.autograd.Function):
         ctx.drop = (float(drop_p), int(drop_seed))
         ctx.act, ctx.res_grad = act, (res is not None and rperiod <= 0)
         ctx.save_for_backward(x, w, y if act == ACT_RELU else None)
+        if RELU_TAP is not None and act == ACT_RELU and not drop_p > 0:
+            RELU_TAP.append((tuple(w.shape), y > 0))
         ctx.has_b = b is not None
         ctx.bias = b if isinstance(b, torch.nn.Parameter) else None      # identity only (leaf / .grad checks in backward)
         if BATCHED_WT and w.is_cuda and w.is_leaf and ctx.needs_input_grad[0]:

@@ -355,9 +355,9 @@ def main():
                          "encoder layers of each branch as one dependency-driven persistent launch")
     ap.add_argument("--chain-group", type=int, default=8, help="schedule 1: clips per group of the work-list order")
     ap.add_argument("--chain-skew", type=float, default=0.0, help="schedule 1: ops between consecutive clip groups (0 = op-major)")
-    ap.add_argument("--train-split-gemm", action="store_true",
-                    help="train mode, A/B: split-precision GEMM for every Linear forward / activation-gradient GEMM with N, K >= 512 "
-                         "(av_separation._train.SPLIT_GEMM; default: the fp32 MFMA GEMM)")
+    ap.add_argument("--train-fp32-forward", action="store_true",
+                    help="train mode, A/B: the fp32 MFMA GEMM for the Linear forward GEMMs (av_separation._train.SPLIT_GEMM = False; "
+                         "default since round 5: split-precision for N, K >= 512)")
     ap.add_argument("--train-fp32-dgrad", action="store_true",
                     help="train mode, A/B: the fp32 MFMA GEMM also for the activation-gradient GEMMs (default: split-precision for N, K >= 512)")
     ap.add_argument("--train-fp32-wgrad", action="store_true",
@@ -644,7 +644,7 @@ def main():
         t_also = time.perf_counter()
         out["also"] = {w: also_forward(av, dev, w) for w in ("cfg3", "cfg5")}
         out["also"]["cfg4_train"] = also_train(av, dev)
-        out["also"]["cfg4_train_split_gemm_opt_in"] = also_train(av, dev, split_gemm=True)
+        out["also"]["cfg4_train_fp32_forward_gemms"] = also_train(av, dev, split_gemm=False)
         out["also"]["seconds"] = round(time.perf_counter() - t_also, 1)
     if dist is not None:
         dist.barrier()
@@ -746,11 +746,11 @@ def also_forward(av, dev, name, steps=20, rounds=5, warmup=4):
     return out
 
 
-def also_train(av, dev, steps=5, rounds=3, warmup=6, split_gemm=False):
+def also_train(av, dev, steps=5, rounds=3, warmup=6, split_gemm=True):
     """A short line for BASELINE configs[3]'s training step inside the default run: the loop body of `--mode train`
     (zero_grad, train-mode forward with dropout 0.1, SeparationLoss, backward, clip, fused Adam) on one resident 16-clip
-    batch, single rank.  split_gemm: the opt-in switch av_separation._train.SPLIT_GEMM ("the training step on the
-    split-precision GEMM") for the duration of the line."""
+    batch, single rank.  split_gemm: av_separation._train.SPLIT_GEMM (DESIGN.md, "the training step on the split-precision GEMM";
+    on by default since round 5) for the duration of the line."""
     from av_separation import _train
     from av_separation.losses import SeparationLoss
     was = _train.SPLIT_GEMM
@@ -799,8 +799,10 @@ def _also_train(av, dev, steps, rounds, warmup, split_gemm):
            "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "rounds": rounds, "batch_per_gpu": B,
            "gflop_per_clip": round(gflop, 3), "frac": round(value * gflop / 1e3 / FP32_MATRIX_PEAK_TFLOPS, 4),
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)],
-           "linear_gemm": ("split-precision (opt-in: av_separation._train.SPLIT_GEMM; 4 of 330 gradient tensors leave the 1.5x gate)"
-                           if split_gemm else "fp32 MFMA forward, split-precision activation-gradient GEMMs (default)")}
+           "linear_gemm": ("split-precision forward, activation-gradient and weight-gradient GEMMs (default; gradients gated against the float64 "
+                           "oracle run with the step's own ReLU decisions, tests/test_train_gpu.py)"
+                           if split_gemm else "fp32 MFMA forward (av_separation._train.SPLIT_GEMM = False: the reference's own ReLU decisions), "
+                           "split-precision activation-gradient and weight-gradient GEMMs")}
     del model, opt
     torch.cuda.empty_cache()
     return out
@@ -834,8 +836,8 @@ def train_main(a, av, dev, dist, rank, world):
     on one resident batch per rank.  Not the headline metric; reported for the N1 row."""
     from av_separation import parallel, _train
     from av_separation.losses import SeparationLoss
-    if a.train_split_gemm:
-        _train.SPLIT_GEMM = True
+    if a.train_fp32_forward:
+        _train.SPLIT_GEMM = False
     if a.train_fp32_dgrad:
         _train.SPLIT_GEMM_DGRAD = False
     if a.train_fp32_wgrad:
@@ -907,7 +909,7 @@ def train_main(a, av, dev, dist, rank, world):
                    "batch_per_gpu": B, "global_batch": world * B, "gflop_per_clip": round(gflop_clip, 3),
                    "parameters": nparam, "launch": "eager, one launch per op",
                    "gemm": ("Linear layers with N, K >= 512: forward GEMMs " +
-                            ("split-precision (opt-in)" if _train.SPLIT_GEMM else "fp32 MFMA") + ", activation-gradient GEMMs " +
+                            ("split-precision" if _train.SPLIT_GEMM else "fp32 MFMA (A/B switch)") + ", activation-gradient GEMMs " +
                             ("split-precision" if (_train.SPLIT_GEMM or _train.SPLIT_GEMM_DGRAD) else "fp32 MFMA") + ", weight gradients " +
                             ("split-precision" if _train.SPLIT_GEMM_WGRAD else "fp32 MFMA") +
                             " (split-precision = six bf16 MFMA products per fp32 product, fp32-equivalent); everything else fp32 MFMA"),

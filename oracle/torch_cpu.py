@@ -29,9 +29,27 @@ import torch.nn.functional as F
 RELU_PROBE = None
 
 
+# When a list is assigned here, ReLU number i of a forward (call order: audio input_proj.0, input_proj.2, audio encoder linear1 per layer,
+# the three Conv2d blocks, visual encoder linear1 per layer) takes its DECISIONS from entry i (a bool / 0-1 tensor of the
+# pre-activation's shape; None = decide by sign as usual): relu(x) := x * mask.  The kink-aware gradient gate of
+# tests/test_train_gpu.py forces the decisions the HIP step made, so that what is compared is the derivative of the SAME piecewise-
+# linear branch of the function -- a pre-activation within rounding of 0 may fall on either side in two correct implementations.
+RELU_FORCE = None
+RELU_RECORD = None      # a list: every ReLU appends the decisions it made by sign (x > 0)
+_relu_calls = [0]
+
+
 def _relu(x):
+    i = _relu_calls[0]
+    _relu_calls[0] = i + 1
     if RELU_PROBE is not None:
         RELU_PROBE.append(float(x.detach().abs().min()))
+    if RELU_RECORD is not None:
+        RELU_RECORD.append(x.detach() > 0)
+    if RELU_FORCE is not None and i < len(RELU_FORCE) and RELU_FORCE[i] is not None:
+        m = RELU_FORCE[i]
+        assert m.shape == x.shape, (i, tuple(m.shape), tuple(x.shape))
+        return x * m.to(x.dtype)
     return F.relu(x)
 
 
@@ -100,6 +118,7 @@ def forward_train(state, mixed, lips, nhead, num_speakers, dropout=0.0):
 
 def _forward(W, mixed, lips, nhead, num_speakers, fast, train, drop):
     B, Fq, T = mixed.shape
+    _relu_calls[0] = 0
     # ---- AudioEncoder (model.py:54-60)
     h = _relu(F.conv1d(mixed, W["audio_encoder.input_proj.0.weight"], W["audio_encoder.input_proj.0.bias"], padding=1))
     h = _relu(F.conv1d(h, W["audio_encoder.input_proj.2.weight"], W["audio_encoder.input_proj.2.bias"], padding=1))

@@ -58,7 +58,7 @@ def test_bench_single_gpu_contract_line():
         assert al[w]["steps_in_flight"] in (1, 2) and al[w]["value"] >= al[w]["one_step_at_a_time"]["value"] - 1e-6
         assert al[w]["one_clip_at_a_time"]["bit_equal_to_the_clip_inside_the_batch"] and al[w]["one_clip_at_a_time"]["ms_per_forward"] > 0
     assert al["cfg4_train"]["batch_per_gpu"] == 16 and al["cfg4_train"]["value"] > 0 and al["seconds"] < 120
-    assert al["cfg4_train"]["linear_gemm"].startswith("fp32") and al["cfg4_train_split_gemm_opt_in"]["value"] > 0
+    assert al["cfg4_train"]["linear_gemm"].startswith("split-precision") and al["cfg4_train_fp32_forward_gemms"]["value"] > 0
     ql = cb["quality"]
     assert ql["gpu"]["snr_improvement_db"] >= 35.0 and abs(ql["trained_out_snr_gpu_minus_cpu_db"]) < 1.0
     if rf["traffic"] is not None:
