@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "avsep_finalize_weights", "avsep_workspace_bytes", "avsep_forward", "avsep_forward_graph",
     "avsep_audio_encoder", "avsep_visual_encoder", "avsep_fusion", "avsep_decoder",
     "avsep_set_debug_taps", "avsep_set_split_precision", "avsep_read_tap", "avsep_profile_begin", "avsep_profile_end", "avsep_op_linear", "avsep_op_linear_split", "avsep_op_split_planes", "avsep_op_linear_planes", "avsep_op_layernorm_planes", "avsep_op_interp_linear_planes", "avsep_op_attention_split_planes", "avsep_op_h2_row_stats", "avsep_op_split_h2", "avsep_op_linear_h2", "avsep_op_interp_linear_h2", "avsep_op_layernorm_h2", "avsep_op_attention_split_h2", "avsep_op_layernorm", "avsep_op_ln_linear",
-    "avsep_op_attention", "avsep_op_attention_split", "avsep_op_interp_linear", "avsep_stft_basis_floats", "avsep_stft_basis", "avsep_op_stft_mag",
+    "avsep_op_attention", "avsep_op_attention_split", "avsep_op_attention_h2", "avsep_op_interp_linear", "avsep_stft_basis_floats", "avsep_stft_basis", "avsep_op_stft_mag",
     # training ops
     "avsep_op_linear_ex", "avsep_op_attention_train", "avsep_op_attention_bwd", "avsep_op_transpose",
     "avsep_op_transpose_pad", "avsep_op_im2col1d", "avsep_op_col2im1d", "avsep_op_im2col2d", "avsep_op_col2im2d",
@@ -111,6 +111,7 @@ def _open(path):
     lib.avsep_op_interp_linear_h2.argtypes = [fp, p, fp, i64, i, i, i, i, p]
     lib.avsep_op_layernorm_h2.argtypes = [fp, fp, fp, p, i64, i, i, C.c_float, i, p]
     lib.avsep_op_attention_split_h2.argtypes = [fp, i, fp, i, fp, i, p, i64, i, i, i, i, i, i, p]
+    lib.avsep_op_attention_h2.argtypes = [fp, i, fp, i, fp, i, fp, i, i, i, i, i, i, i, i, i, p]
     lib.avsep_set_split_precision.argtypes = [p, i]
     lib.avsep_op_layernorm.argtypes = [fp, fp, fp, fp, i, i, C.c_float, p]
     lib.avsep_op_ln_linear.argtypes = [fp, fp, fp, fp, fp, fp, fp, i, i, i, i, C.c_float, i, p]

@@ -326,6 +326,282 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const float* __
   }
 }
 
+// ---- two fp16 terms (round 5): the scheme of gemm_h2.hip applied to both products of the attention ---------------------------------
+// Where the caller has a STATIC bound on |q|, |k| and |v| (self-attention behind a LayerNorm: the bound of the in-projection,
+// avsep_api.hip h2_prepare), every operand is x 2^e = hi + lo with hi = rn16(x 2^e), lo = rn16(x 2^e - hi) (e puts the bound below
+// 2^14; 22 significant bits for every |x| within 17 binades of the bound, 2^-39 of the bound below that), the probabilities --
+// in [0, 1] by construction -- with e = 14, and a product is the THREE fp16 MFMA products (lo,hi) (hi,lo) (hi,hi): half the matrix
+// work of the three-term kernel above and a cheaper split (one v_cvt_pk_f16_f32 pair per two values).  The scores stay in units of
+// 2^(eq + ek): the running maximum and the exponentials work on the scaled values with the constants of exp_neg scaled by the same
+// power of two (exact), so the descale costs nothing; O is descaled by 2^-(14 + ev) together with the division by the row sum.
+// Same tiling, same LDS images (two planes per operand instead of three: 16 KB per step), same fragment reads.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int AH_BUF = 4 * AS_PL;            // [K hi|lo][V hi|lo] = 16 KB
+
+struct Planes2 {
+  unsigned hi[4], lo[4];
+};
+__device__ __forceinline__ Planes2 split8_h2(const f32x4 a, const f32x4 b, float mul) {
+  Planes2 w;
+  split_pair_h2(f32x2{a[0], a[1]} * mul, w.hi[0], w.lo[0]);
+  split_pair_h2(f32x2{a[2], a[3]} * mul, w.hi[1], w.lo[1]);
+  split_pair_h2(f32x2{b[0], b[1]} * mul, w.hi[2], w.lo[2]);
+  split_pair_h2(f32x2{b[2], b[3]} * mul, w.hi[3], w.lo[3]);
+  return w;
+}
+__device__ __forceinline__ f16x8 as_frag_h(const u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+// exp((x) * c) for a power of two c, x <= 0: exp_neg_finite / exp_neg_pair with their three constants multiplied by c (exact)
+__device__ __forceinline__ float exp_neg_scaled(float x, float hi, float lo) {
+  const float t = x * hi;
+  float r = fmaf(x, hi, -t);
+  r = fmaf(x, lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.69314718055994530942f, e);
+}
+__device__ __forceinline__ f32x2 exp_neg_pair_scaled(f32x2 x, float hi, float lo) {
+  const f32x2 HI = {hi, hi}, LO = {lo, lo};
+  const f32x2 LN2 = {0.69314718055994530942f, 0.69314718055994530942f};
+  const f32x2 t = x * HI;
+  f32x2 r = __builtin_elementwise_fma(x, HI, -t);
+  r = __builtin_elementwise_fma(x, LO, r);
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(t[0]);
+  e[1] = __builtin_amdgcn_exp2f(t[1]);
+  return __builtin_elementwise_fma(e, r * LN2, e);
+}
+
+template <int QT>
+__global__ __launch_bounds__(256, 2) void attention_h2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                              int ldk, const float* __restrict__ v, int ldv, float* __restrict__ o,
+                                                              int ldo, int nhead, int Lq, int Lk, int nqt, float qmul, float kmul,
+                                                              float vmul, float sdesc, float odesc, unsigned short* __restrict__ op,
+                                                              long long o_rows, float h2_scale, const int* __restrict__ clip_exp,
+                                                              int clip_stride, int eq, float* __restrict__ rs_out) {
+  constexpr int DH = 64;
+  __shared__ __attribute__((aligned(16))) char lds[2 * AH_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int nqw = (nqt + QT - 1) / QT;
+  const int wg_per_head = (nqw + 3) >> 2;
+  const int bh = blockIdx.x / wg_per_head;
+  const int qw = (blockIdx.x - bh * wg_per_head) * 4 + wave;
+  const bool active = qw < nqw;                       // no wave leaves early (barriers): idle waves compute on clamped rows
+  const int b = bh / nhead, h = bh - b * nhead;
+  float rs_clip = 0.0f;
+  if (clip_exp) {                                     // block-uniform: this clip's k / v exponents (cross-attention, clip_exp_kernel)
+    const int ek = clip_exp[(size_t)b * clip_stride], ev = clip_exp[(size_t)b * clip_stride + 1];
+    kmul = ldexpf(1.0f, ek);
+    vmul = ldexpf(1.0f, ev);
+    sdesc = ldexpf(1.0f, -(eq + ek));
+    odesc = ldexpf(1.0f, -(14 + ev));
+    h2_scale = vmul;                                  // |o| <= the bound of v: the out-projection's operand carries the clip's 2^ev
+    rs_clip = ldexpf(1.0f, -ev);
+  }
+  const float* qb = q + (size_t)b * Lq * ldq + h * DH;
+  const float* kb = k + (size_t)b * Lk * ldk + h * DH;
+  const float* vb = v + (size_t)b * Lk * ldv + h * DH;
+  float* ob = o + (size_t)b * Lq * ldo + h * DH;
+  const float l2e_hi = 1.44269502162933349609f * sdesc, l2e_lo = 1.92596299112661746e-08f * sdesc;   // sdesc = 2^-(eq + ek)
+  // a masked score in the scores' units: below every real one (|scaled score| <= 64 * 2^28) and finite times l2e_hi for sdesc <= 2^60
+  const float masked = MASKED * fminf(1.0f, 1.0f / sdesc);
+
+  f16x8 qh[QT][2], ql[QT][2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = min((qw * QT + t) * 16 + c, Lq - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float* src = qb + (size_t)qrow * ldq + 32 * s + 8 * g;
+      const Planes2 w = split8_h2(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), qmul);
+      qh[t][s] = as_frag_h(vec4(w.hi)); ql[t][s] = as_frag_h(vec4(w.lo));
+    }
+  }
+  f32x4 acc[QT][4];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    mrun[t] = masked;
+    lrun[t] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int srow = tid >> 3, spc = tid & 7;
+  const int kst = srow * 128 + ((spc ^ (srow & 7)) << 4);
+  const int vsw = (srow >> 1) & 3;
+  const int vst0 = 2 * AS_PL + srow * 128 + ((((2 * spc) >> 2) ^ vsw) << 5) + (((2 * spc) & 3) << 3);
+  const int vst1 = 2 * AS_PL + srow * 128 + ((((2 * spc + 1) >> 2) ^ vsw) << 5) + (((2 * spc + 1) & 3) << 3);
+  f32x4 sk0, sk1, sv0, sv1;
+  const int nstep = (Lk + AS_KEYS - 1) / AS_KEYS;
+  auto load_step = [&](int st) {
+    const int key = min(st * AS_KEYS + srow, Lk - 1);
+    const float* ks = kb + (size_t)key * ldk + 8 * spc;
+    const float* vs = vb + (size_t)key * ldv + 8 * spc;
+    sk0 = *reinterpret_cast<const f32x4*>(ks); sk1 = *reinterpret_cast<const f32x4*>(ks + 4);
+    sv0 = *reinterpret_cast<const f32x4*>(vs); sv1 = *reinterpret_cast<const f32x4*>(vs + 4);
+  };
+  auto store_step = [&](int buf) {
+    char* base = lds + buf * AH_BUF;
+    const Planes2 wk = split8_h2(sk0, sk1, kmul);
+    *reinterpret_cast<u32x4*>(base + kst) = vec4(wk.hi);
+    *reinterpret_cast<u32x4*>(base + AS_PL + kst) = vec4(wk.lo);
+    const Planes2 wv = split8_h2(sv0, sv1, vmul);
+    *reinterpret_cast<u32x2*>(base + vst0) = u32x2{wv.hi[0], wv.hi[1]};
+    *reinterpret_cast<u32x2*>(base + vst1) = u32x2{wv.hi[2], wv.hi[3]};
+    *reinterpret_cast<u32x2*>(base + AS_PL + vst0) = u32x2{wv.lo[0], wv.lo[1]};
+    *reinterpret_cast<u32x2*>(base + AS_PL + vst1) = u32x2{wv.lo[2], wv.lo[3]};
+  };
+  int kfo[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int row = 16 * kt + c;
+      kfo[kt][s] = row * 128 + (((4 * s + g) ^ (row & 7)) << 4);
+    }
+  int vfo[2];
+  {
+    const int qq = c >> 2, p = c & 3;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int row = 16 * kt + 4 * g + qq;
+      vfo[kt] = 2 * AS_PL + row * 128 + (p << 3) + ((((row >> 1) & 3)) << 5);
+    }
+  }
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+  for (int st = 0; st < nstep; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstep) load_step(st + 1);
+    const char* base = lds + buf * AH_BUF;
+
+    f32x4 stt[2][QT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int t = 0; t < QT; ++t) stt[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 kh[2], kl[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        kh[kt] = *reinterpret_cast<const f16x8*>(base + kfo[kt][s]);
+        kl[kt] = *reinterpret_cast<const f16x8*>(base + AS_PL + kfo[kt][s]);
+      }
+#define AH_S(KP, QP)                                                                                       \
+  _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) _Pragma("unroll") for (int t = 0; t < QT; ++t)         \
+      stt[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(KP[kt], QP[t][s], stt[kt][t], 0, 0, 0);
+      AH_S(kl, qh)
+      AH_S(kh, ql)
+      AH_S(kh, qh)
+#undef AH_S
+    }
+
+    f16x8 ph[QT], pl[QT];
+    const bool ragged = (st + 1) * AS_KEYS > Lk;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (ragged) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stt[kt][t][r] = st * AS_KEYS + 16 * kt + 4 * g + r < Lk ? stt[kt][t][r] : masked;
+      }
+      float tmax = fmaxf(fmaxf(fmaxf(stt[0][t][0], stt[0][t][1]), fmaxf(stt[0][t][2], stt[0][t][3])),
+                         fmaxf(fmaxf(stt[1][t][0], stt[1][t][1]), fmaxf(stt[1][t][2], stt[1][t][3])));
+      tmax = rows_max(tmax);
+      const float mnew = fmaxf(mrun[t], tmax);
+      const float alpha = exp_neg_scaled(mrun[t] - mnew, l2e_hi, l2e_lo);
+      const f32x2 m2 = {mnew, mnew};
+      const f32x2 p01 = exp_neg_pair_scaled(f32x2{stt[0][t][0], stt[0][t][1]} - m2, l2e_hi, l2e_lo);
+      const f32x2 p23 = exp_neg_pair_scaled(f32x2{stt[0][t][2], stt[0][t][3]} - m2, l2e_hi, l2e_lo);
+      const f32x2 p45 = exp_neg_pair_scaled(f32x2{stt[1][t][0], stt[1][t][1]} - m2, l2e_hi, l2e_lo);
+      const f32x2 p67 = exp_neg_pair_scaled(f32x2{stt[1][t][2], stt[1][t][3]} - m2, l2e_hi, l2e_lo);
+      const float psum = (((p01[0] + p01[1]) + (p23[0] + p23[1])) + ((p45[0] + p45[1]) + (p67[0] + p67[1])));
+      lrun[t] = lrun[t] * alpha + psum;
+      mrun[t] = mnew;
+      Planes2 w;
+      split_pair_h2(p01 * 16384.0f, w.hi[0], w.lo[0]);
+      split_pair_h2(p23 * 16384.0f, w.hi[1], w.lo[1]);
+      split_pair_h2(p45 * 16384.0f, w.hi[2], w.lo[2]);
+      split_pair_h2(p67 * 16384.0f, w.hi[3], w.lo[3]);
+      ph[t] = as_frag_h(vec4(w.hi)); pl[t] = as_frag_h(vec4(w.lo));
+      const f32x2 a2 = {alpha, alpha};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 lo2 = f32x2{acc[t][i][0], acc[t][i][1]} * a2, hi2 = f32x2{acc[t][i][2], acc[t][i][3]} * a2;
+        acc[t][i] = f32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+      }
+    }
+
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      f16x8 vh, vl;
+      {
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        u32x4 w[2];
+#pragma unroll
+        for (int pln = 0; pln < 2; ++pln) {
+          const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + pln * AS_PL + (vfo[0] ^ (blk << 5))));
+          const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + pln * AS_PL + (vfo[1] ^ (blk << 5))));
+          const u32x2 d0 = __builtin_bit_cast(u32x2, r0), d1 = __builtin_bit_cast(u32x2, r1);
+          w[pln] = u32x4{d0[0], d0[1], d1[0], d1[1]};
+        }
+        vh = as_frag_h(w[0]); vl = as_frag_h(w[1]);
+      }
+#define AH_O(VP, PP) \
+  _Pragma("unroll") for (int t = 0; t < QT; ++t) acc[t][blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(VP, PP[t], acc[t][blk], 0, 0, 0);
+      AH_O(vl, ph)
+      AH_O(vh, pl)
+      AH_O(vh, ph)
+#undef AH_O
+    }
+    if (st + 1 < nstep) store_step(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (!active) return;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    float l = lrun[t];
+    l = rows_sum(l);
+    const float inv = odesc / l;                        // odesc = 2^-(14 + ev)
+    const int qo = (qw * QT + t) * 16 + c;
+    if (op) {                                           // block-uniform: the two fp16 terms of the out-projection's A operand (gemm_h2.hip)
+      const size_t ts = (size_t)o_rows * 64;
+      const int slot = ((g & 1) << 1) | (g >> 1);
+      if (rs_out && h == 0 && g == 0 && qo < Lq) rs_out[(size_t)b * Lq + qo] = rs_clip;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float lo4[4], hi4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[t][2 * u][r] * inv), __float_as_uint(acc[t][2 * u + 1][r] * inv), false, false);
+          lo4[r] = __uint_as_float(sw[0]);
+          hi4[r] = __uint_as_float(sw[1]);
+        }
+        unsigned hh[4], ll[4];
+        split_pair_h2(f32x2{lo4[0], lo4[1]} * h2_scale, hh[0], ll[0]);
+        split_pair_h2(f32x2{lo4[2], lo4[3]} * h2_scale, hh[1], ll[1]);
+        split_pair_h2(f32x2{hi4[0], hi4[1]} * h2_scale, hh[2], ll[2]);
+        split_pair_h2(f32x2{hi4[2], hi4[3]} * h2_scale, hh[3], ll[3]);
+        if (qo < Lq) {
+          char* dst = reinterpret_cast<char*>(op) + (((size_t)(2 * h + u) * 2) * o_rows + (size_t)b * Lq + qo) * 64 + slot * 16;
+          *reinterpret_cast<u32x4*>(dst) = vec4(hh);
+          *reinterpret_cast<u32x4*>(dst + ts) = vec4(ll);
+        }
+      }
+    } else if (qo < Lq) {
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+        *reinterpret_cast<f32x4*>(ob + (size_t)qo * ldo + 16 * blk + 4 * g) =
+            f32x4{acc[t][blk][0] * inv, acc[t][blk][1] * inv, acc[t][blk][2] * inv, acc[t][blk][3] * inv};
+    }
+  }
+}
+
 }  // namespace
 
 bool attention_split_supported(int dh, int Lq, int Lk) { return dh == 64 && Lq > 0 && Lk > 0; }
@@ -341,5 +617,28 @@ hipError_t launch_attention_split(const float* q, int ldq, const float* k, int l
   const dim3 grid((unsigned)((long)B * nhead * ((nqw + 3) / 4)));
   hipLaunchKernelGGL((attention_split_kernel<QT>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt, qscale, op, o_rows,
                      h2 ? ldexpf(1.0f, h2_exp) : 0.0f);
+  return hipGetLastError();
+}
+
+// eq / ek / ev: the static exponents of q, k, v (|x| 2^e <= 2^14 for every entry the caller can produce: the caller's bound, not a
+// measurement).  op: the attention output as the two fp16 planes of the out-projection (scaled by 2^h2_exp) instead of fp32 o.
+bool attention_h2_supported(int dh, int Lq, int Lk, int eq, int ek, int ev) {
+  return dh == 64 && Lq > 0 && Lk > 0 && abs(eq) <= 60 && abs(ek) <= 60 && abs(ev) <= 60 && abs(eq + ek) <= 60;
+}
+hipError_t launch_attention_h2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B,
+                               int nhead, int dh, int Lq, int Lk, int eq, int ek, int ev, hipStream_t s, unsigned short* op,
+                               long long o_rows, int h2_exp, const int* clip_exp, int clip_stride, float* rs_out) {
+  if (clip_exp) { ek = ev = 0; }                      // read per clip inside the kernel (clamped to +-60 by clip_exp_kernel)
+  if (B <= 0 || nhead <= 0 || !attention_h2_supported(dh, Lq, Lk, eq, ek, ev)) return hipErrorInvalidValue;
+  if (clip_exp && (clip_stride < 2 || eq < 0 || eq > 60 || !op || !rs_out)) return hipErrorInvalidValue;   // eq + ek >= -60 with the clips' ek >= -60
+  if (op && o_rows < (long long)B * Lq) return hipErrorInvalidValue;
+  if (!op && !o) return hipErrorInvalidValue;
+  if ((ldq | ldk | ldv | ldo) & 3) return hipErrorInvalidValue;
+  constexpr int QT = 2;
+  const int nqt = (Lq + 15) / 16, nqw = (nqt + QT - 1) / QT;
+  const dim3 grid((unsigned)((long)B * nhead * ((nqw + 3) / 4)));
+  hipLaunchKernelGGL((attention_h2_kernel<QT>), grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, nhead, Lq, Lk, nqt, ldexpf(1.0f, eq),
+                     ldexpf(1.0f, ek), ldexpf(1.0f, ev), ldexpf(1.0f, -(eq + ek)), ldexpf(1.0f, -(14 + ev)), op, o_rows, ldexpf(1.0f, h2_exp), clip_exp,
+                     clip_stride, eq, rs_out);
   return hipGetLastError();
 }

@@ -76,6 +76,8 @@ struct Workspace {   // all float*, carved from the caller's buffer
   // rows_a / rows_v: row counts of the audio-length / frame-length buffers (the planes' slab height; a half-batch view keeps them)
   unsigned short *ln_p, *att_p, *ffn_p, *v_ln_p, *v_att_p, *v_ffn_p, *v_up_p;
   float* v_up_rs;            // per-row descale of the resized visual stream's two-term planes (2^-e of each row)
+  int* f_clip_exp;           // [B][Lf][2]: per clip and fusion layer, the exponents of the cross-attention's k and v (clip_exp_kernel)
+  float* f_att_rs;           // per-row descale of the cross-attention output's two-term planes (2^-ev of the row's clip)
   long long rows_a, rows_v;
   size_t floats;
 };
@@ -132,9 +134,11 @@ struct avsep_ctx {
   // Two fp16 terms, three products (gemm_h2.hip; round 5): the GEMM sites whose A operand has a STATIC bound from the weights alone
   // (LayerNorm outputs, act(LayerNorm(x) W^T + b), self-attention outputs).  Per site: the weight's H2 planes (row n scaled by
   // 2^ew[n]), the A operand's exponent eA, cscale[n] = 2^-(eA + ew[n]).  A rule on the model and the weight, never on the batch.
-  struct H2Site { unsigned short* wp; float* cscale; int* ew; float* l2; int eA, N, K; };
+  struct H2Site { unsigned short* wp; float* cscale; int* ew; float* l2; int eA, N, K; int eq, ek, ev; bool qkv; };   // eq / ek / ev: an in-projection's output bounds (attention_h2_kernel)
   std::unordered_map<const float*, H2Site> h2;
   bool use_h2 = true;
+  float* fkv_const = nullptr;    // [Lf][2][2]: per fusion layer, {sqrt(d) max ||w_n||_2, max |b_n|} of its K rows and of its V rows (clip_exp_kernel)
+  bool cross_h2 = false;         // the cross-attention and its out-projection on two fp16 terms with per-clip exponents
   // ... and the fused conv stack's conv2 / conv3 (conv_stack_h2_kernel), every model size: weights as H2 planes + row exponents
   ConvH2 conv_h2{};
   unsigned short *c2_h = nullptr, *c3_h = nullptr;
@@ -246,7 +250,8 @@ void layout_arena(avsep_ctx* c, F&& take) {
     };
     for (auto* v : {&c->a_layers, &c->v_layers})
       for (auto& L : *v) { h2(L.wqkv, 3 * d, d); h2(L.wo, d, d); h2(L.w1, 4 * d, d); h2(L.w2, d, 4 * d); }
-    for (auto& L : c->f_layers) { h2(L.wq, d, d); h2(L.w1, 4 * d, d); h2(L.w2, d, 4 * d); }   // wo: cross-attention output, no static bound
+    for (auto& L : c->f_layers) { h2(L.wq, d, d); h2(L.wo, d, d); h2(L.w1, 4 * d, d); h2(L.w2, d, 4 * d); }   // wo: its operand carries one power of two per CLIP (eA stays 0)
+    c->fkv_const = take((size_t)std::max(c->Lf, 1) * 4);
     h2(c->wkv_all, c->Lf * 2 * d, d);   // its input (the resized visual stream) carries one power of two per ROW (eA stays 0)
     h2(c->d_w1, 2 * d, d);
     h2(c->d_w2, S * c->F, 2 * d);
@@ -398,6 +403,8 @@ size_t carve(const avsep_ctx* c, Workspace* w, float* base, int B, int T, int N,
     t.v_ln_p = planes(Mv * d); t.v_att_p = planes(Mv * d); t.v_ffn_p = planes(Mv * 4 * d);
     t.v_up_p = planes(Ma * d);
     t.v_up_rs = take(Ma);
+    t.f_clip_exp = reinterpret_cast<int*>(take((size_t)std::max(B, 1) * std::max(c->Lf, 1) * 2));
+    t.f_att_rs = take(Ma);
     if (!base) t.ln_p = t.att_p = t.ffn_p = t.v_ln_p = t.v_att_p = t.v_ffn_p = t.v_up_p = nullptr;
   }
   t.rows_a = (long long)Ma;
@@ -524,9 +531,17 @@ bool attention_is_split(const avsep_ctx* c, int Lq, int Lk);
 // op (o_rows): the output as the planes of the out-projection's A operand instead of fp32 `o` (only where attention_is_split())
 int run_attention(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                   int ldo, int B, int Lq, int Lk, hipStream_t s, unsigned short* op = nullptr, long long o_rows = 0, int h2 = 0,
-                  int h2_exp = 0) {
+                  int h2_exp = 0, const avsep_ctx::H2Site* qkv = nullptr) {
   const double flops = 4.0 * B * c->h * (double)Lq * Lk * c->dh;
   const double bytes = 4.0 * B * c->d * (2.0 * Lq + 2.0 * Lk);
+  // two fp16 terms where the operands have static bounds (self-attention behind the in-projection of a two-term site): the rule looks
+  // at the model and the sequence lengths only
+  static const bool no_h2_attn = dev_env("AVSEP_NO_H2_ATTN") != nullptr;                             // developer A/B
+  if (qkv && qkv->qkv && h2 && op && !no_h2_attn && attention_is_split(c, Lq, Lk) &&
+      attention_h2_supported(c->dh, Lq, Lk, qkv->eq, qkv->ek, qkv->ev))
+    return profiled(c, "attention_h2_kernel<2>", flops, bytes, s, [&] {
+      return launch_attention_h2(q, ldq, k, ldk, v, ldv, o, ldo, B, c->h, c->dh, Lq, Lk, qkv->eq, qkv->ek, qkv->ev, s, op, o_rows, h2_exp);
+    });
   // split-precision attention (attention_split.hip): the models whose Linear layers run on the split-precision GEMM
   // (d_model >= 512), head width 64, sequences of 128 keys or more -- the domain of the LDS-staged fp32 kernel it replaces.
   // The rule looks at the model and the sequence lengths only, never at the batch size.
@@ -552,10 +567,11 @@ GemmParams linear_params(const float* A, int lda, const float* W, int K, const f
 // att_p (rows): with planes_rows(), the attention output goes to the projection as planes (split-precision attention only)
 int run_attention_proj(avsep_ctx* c, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* att,
                        const float* wo, const float* bo, float* x, int B, int Lq, int Lk, hipStream_t s,
-                       unsigned short* att_p = nullptr, long long rows = 0, const avsep_ctx::H2Site* h2 = nullptr) {
+                       unsigned short* att_p = nullptr, long long rows = 0, const avsep_ctx::H2Site* h2 = nullptr,
+                       const avsep_ctx::H2Site* qkv = nullptr) {
   const int d = c->d, M = B * Lq;
   if (att_p && attention_is_split(c, Lq, Lk)) {
-    RCK(run_attention(c, q, ldq, k, ldk, v, ldv, att, d, B, Lq, Lk, s, att_p, rows, h2 != nullptr, h2 ? h2->eA : 0));
+    RCK(run_attention(c, q, ldq, k, ldk, v, ldv, att, d, B, Lq, Lk, s, att_p, rows, h2 != nullptr, h2 ? h2->eA : 0, qkv));
     GemmParams po = linear_params(nullptr, d, wo, d, bo, x, d, M, d, ACT_NONE);
     po.Ap = att_p; po.a_rows = rows; po.h2 = h2 != nullptr;
     po.R = x; po.ldr = d; po.rperiod = 0;
@@ -793,7 +809,7 @@ int encoder_layer(avsep_ctx* c, const EncLayerW& L, float* x, float* ln, float* 
   if (bp.ln && bp.h2) {   // two fp16 terms, three products: LayerNorm, attention and FFN-1 write the scaled planes their consumers read
     const avsep_ctx::H2Site *sq = &c->h2.at(L.wqkv), *so = &c->h2.at(L.wo), *s1 = &c->h2.at(L.w1), *s2 = &c->h2.at(L.w2);
     RCK(run_ln_linear_h2(c, x, L.g1, L.be1, bp.ln, bp.rows, L.wqkv, L.bqkv, qkv, nullptr, sq, nullptr, M, 3 * d, ACT_NONE, s));
-    RCK(run_attention_proj(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, L.wo, L.bo, x, B, Lseq, Lseq, s, bp.att, bp.rows, so));
+    RCK(run_attention_proj(c, qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, att, L.wo, L.bo, x, B, Lseq, Lseq, s, bp.att, bp.rows, so, sq));
     RCK(run_ln_linear_h2(c, x, L.g2, L.be2, bp.ln, bp.rows, L.w1, L.b1, nullptr, bp.ffn, s1, s2, M, 4 * d, ACT_RELU, s));
     GemmParams p2 = linear_params(nullptr, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
     p2.Ap = bp.ffn; p2.a_rows = bp.rows; p2.h2 = 1;
@@ -972,6 +988,8 @@ int fusion_kv(avsep_ctx* c, const Workspace& w, const float* visual, int B, int 
     p.A = nullptr; p.Ap = w.v_up_p; p.a_rows = w.rows_a;
   }
   RCK(run_gemm(c, p, s));
+  if (p.h2 && c->cross_h2 && w.f_clip_exp)   // the cross-attention's per-clip k / v exponents, from the row scales of the resized visual stream
+    RCK(profiled(c, "clip_exp_kernel", 0.0, 4.0 * M, s, [&] { return launch_clip_exp(w.v_up_rs, c->fkv_const, w.f_clip_exp, B, T, c->Lf, s); }));
   return AVSEP_OK;
 }
 
@@ -985,7 +1003,23 @@ int fusion_layer(avsep_ctx* c, const Workspace& w, float* x, int B, int T, int i
     RCK(run_ln_linear_h2(c, x, L.g1, L.be1, w.ln_p, w.rows_a, L.wq, L.bq, w.f_q, nullptr, sq, nullptr, M, d, ACT_NONE, s));
     // the cross-attention output (a combination of rows of the VISUAL stream's projection) has no static bound: its projection stays
     // on three bf16 terms -- as planes from the 256 x 128 kernel's row count on, else cut in flight (same bits)
-    if (planes_rows(c, w, M)) RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s, w.att_p, w.rows_a));
+    static const bool no_cross_h2 = dev_env("AVSEP_NO_H2_CROSS") != nullptr;                          // developer A/B
+    if (c->cross_h2 && !no_cross_h2 && sq->qkv && w.f_clip_exp && attention_is_split(c, T, T) && attention_h2_supported(c->dh, T, T, sq->eq, 0, 0)) {
+      // ... unless its K and V carry a bound per CLIP (clip_exp_kernel): two fp16 terms, the output scaled by the clip's power of two, the
+      // projection descaled per row -- at every row count
+      const avsep_ctx::H2Site* so = &c->h2.at(L.wo);
+      const int* ce = w.f_clip_exp + (size_t)i * 2;
+      const double flops = 4.0 * B * c->h * (double)T * T * c->dh, bytes = 4.0 * B * c->d * 4.0 * T;
+      RCK(profiled(c, "attention_h2_kernel<2>", flops, bytes, s, [&] {
+        return launch_attention_h2(w.f_q, d, kk, nkv, kk + d, nkv, nullptr, d, B, c->h, c->dh, T, T, sq->eq, 0, 0, s, w.att_p, w.rows_a, 0, ce,
+                                   c->Lf * 2, w.f_att_rs);
+      }));
+      GemmParams po = linear_params(nullptr, d, L.wo, d, L.bo, x, d, M, d, ACT_NONE);
+      po.Ap = w.att_p; po.a_rows = w.rows_a; po.h2 = 1; po.rscale = w.f_att_rs;
+      po.R = x; po.ldr = d; po.rperiod = 0;
+      (void)so;
+      RCK(run_gemm(c, po, s));
+    } else if (planes_rows(c, w, M)) RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s, w.att_p, w.rows_a));
     else RCK(run_attention_proj(c, w.f_q, d, kk, nkv, kk + d, nkv, w.att, L.wo, L.bo, x, B, T, T, s));
     RCK(run_ln_linear_h2(c, x, L.g2, L.be2, w.ln_p, w.rows_a, L.w1, L.b1, nullptr, w.ffn_p, s1, s2, M, 4 * d, ACT_GELU, s));
     GemmParams p2 = linear_params(nullptr, 4 * d, L.w2, 4 * d, L.b2, x, d, M, d, ACT_NONE);
@@ -1078,6 +1112,7 @@ Workspace shift_rows(const avsep_ctx* c, const Workspace& w, int b0, int T) {
   v.kv_all += rows * (size_t)c->Lf * 2 * d;
   // plane buffers: a row-range view is the same slab layout 32 * row0 elements further on, with the same slab height
   if (v.ln_p) { v.ln_p += rows * 32; v.att_p += rows * 32; v.ffn_p += rows * 32; v.v_up_p += rows * 32; }
+  if (v.f_clip_exp) { v.f_clip_exp += (size_t)b0 * c->Lf * 2; v.f_att_rs += rows; }
   return v;
 }
 
@@ -1305,7 +1340,14 @@ int h2_prepare(avsep_ctx* c, hipStream_t s) {
     for (auto& L : layers) {
       const LnB n1 = ln_bound(L.g1, L.be1), n2 = ln_bound(L.g2, L.be2);
       set(L.wqkv, n1.elem);
-      set(L.wo, proj_bound(L.wqkv, L.bqkv, 2 * d, 3 * d, n1.l2));          // a convex combination of value rows
+      const double bq = proj_bound(L.wqkv, L.bqkv, 0, d, n1.l2), bk = proj_bound(L.wqkv, L.bqkv, d, 2 * d, n1.l2),
+                   bv = proj_bound(L.wqkv, L.bqkv, 2 * d, 3 * d, n1.l2);
+      set(L.wo, bv);                                                        // a convex combination of value rows
+      auto it = c->h2.find(L.wqkv);
+      if (it != c->h2.end()) {                                              // the self-attention's operand bounds (packed q rows carry 1 / sqrt(dh))
+        it->second.eq = h2_exponent(bq); it->second.ek = h2_exponent(bk); it->second.ev = h2_exponent(bv);
+        it->second.qkv = true;
+      }
       set(L.w1, n2.elem);
       set(L.w2, proj_bound(L.w1, L.b1, 0, 4 * d, n2.l2));
     }
@@ -1313,12 +1355,40 @@ int h2_prepare(avsep_ctx* c, hipStream_t s) {
   encoder(c->a_layers, c->ok_audio);
   encoder(c->v_layers, c->ok_visual);
   if (c->ok_fusion) {
-    for (auto& L : c->f_layers) {
+    c->cross_h2 = c->Lf > 0;
+    std::vector<float> kc((size_t)std::max(c->Lf, 1) * 4, 0.0f);
+    const std::vector<float> kvb = c->bkv_all ? host(c->bkv_all, (size_t)c->Lf * 2 * d) : std::vector<float>();
+    auto kvs = c->h2.find(c->wkv_all);
+    const std::vector<float> kvl2 = kvs != c->h2.end() ? host(kvs->second.l2, (size_t)c->Lf * 2 * d) : std::vector<float>();
+    if (kvl2.size() != (size_t)c->Lf * 2 * d || kvb.size() != kvl2.size()) c->cross_h2 = false;
+    for (size_t li = 0; li < c->f_layers.size(); ++li) {
+      auto& L = c->f_layers[li];
       const LnB n1 = ln_bound(L.g1, L.be1), n2 = ln_bound(L.g2, L.be2);
       set(L.wq, n1.elem);
       set(L.w1, n2.elem);
       set(L.w2, proj_bound(L.w1, L.b1, 0, 4 * d, n2.l2));
+      auto it = c->h2.find(L.wq);                                         // the cross-attention's q bound (packed q rows carry 1 / sqrt(dh))
+      if (it != c->h2.end()) {
+        it->second.eq = h2_exponent(proj_bound(L.wq, L.bq, 0, d, n1.l2));
+        it->second.qkv = true;
+        if (it->second.eq < 0) c->cross_h2 = false;
+      } else {
+        c->cross_h2 = false;
+      }
+      if (c->cross_h2)
+        for (int kv = 0; kv < 2; ++kv) {                                  // K rows [li 2d, li 2d + d), V rows behind them
+          double wmax = 0.0, bmax = 0.0;
+          for (int n = 0; n < d; ++n) {
+            const size_t r = li * 2 * d + (size_t)kv * d + n;
+            wmax = std::max(wmax, (double)kvl2[r]);
+            bmax = std::max(bmax, std::fabs((double)kvb[r]));
+          }
+          kc[li * 4 + kv * 2] = (float)(std::sqrt((double)d) * wmax * (1.0 + 1e-6));
+          kc[li * 4 + kv * 2 + 1] = (float)(bmax * (1.0 + 1e-6));
+          if (!std::isfinite(kc[li * 4 + kv * 2]) || !std::isfinite(kc[li * 4 + kv * 2 + 1])) finite = false;
+        }
     }
+    if (c->cross_h2 && c->fkv_const) HCK(hipMemcpy(c->fkv_const, kc.data(), kc.size() * sizeof(float), hipMemcpyHostToDevice));
     if (c->ok_decoder) {
       const LnB nf = ln_bound(c->fn_g, c->fn_b);
       set(c->d_w1, nf.elem);
@@ -2088,6 +2158,16 @@ int avsep_op_attention_split(const float* q, int ldq, const float* k, int ldk, c
   if (!attention_split_supported(dh, Lq, Lk)) return fail(AVSEP_EINVAL, "the split-precision attention needs dh = 64");
   if ((ldq | ldk | ldv | ldo) & 3) return fail(AVSEP_EINVAL, "rows must be 16-byte aligned");
   HCK(launch_attention_split(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, 1.0f, reinterpret_cast<hipStream_t>(stream)));
+  return AVSEP_OK;
+}
+
+int avsep_op_attention_h2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B,
+                          int nhead, int dh, int Lq, int Lk, int eq, int ek, int ev, void* stream) {
+  if (!q || !k || !v || !out) return fail(AVSEP_EINVAL, "null pointer");
+  if (B <= 0 || nhead <= 0 || Lq <= 0 || Lk <= 0) return fail(AVSEP_EINVAL, "bad argument");
+  if (!attention_h2_supported(dh, Lq, Lk, eq, ek, ev)) return fail(AVSEP_EINVAL, "the two-term attention needs dh = 64 and |exponents| <= 60, |eq + ek| <= 60");
+  if ((ldq | ldk | ldv | ldo) & 3) return fail(AVSEP_EINVAL, "rows must be 16-byte aligned");
+  HCK(launch_attention_h2(q, ldq, k, ldk, v, ldv, out, ldo, B, nhead, dh, Lq, Lk, eq, ek, ev, reinterpret_cast<hipStream_t>(stream)));
   return AVSEP_OK;
 }
 

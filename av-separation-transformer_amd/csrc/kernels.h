@@ -189,7 +189,15 @@ bool attention_split_supported(int dh, int Lq, int Lk);
 // h * 64 + c of a buffer with o_rows rows) INSTEAD of fp32 o
 hipError_t launch_attention_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                                   int B, int nhead, int dh, int Lq, int Lk, float qscale, hipStream_t s,
-                                  unsigned short* op = nullptr, long long o_rows = 0, int h2 = 0, int h2_exp = 0);   // h2: two fp16 terms scaled by 2^h2_exp
+                                  unsigned short* op = nullptr, long long o_rows = 0, int h2 = 0, int h2_exp = 0);
+bool attention_h2_supported(int dh, int Lq, int Lk, int eq, int ek, int ev);
+// clip_exp (stride clip_stride ints per clip: {ek, ev}): per-clip exponents of k and v instead of ek / ev; the plane output is then
+// scaled by the clip's 2^ev and rs_out[b Lq + q] = 2^-ev is written for the out-projection (GemmParams::rscale)
+hipError_t launch_attention_h2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B,
+                               int nhead, int dh, int Lq, int Lk, int eq, int ek, int ev, hipStream_t s, unsigned short* op = nullptr,
+                               long long o_rows = 0, int h2_exp = 0, const int* clip_exp = nullptr, int clip_stride = 0,
+                               float* rs_out = nullptr);
+hipError_t launch_clip_exp(const float* rscale, const float* kc, int* out, int B, int T, int Lf, hipStream_t s);   // h2: two fp16 terms scaled by 2^h2_exp
 // weight gradient dW[N][K] = dY^T X from row-major dY [R][ldy], X [R][ldx] (gemm.hip wgrad_kernel)
 int wgrad_slices(int N, int K, int R);
 // with_bias: each slice is N*K + N floats, the last N = column sums of dy (the bias gradient)

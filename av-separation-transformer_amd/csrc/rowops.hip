@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void interp_linear_h2_kernel(const float* __re
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
   // e with mx 2^e in [2^13, 2^14) (0 for a zero row; clamped): the weight rows' rule (gemm_h2.hip h2_row_stats_kernel)
-  int e = 0;
+  int e = mx == 0.0f ? 100 : 0;                                            // a zero row: the smallest bound (it never sets a clip's bound, below)
   if (mx > 0.0f && mx < 3.0e38f) {
     const int ex = (int)((__float_as_uint(mx) >> 23) & 255u) - 126;        // mx < 2^ex
     e = 14 - ex;
@@ -261,6 +261,30 @@ __global__ __launch_bounds__(256) void interp_linear_h2_kernel(const float* __re
       *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
       *reinterpret_cast<u32x4*>(dst + (size_t)rows * 64) = u32x4{l[0], l[1], l[2], l[3]};
     }
+  }
+}
+
+// Per clip and fusion layer: the exponents of the cross-attention's K and V operands (attention_h2_kernel).  Row t of clip b of the
+// resized visual stream satisfies |x| < 2^14 rscale[b T + t] (interp_linear_h2_kernel), so U = 2^14 max_t rscale bounds the clip, and
+// |K| <= U ck + bk, |V| <= U cv + bv with the layer's constants kc[l] = {sqrt(d) max ||w_n||_2, max |b_n|} of its K rows and V rows
+// (avsep_api.hip h2_prepare).  out[(b Lf + l) 2 + {0, 1}] = e with bound 2^e <= 2^14.  A clip's exponents depend on that clip alone.
+__global__ __launch_bounds__(64) void clip_exp_kernel(const float* __restrict__ rscale, const float* __restrict__ kc, int* __restrict__ out,
+                                                      int T, int Lf) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float mx = 0.0f;
+  for (int t = lane; t < T; t += 64) mx = fmaxf(mx, rscale[(size_t)b * T + t]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  const float U = 16384.0f * mx;
+  for (int i = lane; i < 2 * Lf; i += 64) {
+    const float bound = fmaf(U, kc[2 * i], kc[2 * i + 1]) * 1.00001f;
+    int e = 0;
+    if (bound > 0.0f && bound < 3.0e38f) {
+      const int ex = (int)((__float_as_uint(bound) >> 23) & 255u) - 126;   // bound < 2^ex
+      e = 14 - ex;
+      e = e > 60 ? 60 : e < -60 ? -60 : e;
+    }
+    out[(size_t)b * 2 * Lf + i] = e;
   }
 }
 
@@ -435,6 +459,12 @@ hipError_t launch_interp_linear_h2(const float* x, unsigned short* yp, float* rs
   if (d <= 512) hipLaunchKernelGGL(interp_linear_h2_kernel<1>, grid, block, 0, s, x, yp, rscale, rows, B, N, T, d, sc);
   else if (d <= 1024) hipLaunchKernelGGL(interp_linear_h2_kernel<2>, grid, block, 0, s, x, yp, rscale, rows, B, N, T, d, sc);
   else hipLaunchKernelGGL(interp_linear_h2_kernel<4>, grid, block, 0, s, x, yp, rscale, rows, B, N, T, d, sc);
+  return hipGetLastError();
+}
+
+hipError_t launch_clip_exp(const float* rscale, const float* kc, int* out, int B, int T, int Lf, hipStream_t s) {
+  if (B <= 0 || T <= 0 || Lf <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(clip_exp_kernel, dim3((unsigned)B), dim3(64), 0, s, rscale, kc, out, T, Lf);
   return hipGetLastError();
 }
 

@@ -43,10 +43,10 @@ HBM_PEAK_GBS = 8000.0
 
 def kernel_pipe(name):
     """(pipe, matrix products executed per algorithmic fp32 product, peak TFLOP/s) of a kernel instance, by its name as
-    rocprofv3 prints it.  The two-term fp16 GEMM (csrc/gemm_h2.hip) executes THREE fp16 MFMA products per fp32 product, the
+    rocprofv3 prints it.  The two-term fp16 GEMM and attention (csrc/gemm_h2.hip, attention_h2_kernel) execute THREE fp16 MFMA products per fp32 product, the
     three-term bf16 kernels (gemm_split.hip, gemm_planes.hip, attention_split.hip, wgrad_split.hip) SIX bf16 ones -- both on
     the 16-bit matrix pipe (2.5 PFLOP/s dense) --, every other matrix kernel one fp32 MFMA; None: no matrix work (HBM-bound)."""
-    if name.startswith("gemm_h2"):
+    if name.startswith(("gemm_h2", "attention_h2")):
         return ("fp16 MFMA, 3 products per fp32 product", 3, BF16_MATRIX_PEAK_TFLOPS)
     if name.startswith(("gemm_split", "gemm_planes", "attention_split", "wgrad_split")):
         return ("bf16 MFMA, 6 products per fp32 product", 6, BF16_MATRIX_PEAK_TFLOPS)

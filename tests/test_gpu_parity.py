@@ -1331,6 +1331,55 @@ def test_op_attention_split_precision(lib, dev, B, h, Lq, Lk):
                                         _stream()) == -1        # dh != 64
 
 
+@pytest.mark.parametrize("B,h,Lq,Lk", [(2, 8, 251, 251), (1, 4, 501, 501), (3, 2, 130, 129), (1, 2, 40, 300), (2, 2, 129, 128),
+                                       (1, 3, 1, 33), (2, 2, 33, 1), (1, 2, 64, 31), (1, 1, 300, 47)])
+@pytest.mark.parametrize("slack", [0, 9])
+def test_op_attention_h2_precision(lib, dev, B, h, Lq, Lk, slack):
+    """The two-term fp16 attention (attention_h2_kernel; what the forward runs for the self-attention of d_model >= 512 models at 128
+    keys or more): three fp16 MFMA products per fp32 product with caller-stated bounds on q, k, v.  Against float64: inside the fp32
+    kernel's bound and at most 2x the fp32-MFMA kernel's measured error + 2e-7 on the same operands -- with the exponents at the
+    operands' true maxima (slack 0) AND with bounds 2^9 too loose (the forward's bounds are worst cases, not measurements); ragged last
+    steps, a spiked key (online-softmax rescale) and operands 1e-4 of the bound included; a (clip, head) alone has the bits it has
+    inside the batch."""
+    from av_separation._native import check
+    dh = 64
+    d = h * dh
+    q = seeded.tensor(7, "q", (B, Lq, d), -1, 1)
+    k = seeded.tensor(7, "k", (B, Lk, d), -1.5, 1.5)
+    v = seeded.tensor(7, "v", (B, Lk, d), -2, 2)
+    k[0, Lk // 2] *= 6.0
+    v[0, :, :dh // 2] *= 1e-4                                       # a quiet half of a head next to a loud one
+    ex = lambda a: 14 - math.frexp(float(np.abs(a).max()) * (1 + 1e-6))[1] - slack
+    eq, ek, ev = ex(q), ex(k), ex(v)
+    qd, kd, vd = t(q, dev), t(k, dev), t(v, dev)
+    o0 = torch.full((B, Lq, d), float("nan"), device=dev)
+    o1 = torch.full((B, Lq, d), float("nan"), device=dev)
+    check(lib.avsep_op_attention(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o0.data_ptr(), d, B, h, dh, Lq, Lk, _stream()))
+    check(lib.avsep_op_attention_h2(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o1.data_ptr(), d, B, h, dh, Lq, Lk, eq, ek, ev, _stream()))
+    assert torch.isfinite(o1).all()
+    q64 = q.astype(np.float64).reshape(B, Lq, h, dh).transpose(0, 2, 1, 3)
+    k64 = k.astype(np.float64).reshape(B, Lk, h, dh).transpose(0, 2, 1, 3)
+    v64 = v.astype(np.float64).reshape(B, Lk, h, dh).transpose(0, 2, 1, 3)
+    scores = q64 @ k64.transpose(0, 1, 3, 2)
+    ref = (onp.softmax_last(scores) @ v64).transpose(0, 2, 1, 3).reshape(B, Lq, d)
+    tol = 2e-6 + 6e-8 * float(np.abs(scores).max()) * math.sqrt(dh) * 4.0
+    e0, e1 = maxabs(o0.cpu().numpy(), ref), maxabs(o1.cpu().numpy(), ref)
+    assert e1 < tol, (e0, e1, tol)
+    assert e1 < 2.0 * e0 + 2e-7, (e0, e1)
+    # the quiet columns: the fp32 kernel's error at THEIR size, plus the floor of the format -- an entry more than 17 binades under the
+    # stated bound keeps an absolute error of 2^-39 of that bound per term (its low term is a subnormal fp16)
+    quiet = np.s_[0, :, :dh // 2]
+    assert maxabs(o1.cpu().numpy()[quiet], ref[quiet]) < 1e-4 * (2.0 * e0 + 2e-7) + math.ldexp(1.0, 14 - ev - 36), (slack,)
+    o2 = torch.full((Lq, dh), float("nan"), device=dev)
+    off = ((B - 1) * Lq * d + (h - 1) * dh) * 4
+    offk = ((B - 1) * Lk * d + (h - 1) * dh) * 4
+    check(lib.avsep_op_attention_h2(qd.data_ptr() + off, d, kd.data_ptr() + offk, d, vd.data_ptr() + offk, d, o2.data_ptr(), dh,
+                                    1, 1, dh, Lq, Lk, eq, ek, ev, _stream()))
+    assert torch.equal(o2, o1[B - 1, :, (h - 1) * dh:])
+    assert lib.avsep_op_attention_h2(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o1.data_ptr(), d, B, h, 32, Lq, Lk, eq, ek, ev,
+                                     _stream()) == -1               # dh != 64
+
+
 @pytest.mark.parametrize("B,h,Lq,Lk", [(2, 8, 251, 251), (1, 4, 501, 501), (3, 2, 130, 129), (1, 2, 40, 300)])
 def test_op_attention_lds_variant_is_bit_identical(lib, devlib, dev, B, h, Lq, Lk):
     """Long sequences (dh = 64, Lk >= 128) take K / V through LDS; same arithmetic in the same order as the
