@@ -371,7 +371,7 @@ __device__ __forceinline__ f32x2 exp_neg_pair_scaled(f32x2 x, float hi, float lo
 }
 
 template <int QT>
-__global__ __launch_bounds__(256, 2) void attention_h2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+__global__ __launch_bounds__(256, 3) void attention_h2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                               int ldk, const float* __restrict__ v, int ldv, float* __restrict__ o,
                                                               int ldo, int nhead, int Lq, int Lk, int nqt, float qmul, float kmul,
                                                               float vmul, float sdesc, float odesc, unsigned short* __restrict__ op,

@@ -100,6 +100,37 @@ def test_fuzz_wide_models_against_torch_cpu_port(case):
     assert maxabs(sep.cpu().numpy(), rs.contiguous().numpy()) < 4e-6 * max(1.0, float(np.abs(mixed).max())), (cfg, dm)
 
 
+@pytest.mark.parametrize("scale", [1e-5, 1e-2, 1.0, 3e2, 1e5])
+def test_visual_stream_magnitude_sweep_on_the_two_term_path(scale):
+    """The cross-attention of a d_model >= 512 model runs on two fp16 terms with exponents taken PER CLIP from the magnitude of the
+    resized visual stream (clip_exp_kernel), the self-attention with static bounds of its in-projection.  Nothing normalises the visual
+    residual stream before it is resized, so its magnitude is whatever frame_proj makes it: swept here over ten decades (one clip of
+    the batch a further 1000x louder than the others).  Outputs stay finite and as close to the float64 oracle as the fp32 oracle is
+    (2x its error + MASK_TOL), and the loud clip alone has the bits it has inside the batch."""
+    dev = torch.device("cuda:0")
+    cfg = dict(freq_bins=129, d_model=512, nhead=8, num_encoder_layers=1, num_fusion_layers=2, num_speakers=2)
+    B, T, N, H, W = 3, 200, 9, 16, 16
+    m = _model(dev, cfg, 77).eval()
+    with torch.no_grad():
+        m.visual_encoder.frame_proj.weight.mul_(scale)
+        m.visual_encoder.frame_proj.bias.mul_(scale)
+    mixed, lips = seeded.inputs(4242, B, cfg["freq_bins"], T, N, H, W)
+    lips[1] *= 1000.0
+    x, l = torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev)
+    with torch.no_grad():
+        sep, masks = m(x, l)
+        s1, m1 = m(x[1:2], l[1:2])
+    assert torch.isfinite(masks).all() and torch.isfinite(sep).all()
+    assert torch.equal(m1, masks[1:2]) and torch.equal(s1, sep[1:2])
+    state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    _, r32 = torch_cpu.forward(state, torch.from_numpy(mixed), torch.from_numpy(lips), cfg["nhead"], cfg["num_speakers"])
+    s64 = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
+    _, r64 = torch_cpu.forward(s64, torch.from_numpy(mixed).double(), torch.from_numpy(lips).double(), cfg["nhead"], cfg["num_speakers"])
+    e32 = maxabs(r32.contiguous().numpy().astype(np.float64), r64.contiguous().numpy())
+    e = maxabs(masks.cpu().numpy().astype(np.float64), r64.contiguous().numpy())
+    assert e < 2.0 * e32 + 4e-6, (scale, e, e32)
+
+
 @pytest.mark.parametrize("case", range(int(os.environ.get("AVSEP_FUZZ_TRAIN", "10"))))
 def test_fuzz_training_gradients_against_torch_cpu_port(case):
     from av_separation.losses import SeparationLoss
