@@ -39,8 +39,9 @@ def test_linear_fn_forward_backward(dev, M, N, K, act, res):
     x2, w2, b2 = (t.detach().clone().requires_grad_() for t in (x, w, b))
     r2 = r.detach().clone().requires_grad_() if res else None
     y2 = F.linear(x2, w2, b2)
-    if act:
-        y2 = torch.relu(y2)
+    if act:     # the ReLU decisions of the op under test (a pre-activation within rounding of 0 may fall on either side in two correct
+        y2 = y2 * (y.detach() > 0)   # GEMMs -- the split-precision forward GEMM is the default); the VALUES are compared below
+        assert float((torch.relu(F.linear(x2, w2, b2)).detach() - y.detach()).abs().max()) < 2e-5 * float(y.detach().abs().max())
     if res:
         y2 = y2 + r2
     y2.backward(dy)
