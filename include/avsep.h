@@ -233,9 +233,12 @@ int avsep_op_attention_split(const float* q, int ldq, const float* k, int ldk, c
 /* The same function on TWO fp16 terms per operand and three fp16 MFMA products per fp32 product (csrc/attention_split.hip,
  * attention_h2_kernel; the scheme of avsep_op_linear_h2): the caller states a bound on its operands as powers of two -- every |q| 2^eq,
  * |k| 2^ek, |v| 2^ev it can produce is below 2^14 (larger values saturate to +-inf: a bound, not a measurement) -- the probabilities
- * are in [0, 1] by construction.  22 significant bits for every operand entry within 17 binades of its bound.  The forward runs it for
- * the self-attention of d_model >= 512 models at 128 keys or more, with the bounds avsep_finalize_weights derives from the
- * in-projection behind its LayerNorm (nn.MultiheadAttention, /root/reference/src/av_separation/model.py:46-60). */
+ * are in [0, 1] by construction.  22 significant bits for every operand entry within 17 binades of its bound, an absolute error of
+ * 2^-39 of the bound below that.  The forward runs it for the attention of d_model >= 512 models at 128 keys or more: self-attention
+ * with the bounds avsep_finalize_weights derives from the in-projection behind its LayerNorm; cross-attention with the q bound of its
+ * q-projection and k / v bounds PER CLIP, computed on the device in every forward from the row scales of the resized visual stream
+ * (its magnitude is data, not weights) -- a clip's exponents depend on that clip alone, so a clip has the same bits alone and inside
+ * any batch (nn.MultiheadAttention, /root/reference/src/av_separation/model.py:46-60,159-172). */
 int avsep_op_attention_h2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B,
                           int nhead, int dh, int Lq, int Lk, int eq, int ek, int ev, void* stream);
 #ifdef AVSEP_DEV

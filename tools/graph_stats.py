@@ -20,7 +20,8 @@ for r in csv.DictReader(open(path)):
     if "anonymous" not in r["Name"]:
         continue
     n = norm(r["Name"])
-    if n.startswith(("pack_", "scale_copy", "pe_fill", "void at::", "at::")):   # weight packing / ATen checks: not part of a replayed step
+    if n.startswith(("pack_", "scale_copy", "pe_fill", "void at::", "at::", "split_h2_kernel", "split_planes_kernel", "h2_row_stats_kernel")):
+        # weight packing / weight planes / ATen checks: not part of a replayed step
         continue
     ks[n] = {"calls_per_step": int(r["Calls"]) / replays, "avg_us": float(r["AverageNs"]) / 1e3,
              "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
