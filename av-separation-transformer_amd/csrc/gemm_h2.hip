@@ -822,7 +822,7 @@ static int h2_variant(const GemmParams& p) {
 }
 
 const char* gemm_h2_instance_name(const GemmParams& p) {
-  return h2_variant(p) == 128 ? "gemm_h2_kernel<128>" : "gemm_h2_small_kernel";
+  return h2_variant(p) == 128 ? "gemm_h2_kernel<128, 0>" : "gemm_h2_small_kernel";
 }
 
 template <int BN, int V = 0>
