@@ -313,6 +313,11 @@ hipError_t chain_build(ChainBuilder* b, int xcd_local, int order_group, float or
   const int B = M / L;
   for (auto& h : b->ops)
     if (h.rows_per_clip != L || h.op.M != M) return hipErrorInvalidValue;      // one sequence geometry per chain
+  if (xcd_local) {   // one queue per XCD, chosen by HW_REG_XCC_ID & 7: only on a device that exposes eight of them (CPX / DPX
+    int dev = 0, xccs = 0;   // partitions or other parts would leave queues whose tickets nobody draws)
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || xccs != 8)
+      return hipErrorNotSupported;
+  }
   const int G = xcd_local ? (B + 7) / 8 : B;                                    // clips per group
   const int NG = (B + G - 1) / G;
   const int tpg = (G * L + 31) / 32;                                            // row tiles per group

@@ -229,8 +229,8 @@ double chain_plan_flops(const ChainPlanImpl* p);
 double chain_plan_bytes(const ChainPlanImpl* p);
 int chain_plan_items(const ChainPlanImpl* p);
 hipError_t launch_chain(const ChainPlanImpl* p, hipStream_t s);                       // memset of the counters + ONE kernel
-hipError_t chain_plan_error(const ChainPlanImpl* p, hipStream_t s, unsigned* word);
-hipError_t chain_plan_peek(const ChainPlanImpl* p, hipStream_t s, unsigned* out, int n);   // developer aid   // 0 = no wait timed out (synchronises s)
+hipError_t chain_plan_error(const ChainPlanImpl* p, hipStream_t s, unsigned* word);    // word 0 = no wait timed out (synchronises s)
+hipError_t chain_plan_peek(const ChainPlanImpl* p, hipStream_t s, unsigned* out, int n);   // developer aid
 
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, int d, float eps,
                             hipStream_t s);

@@ -457,6 +457,8 @@ def main():
             raise SystemExit("an in-flight slot does not reproduce slot 0's outputs: refusing to time it")
         nrounds = max(1, a.rounds)
         worst, mine = timed_rounds(dist, dev, nrounds, lambda: run_steps(a.steps, R))     # each round: EXACTLY K steps
+        if a.schedule:      # a chained launch that gave up waiting for a producer tile returns stale activations with AVSEP_OK: ask
+            model.chain_status()
         elapsed = median(worst)
         # the same K steps strictly one after the other on one stream (the latency view; the figure to compare rounds by)
         single = single_rounds = None

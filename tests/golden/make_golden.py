@@ -302,13 +302,14 @@ def make_trained_d512(outdir):
     BASELINE config 3's shapes (nhead 8, 2 s @ 16 kHz: T = 251, 50 lip frames 32 x 32, 2 speakers) with 1 + 1 layers -- one audio
     encoder layer, one visual encoder layer, one fusion layer, the decoder: every kind of GEMM site of the path once, 10.8 M
     parameters --, after the reference's OWN `quick_train` (/root/reference/demo.py:83-113 called as it is: DataLoader(batch 8,
-    shuffle), Adam, clip 1.0, SeparationLoss(0.5), train mode, dropout 0.1) for 60 steps.  Matrices on the bfloat16 grid AFTER
-    training like trained_cfg1 (the reference produced the stored outputs with exactly those weights; vectors -- biases, LayerNorm /
-    BatchNorm parameters and statistics -- full float32).  Stored: weights, SyntheticAVDataset items 0, 1 as inputs, full
+    shuffle), Adam, clip 1.0, SeparationLoss(0.5), train mode, dropout 0.1) for 60 steps.  Matrices: the trained values' upper 16 bits
+    (round to nearest even) are stored, their low 16 bits replaced by a seeded stream that the tests rebuild -- full 24-bit weights at 2
+    bytes each, changed by < 2^-8 relative (the reference produced the stored outputs with exactly those weights; vectors -- biases,
+    LayerNorm / BatchNorm parameters and statistics -- full float32).  Stored: weights, SyntheticAVDataset items 0, 1 as inputs, full
     (separated, masks) in float32 and from the float64 copy, every stage tap as strided slices + float64 checksums, the losses."""
     sys.path.insert(0, "/root/reference")
     import demo as refdemo
-    c = dict(F=257, d=512, h=8, Le=1, Lf=1, S=2, seed=43, full=False)
+    c = dict(F=257, d=512, h=8, Le=1, Lf=1, S=2, seed=43, full=False, lowbits=20251005)
     dkw = dict(sample_rate=16000, duration=2.0, num_frames=25, frame_h=32, frame_w=32, speaker_freqs=(220.0, 440.0))
     torch.manual_seed(8765)
     mk = dict(freq_bins=c["F"], d_model=c["d"], nhead=c["h"], num_encoder_layers=c["Le"], num_fusion_layers=c["Lf"],
@@ -327,7 +328,11 @@ def make_trained_d512(outdir):
             u = a.view(np.uint32).astype(np.uint64)
             u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)          # round to nearest even, keep 16 bits
             out["wh." + k] = u
-            sd[k] = torch.from_numpy((u.astype(np.uint32) << 16).view(np.float32).reshape(a.shape).copy())
+            # ... and fill the low 16 bits of every word from a seeded stream (tests/helpers.py::low_bits rebuilds them): the model the
+            # reference runs below has full 24-bit weights, so no split term of W is identically zero; 2 bytes per weight stored
+            sys.path.insert(0, os.path.join(ROOT, "tests")); from helpers import low_bits
+            w32 = (u.astype(np.uint32) << 16) | low_bits(k, a.shape, c["lowbits"])
+            sd[k] = torch.from_numpy(w32.view(np.float32).reshape(a.shape).copy())
         else:
             out["w." + k] = a.copy()
     mq = ref.AVSeparationTransformer(**mk)

@@ -581,7 +581,8 @@ def test_op_ln_linear_forms_agree(lib, devlib, dev, M, N, K, act):
         os.environ.pop("AVSEP_GEMM_TILE", None)
     rc, p0 = run(0, lib)
     assert rc == 0 and torch.equal(p0, run(0))
-    assert run(2, lib)[0] == -1 and b"developer" in lib.avsep_last_error()
+    if os.environ.get("AVSEP_LIB") != "dev":            # (under AVSEP_LIB=dev `lib` IS the developer library, which has form 2)
+        assert run(2, lib)[0] == -1 and b"developer" in lib.avsep_last_error()
     if K <= 256:
         y1 = run(1)
         assert (y1.double().cpu() - ref).abs().max().item() < 2e-5
@@ -803,7 +804,7 @@ def test_mask_head_epilogue_bit_identical_to_block_by_block(devlib, dev, M, S, F
 @pytest.mark.parametrize("M,N,K,act,res", [(16064, 512, 512, 0, True), (3200, 1536, 512, 1, False), (4016, 512, 2048, 2, True),
                                            (251, 2048, 512, 1, False), (777, 260, 96, 3, True), (129, 516, 544, 0, False),
                                            (1, 512, 512, 2, True),
-                                           # the 256 x 128 kernel (>= 192 tiles of that size): ragged M and N, odd chunk count, one chunk
+                                           # the 256 x 128 kernel (from 128 tiles of that size on in the stand-alone op, 48 in the forward): ragged M and N, odd chunk count, one chunk
                                            (12300, 644, 544, 2, True), (16032, 2048, 512, 1, False), (49200, 132, 32, 0, False),
                                            (24600, 260, 64, 3, True)])
 def test_op_linear_split_precision(lib, dev, M, N, K, act, res):
