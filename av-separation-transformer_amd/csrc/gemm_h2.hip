@@ -649,11 +649,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_mid_kernel(const GemmParams pi
 // L2 round trip PER CHUNK (issue -> wait -> barrier with 12 MFMAs in between: 9 us for 251 x 1536 x 512); now three chunks' fetches
 // are in flight behind the one being multiplied (a four-slot ring -- two workgroups per CU -- was slower on the mid-size problems).  Counted s_waitcnt vmcnt (four DMA instructions per wave and chunk) and a RAW
 // s_barrier: __syncthreads() would drain the DMA queue (cdna_hip_programming.md, Pipelining across barriers).
-__global__ __launch_bounds__(256, 3) void gemm_h2_small_kernel(const GemmParams pin) {
+// KC = 2: two K chunks per ring slot and barrier (same products in the same order: the same bits) -- for problems of so few tiles that a
+// workgroup's life is its chunk loop (one clip of cfg3: the FFN's second layer is 32 workgroups x 64 chunks); 96 KB of LDS, one
+// workgroup per CU, which such a grid does not fill anyway
+template <int KC>
+__global__ __launch_bounds__(256, KC == 1 ? 3 : 1) void gemm_h2_small_kernel(const GemmParams pin) {
   GemmParams p = pin;
-  constexpr int B = 64, PL = B * 64, BUF = 4 * PL;                         // 16 KB per slot: [A hi|lo][W hi|lo]
-  constexpr int NST = 3;
-  __shared__ __attribute__((aligned(1024))) char lds[NST * BUF];
+  constexpr int B = 64, PL = B * 64, BUF1 = 4 * PL, BUF = KC * BUF1;       // 16 KB per chunk: [A hi|lo][W hi|lo]
+  extern __shared__ __attribute__((aligned(1024))) char lds[];            // a ring of three slots: 3 * BUF
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -667,14 +670,18 @@ __global__ __launch_bounds__(256, 3) void gemm_h2_small_kernel(const GemmParams 
   const unsigned a_off = (unsigned)min(m0 + 16 * wave + lr, p.M - 1) * 64u + lslot;
   const unsigned w_off = (unsigned)min(n0 + 16 * wave + lr, p.N - 1) * 64u + lslot;
   const size_t a_ts = (size_t)p.a_rows * 64, w_ts = (size_t)p.w_rows * 64;
-  auto issue = [&](int kc, int buf) {
-    char* lb = lds + buf * BUF + wave * 1024;
-    const char* as = reinterpret_cast<const char*>(p.Ap) + (size_t)kc * 2 * a_ts + a_off;
-    const char* ws = reinterpret_cast<const char*>(p.Wp) + (size_t)kc * 2 * w_ts + w_off;
-    __builtin_amdgcn_global_load_lds((gptr_t)as, (lptr_t)lb, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(as + a_ts), (lptr_t)(lb + PL), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)ws, (lptr_t)(lb + 2 * PL), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(ws + w_ts), (lptr_t)(lb + 3 * PL), 16, 0, 0);
+  auto issue = [&](int ks, int buf) {                                       // step ks = chunks KC ks .. KC ks + KC - 1
+#pragma unroll
+    for (int u = 0; u < KC; ++u) {
+      const int kc = KC * ks + u;
+      char* lb = lds + buf * BUF + u * BUF1 + wave * 1024;
+      const char* as = reinterpret_cast<const char*>(p.Ap) + (size_t)kc * 2 * a_ts + a_off;
+      const char* ws = reinterpret_cast<const char*>(p.Wp) + (size_t)kc * 2 * w_ts + w_off;
+      __builtin_amdgcn_global_load_lds((gptr_t)as, (lptr_t)lb, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(as + a_ts), (lptr_t)(lb + PL), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ws, (lptr_t)(lb + 2 * PL), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws + w_ts), (lptr_t)(lb + 3 * PL), 16, 0, 0);
+    }
   };
   const int fr = lane & 15, fq = lane >> 4;
   int a_fo[2], w_fo[2];
@@ -690,33 +697,41 @@ __global__ __launch_bounds__(256, 3) void gemm_h2_small_kernel(const GemmParams 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nk = p.K >> 5;
+  const int nk = (p.K >> 5) / KC;                                          // steps (the launcher: K % (32 KC) == 0)
   issue(0, 0);
   if (nk > 1) issue(1, 1);
-  int slot = 0;                                                            // kc % 3
+  int slot = 0;                                                            // ks % 3
   for (int kc = 0; kc < nk; ++kc) {
-    // chunk kc has landed once at most the DMA of the chunk behind it is outstanding (block-uniform choice of the literal)
-    if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this wave's fragment reads of chunk kc - 1 are home
-    __builtin_amdgcn_s_barrier();                                         // every wave's share of chunk kc is in LDS; slot (kc - 1) % 3 is free
-    if (kc + 2 < nk) issue(kc + 2, slot == 0 ? 2 : slot - 1);
-    const char* rb = lds + slot * BUF;
-    slot = slot == 2 ? 0 : slot + 1;
-    f16x8 a_hi[2], a_lo[2], w_hi[2], w_lo[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a_hi[i] = *reinterpret_cast<const f16x8*>(rb + a_fo[i]);
-      a_lo[i] = *reinterpret_cast<const f16x8*>(rb + PL + a_fo[i]);
-      w_hi[i] = *reinterpret_cast<const f16x8*>(rb + w_fo[i]);
-      w_lo[i] = *reinterpret_cast<const f16x8*>(rb + PL + w_fo[i]);
+    // step kc has landed once at most the DMA of the step behind it is outstanding (block-uniform choice of the literal)
+    if (kc + 1 < nk) {
+      if constexpr (KC == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this wave's fragment reads of step kc - 1 are home
+    __builtin_amdgcn_s_barrier();                                         // every wave's share of step kc is in LDS; slot (kc - 1) % 3 is free
+    if (kc + 2 < nk) issue(kc + 2, slot == 0 ? 2 : slot - 1);
+    const char* rb0 = lds + slot * BUF;
+    slot = slot == 2 ? 0 : slot + 1;
 #define H2S_MMA(fwp, fap)                                                                     \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwp[j], fap[i], acc[i][j], 0, 0, 0);
-    H2S_MMA(w_lo, a_hi) /* (hi, lo) */
-    H2S_MMA(w_hi, a_lo) /* (lo, hi) */
-    H2S_MMA(w_hi, a_hi) /* (hi, hi) */
+#pragma unroll
+    for (int u = 0; u < KC; ++u) {
+      const char* rb = rb0 + u * BUF1;
+      f16x8 a_hi[2], a_lo[2], w_hi[2], w_lo[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a_hi[i] = *reinterpret_cast<const f16x8*>(rb + a_fo[i]);
+        a_lo[i] = *reinterpret_cast<const f16x8*>(rb + PL + a_fo[i]);
+        w_hi[i] = *reinterpret_cast<const f16x8*>(rb + w_fo[i]);
+        w_lo[i] = *reinterpret_cast<const f16x8*>(rb + PL + w_fo[i]);
+      }
+      H2S_MMA(w_lo, a_hi) /* (hi, lo) */
+      H2S_MMA(w_hi, a_lo) /* (lo, hi) */
+      H2S_MMA(w_hi, a_hi) /* (hi, hi) */
+    }
 #undef H2S_MMA
   }
   // epilogue on the 32 x 32 wave tile: a 4 x 2 accumulator view padded with the two row blocks this wave does not own is not worth
@@ -822,7 +837,9 @@ static int h2_variant(const GemmParams& p) {
 }
 
 const char* gemm_h2_instance_name(const GemmParams& p) {
-  return h2_variant(p) == 128 ? "gemm_h2_kernel<128, 0>" : "gemm_h2_small_kernel";
+  if (h2_variant(p) == 128) return "gemm_h2_kernel<128, 0>";
+  const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  return (tiles <= 256 && !(p.K & 63) && p.K >= 256) ? "gemm_h2_small_kernel<2>" : "gemm_h2_small_kernel<1>";
 }
 
 template <int BN, int V = 0>
@@ -894,6 +911,24 @@ hipError_t launch_gemm_h2(GemmParams p, hipStream_t s) {
     return launch_h2_big<128>(p, s);
   }
   const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-  hipLaunchKernelGGL(gemm_h2_small_kernel, dim3((unsigned)tiles), dim3(256), 0, s, p);
+  // two chunks per barrier where the grid cannot fill the chip anyway (<= one 64 x 64 tile per CU) and the chunk loop is long
+  // enough to matter: the same bits, so the choice may look at the row count
+  bool kc2 = tiles <= 256 && !(p.K & 63) && p.K >= 256;
+#ifdef AVSEP_DEV
+  if (const char* e = getenv("AVSEP_H2_SMALL_KC")) kc2 = atoi(e) == 2 && !(p.K & 63);             // developer A/B
+#endif
+  if (kc2) {
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!raised[dev]) {                                                    // the dynamic-LDS ceiling, once per device
+      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_small_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 16384);
+      if (attr != hipSuccess) return attr;
+      raised[dev] = true;
+    }
+    hipLaunchKernelGGL(gemm_h2_small_kernel<2>, dim3((unsigned)tiles), dim3(256), 3 * 2 * 16384, s, p);
+  } else {
+    hipLaunchKernelGGL(gemm_h2_small_kernel<1>, dim3((unsigned)tiles), dim3(256), 3 * 16384, s, p);
+  }
   return hipGetLastError();
 }
