@@ -653,18 +653,6 @@ int run_ln_linear_h2(avsep_ctx* c, const float* x, const float* g, const float* 
                      const float* W, const float* bias, float* y, unsigned short* yp, const avsep_ctx::H2Site* site,
                      const avsep_ctx::H2Site* next, int M, int N, int act, hipStream_t s) {
   const int d = c->d;
-  {   // a grid of at most one tile per CU (a few clips): LayerNorm inside the GEMM's launch -- the same bits, one launch less
-    static const bool no_fuse = dev_env("AVSEP_NO_H2_LN_FUSE") != nullptr;                           // developer A/B
-    GemmParams pf = linear_params(x, d, W, d, bias, y, N, M, N, act);
-    pf.ln_gamma = g; pf.ln_beta = be; pf.ln_eps = 1e-5f; pf.ln_pscale = std::ldexp(1.0f, site->eA);
-    pf.Wp = site->wp; pf.w_rows = N; pf.cscale = site->cscale; pf.h2 = 1;
-    if (yp) { pf.C = nullptr; pf.Cp = yp; pf.c_rows = rows; pf.cp_scale = std::ldexp(1.0f, next->eA); }
-    if (!no_fuse && c->use_h2 && gemm_h2_ln_supported(pf)) {
-      const double flops = 2.0 * M * (double)N * d + 8.0 * M * d;
-      const double bytes = 4.0 * M * d + 4.0 * (double)N * d + 4.0 * M * (double)N;
-      return profiled(c, "gemm_h2_ln_kernel", flops, bytes, s, [&] { return launch_gemm_h2_ln(pf, s); });
-    }
-  }
   RCK(run_layernorm_h2(c, x, g, be, ln_p, rows, M, d, site->eA, s));
   GemmParams p = linear_params(nullptr, d, W, d, bias, y, N, M, N, act);
   p.Ap = ln_p; p.a_rows = rows; p.h2 = 1;

@@ -822,191 +822,6 @@ bool gemm_h2_supported(const GemmParams& p) {
          p.alt.M <= 0 && !p.epi_general;
 }
 
-// ---- LayerNorm + GEMM in one launch, for grids of at most one workgroup per CU ------------------------------------------------------
-// One clip of cfg3 is 127 launches of 3-20 us; 42 of them are the LayerNorms in front of a Linear.  Here a workgroup normalises the 32
-// rows of its tile itself -- a wavefront per row with layernorm_kernel's arithmetic in layernorm_kernel's order, the two fp16 terms
-// written straight into a resident LDS image of the whole K extent (the fragment reads' swizzle applied to the destination) -- and
-// then walks K with only W coming through the DMA ring: the planes it multiplies are, bit for bit, the ones launch_layernorm_h2
-// would have left in memory, and the products are gemm_h2_small_kernel's in the same order, so the result is the two launches' bit
-// for bit.  Every column tile repeats the LayerNorm of its rows (N / 64 times): nothing at these sizes, which is why the launcher
-// takes this form only when the grid has at most one workgroup per CU.  32 x 64 tile, 4 waves of 16 x 32.
-namespace {
-__device__ __forceinline__ float h2ln_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-template <int VEC>
-__global__ __launch_bounds__(256, 1) void gemm_h2_ln_kernel(const GemmParams pin) {
-  GemmParams p = pin;
-  constexpr int BMR = 32, BNC = 64, WPL = BNC * 64, WBUF = 2 * WPL;        // W: 8 KB per chunk [hi|lo]
-  extern __shared__ __attribute__((aligned(1024))) char lds[];            // [A image: (K/32) x 2 x 32 rows x 64 B][W ring: 3 x 8 KB]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nbn = (p.N + BNC - 1) / BNC;
-  const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
-  const int m0 = bm * BMR, n0 = bn * BNC;
-  const int nk = p.K >> 5, d = p.K;
-  char* wring = lds + (size_t)nk * 2 * BMR * 64;
-  // W DMA: 8 pieces of 1 KiB per chunk (4 row blocks x 2 terms), two per wave
-  const int lr = lane >> 2;
-  const int lslot = ((lane & 3) ^ ((0 - (lane >> 4)) & 3)) << 4;
-  const unsigned w_off = (unsigned)min(n0 + 16 * wave + lr, p.N - 1) * 64u + lslot;
-  const size_t w_ts = (size_t)p.w_rows * 64;
-  auto issue = [&](int kc, int buf) {
-    char* lb = wring + buf * WBUF + wave * 1024;
-    const char* ws = reinterpret_cast<const char*>(p.Wp) + (size_t)kc * 2 * w_ts + w_off;
-    __builtin_amdgcn_global_load_lds((gptr_t)ws, (lptr_t)lb, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(ws + w_ts), (lptr_t)(lb + WPL), 16, 0, 0);
-  };
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  // ---- LayerNorm of the tile's 32 rows: wave w takes rows 8 w .. 8 w + 7, all loads first (layernorm_kernel<VEC, false, 2>'s arithmetic)
-  {
-    f32x4 v[8][VEC];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float* xr = p.A + (size_t)min(m0 + 8 * wave + r, p.M - 1) * p.lda;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const int col = (lane + 64 * i) * 4;
-        v[r][i] = col < d ? *reinterpret_cast<const f32x4*>(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      float s = 0.0f;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
-      const float mean = h2ln_wave_sum(s) / (float)d;
-      float sq = 0.0f;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const int col = (lane + 64 * i) * 4;
-        if (col < d) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float c = v[r][i][e] - mean;
-            sq += c * c;
-          }
-        }
-      }
-      const float var = h2ln_wave_sum(sq) / (float)d;
-      const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-      const int row = 8 * wave + r;                                        // row inside the tile
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const int col = (lane + 64 * i) * 4;
-        if (col < d) {
-          const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.ln_gamma + col);
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.ln_beta + col);
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mean) * rstd * g4[e] + b4[e];
-          unsigned h[2], l[2];
-          split_pair_h2(f32x2{o[0], o[1]} * p.ln_pscale, h[0], l[0]);
-          split_pair_h2(f32x2{o[2], o[3]} * p.ln_pscale, h[1], l[1]);
-          const int ob = (col & 31) * 2;                                    // byte offset inside the row's 64-byte chunk line
-          char* dst = lds + ((size_t)(col >> 5) * 2) * (BMR * 64) + row * 64 + ((((ob >> 4) ^ ((0 - (row >> 2)) & 3))) << 4) + (ob & 15);
-          *reinterpret_cast<u32x2*>(dst) = u32x2{h[0], h[1]};
-          *reinterpret_cast<u32x2*>(dst + BMR * 64) = u32x2{l[0], l[1]};
-        }
-      }
-    }
-  }
-  const int fr = lane & 15, fq = lane >> 4;
-  int a_fo, w_fo[2];
-  {
-    const int r = wm * 16 + fr;
-    a_fo = r * 64 + ((fq ^ ((0 - (r >> 2)) & 3)) << 4);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = wn * 32 + 16 * j + fr;
-      w_fo[j] = c * 64 + ((fq ^ ((0 - (c >> 2)) & 3)) << 4);
-    }
-  }
-  f32x4 acc[1][2];
-  acc[0][0] = acc[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int slot = 0;
-  for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // fragment reads of chunk kc - 1 (and, at kc = 0, the LayerNorm's LDS writes)
-    __builtin_amdgcn_s_barrier();
-    if (kc + 2 < nk) issue(kc + 2, slot == 0 ? 2 : slot - 1);
-    const char* ab = lds + (size_t)kc * 2 * (BMR * 64);
-    const char* wb = wring + slot * WBUF;
-    slot = slot == 2 ? 0 : slot + 1;
-    const f16x8 a_hi = *reinterpret_cast<const f16x8*>(ab + a_fo), a_lo = *reinterpret_cast<const f16x8*>(ab + BMR * 64 + a_fo);
-    f16x8 w_hi[2], w_lo[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      w_hi[j] = *reinterpret_cast<const f16x8*>(wb + w_fo[j]);
-      w_lo[j] = *reinterpret_cast<const f16x8*>(wb + WPL + w_fo[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[j], a_hi, acc[0][j], 0, 0, 0);   /* (hi, lo) */
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[j], a_lo, acc[0][j], 0, 0, 0);   /* (lo, hi) */
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[j], a_hi, acc[0][j], 0, 0, 0);   /* (hi, hi) */
-  }
-  if (p.Cp) {                                                              // the body of gemm_h2_small_kernel's plane epilogue for one row block
-    const bool has_b = p.bias != nullptr;
-    const float* bsrc = has_b ? p.bias : p.cscale;
-    const int pslot = ((fq & 1) << 1) | (fq >> 1);
-    const size_t ts = (size_t)p.c_rows * 64;
-    const int n32 = n0 + wn * 32;
-    const int c0 = min(n32 + 4 * fq, p.N - 4), c1 = min(n32 + 16 + 4 * fq, p.N - 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bsrc + c0), b1 = *reinterpret_cast<const f32x4*>(bsrc + c1);
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.cscale + c0), s1 = *reinterpret_cast<const f32x4*>(p.cscale + c1);
-    const int m = m0 + wm * 16 + fr;
-    f32x4 x0, x1;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      x0[e] = acc[0][0][e] * s0[e];
-      x1[e] = acc[0][1][e] * s1[e];
-      if (has_b) { x0[e] += b0[e]; x1[e] += b1[e]; }
-      x0[e] = apply_act(x0[e], p.act);
-      x1[e] = apply_act(x1[e], p.act);
-    }
-    float lo4[4], hi4[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0[e] * p.cp_scale), __float_as_uint(x1[e] * p.cp_scale), false, false);
-      lo4[e] = __uint_as_float(r[0]);
-      hi4[e] = __uint_as_float(r[1]);
-    }
-    unsigned h[4], l[4];
-    split_pair_h2(f32x2{lo4[0], lo4[1]}, h[0], l[0]);
-    split_pair_h2(f32x2{lo4[2], lo4[3]}, h[1], l[1]);
-    split_pair_h2(f32x2{hi4[0], hi4[1]}, h[2], l[2]);
-    split_pair_h2(f32x2{hi4[2], hi4[3]}, h[3], l[3]);
-    if (m < p.M && n32 < p.N) {
-      char* dst = reinterpret_cast<char*>(p.Cp) + (((size_t)(n32 >> 5) * 2) * p.c_rows + m) * 64 + pslot * 16;
-      *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
-      *reinterpret_cast<u32x4*>(dst + ts) = u32x4{l[0], l[1], l[2], l[3]};
-    }
-  }
-  if (p.C) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 32 + 16 * j + 4 * fq;
-      f32x4 sc;
-      if (!(p.N & 3)) {
-        sc = *reinterpret_cast<const f32x4*>(p.cscale + min(n, p.N - 4));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sc[e] = p.cscale[min(n + e, p.N - 1)];
-      }
-      acc[0][j] *= sc;
-    }
-    gemm_epilogue<1, 2>(p, acc, m0, n0, wm * 16, wn * 32, fr, fq);
-  }
-}
-}  // namespace
-
 // Which kernel: the 256 x 128 tile from half a round of its tiles on (the rule of the bf16 kernels, split_t2_min); below, the
 // 64 x 64 kernel.  Both compute the same bits.  (A 256 x 256 tile -- half the operand traffic per flop -- does not fit eight waves:
 // 128 accumulator + 96 fragment registers per lane, hipcc spills the accumulators inside the loop; the template keeps the
@@ -1116,37 +931,4 @@ hipError_t launch_gemm_h2(GemmParams p, hipStream_t s) {
     hipLaunchKernelGGL(gemm_h2_small_kernel<1>, dim3((unsigned)tiles), dim3(256), 3 * 16384, s, p);
   }
   return hipGetLastError();
-}
-
-// The fused form's rule (host): a LayerNorm site (K = d_model, one exponent), fp32 rows, a grid of at most one 32 x 64 tile per CU.
-bool gemm_h2_ln_supported(const GemmParams& p) {
-  if (!p.A || !p.ln_gamma || !p.ln_beta || !p.Wp || !p.cscale || p.rscale || p.R || p.C2 || (p.K & 31) || (p.lda & 3) || p.K > 1024 ||
-      p.M <= 0 || p.N <= 0) return false;
-  if (p.Cp && ((p.N & 31) || p.C || p.act == ACT_SIGMOID)) return false;
-  if (!p.Cp && (!p.C || (p.N & 3) || (p.ldc & 3))) return false;
-  const long tiles = (long)((p.M + 31) / 32) * ((p.N + 63) / 64);
-  return tiles <= 256;
-}
-hipError_t launch_gemm_h2_ln(GemmParams p, hipStream_t s) {
-  if (!gemm_h2_ln_supported(p)) return hipErrorInvalidValue;
-  p.nbn_magic = 0;
-  p.W = reinterpret_cast<const float*>(p.Wp);          // gemm_tile.h's epilogue reads N floats from W when there is no bias (discarded)
-  const int vec = (p.K + 255) / 256;
-  const size_t bytes = (size_t)(p.K >> 5) * 2 * 32 * 64 + 3 * 8192;
-  const long tiles = (long)((p.M + 31) / 32) * ((p.N + 63) / 64);
-  auto go = [&](auto kern) {
-    static bool raised[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!raised[dev]) {
-      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 2 * 32 * 2 + 3 * 8192);
-      if (attr != hipSuccess) return attr;
-      raised[dev] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), bytes, s, p);
-    return hipGetLastError();
-  };
-  if (vec <= 1) return go(gemm_h2_ln_kernel<1>);
-  if (vec <= 2) return go(gemm_h2_ln_kernel<2>);
-  return go(gemm_h2_ln_kernel<4>);
 }

@@ -143,7 +143,6 @@ struct GemmParams {
   const float* cscale;
   const float* rscale;   // per-ROW descale of an operand that carries one power of two per row (the resized visual stream), or null
   float cp_scale;
-  float ln_pscale;     // gemm_h2_ln_kernel: the power of two of the LayerNorm site (what launch_layernorm_h2 takes as its exponent)
   int h2;              // 1: Ap / Wp / Cp hold two fp16 terms (gemm_h2.hip), 0: three bf16 terms (gemm_planes.hip)
 #ifdef AVSEP_DEV
   struct Alt {
@@ -177,10 +176,6 @@ const char* layernorm_planes_instance_name(int d, int kind);   // kind 1: three 
 bool gemm_h2_supported(const GemmParams& p);
 hipError_t launch_gemm_h2(GemmParams p, hipStream_t s);
 const char* gemm_h2_instance_name(const GemmParams& p);
-// LayerNorm + the same GEMM in ONE launch for grids that cannot fill the chip (a few clips): p.A = the fp32 rows (lda), ln_gamma / ln_beta /
-// ln_eps / ln_pscale the LayerNorm and its exponent, K = the normalised width; the bits of launch_layernorm_h2 + launch_gemm_h2
-bool gemm_h2_ln_supported(const GemmParams& p);
-hipError_t launch_gemm_h2_ln(GemmParams p, hipStream_t s);
 // x [M][ld] fp32 -> H2 planes (fp16 [K/32][2][rows][32]) of x * 2^e, e = row_exp[m] (or the one exponent `e` when row_exp is null)
 hipError_t launch_split_h2(const float* x, int ld, unsigned short* planes, long long rows, int M, int K, const int* row_exp, int e,
                            hipStream_t s);
