@@ -100,6 +100,44 @@ def test_fuzz_wide_models_against_torch_cpu_port(case):
     assert maxabs(sep.cpu().numpy(), rs.contiguous().numpy()) < 4e-6 * max(1.0, float(np.abs(mixed).max())), (cfg, dm)
 
 
+def test_two_term_bounds_follow_weight_updates():
+    """The static exponents of the two-term path are derived from the weights when they are packed (avsep_finalize_weights).  A weight
+    update in eval mode -- in place under no_grad, which the per-call change check sees -- must re-derive them: LayerNorm gains and
+    biases grown 300x, in-projection rows grown 40x and an out-projection shrunk 1e-4x between two forwards of the same module; the
+    second forward stays finite and at the oracle's distance (an exponent left over from the first would overflow fp16 or lose the
+    small operand)."""
+    dev = torch.device("cuda:0")
+    cfg = dict(freq_bins=129, d_model=512, nhead=8, num_encoder_layers=1, num_fusion_layers=1, num_speakers=2)
+    B, T, N, H, W = 2, 160, 7, 16, 16
+    m = _model(dev, cfg, 91).eval()
+    mixed, lips = seeded.inputs(777, B, cfg["freq_bins"], T, N, H, W)
+    x, l = torch.from_numpy(mixed).to(dev), torch.from_numpy(lips).to(dev)
+
+    def check():
+        with torch.no_grad():
+            _, masks = m(x, l)
+        assert torch.isfinite(masks).all()
+        state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        _, r32 = torch_cpu.forward(state, torch.from_numpy(mixed), torch.from_numpy(lips), cfg["nhead"], cfg["num_speakers"])
+        s64 = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
+        _, r64 = torch_cpu.forward(s64, torch.from_numpy(mixed).double(), torch.from_numpy(lips).double(), cfg["nhead"], cfg["num_speakers"])
+        e32 = maxabs(r32.contiguous().numpy().astype(np.float64), r64.contiguous().numpy())
+        e = maxabs(masks.cpu().numpy().astype(np.float64), r64.contiguous().numpy())
+        assert e < 2.0 * e32 + 4e-6, (e, e32)
+
+    check()
+    sd = dict(m.named_parameters())
+    with torch.no_grad():
+        for k in ("audio_encoder.transformer.layers.0.norm1.weight", "audio_encoder.transformer.layers.0.norm1.bias",
+                  "fusion.layers.0.norm2.weight", "fusion.layers.0.norm2.bias", "fusion.norm.weight"):
+            sd[k].mul_(300.0)
+        sd["audio_encoder.transformer.layers.0.self_attn.in_proj_weight"].mul_(40.0 / 300.0)   # q, k, v bounds move, the scores stay sane
+        sd["fusion.layers.0.cross_attn.out_proj.weight"].mul_(1e-4)
+        sd["fusion.layers.0.ff.0.weight"].mul_(1.0 / 300.0)
+        sd["decoder.decoder.0.weight"].mul_(1.0 / 300.0)
+    check()
+
+
 @pytest.mark.parametrize("scale", [1e-5, 1e-2, 1.0, 3e2, 1e5])
 def test_visual_stream_magnitude_sweep_on_the_two_term_path(scale):
     """The cross-attention of a d_model >= 512 model runs on two fp16 terms with exponents taken PER CLIP from the magnitude of the
