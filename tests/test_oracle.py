@@ -204,3 +204,43 @@ def test_torch_cpu_port_matches_reference_outputs(golden, name):
         else:
             assert maxabs(sliced(masks, 7), g["masks.slice"]) < 2e-6, (name, fast)
             assert maxabs(sliced(sep, 7), g["separated.slice"]) < 2e-6 * scale, (name, fast)
+
+
+def test_fixture_low_bits_stream_known_answers():
+    """tests/helpers.py::low_bits (the seeded low 16 bits of trained_d512's weight words) is part of a committed fixture: pin the stream
+    (numpy's PCG64 with a SeedSequence of [seed, crc32(name)]) so that a numpy upgrade that changed it would fail HERE, not as a parity
+    mystery."""
+    from helpers import low_bits
+    got = low_bits("audio_encoder.input_proj.0.weight", (2, 3), 20251005)
+    assert got.dtype == np.uint32 and got.tolist() == [[47434, 37588, 18345], [48786, 49516, 49537]]
+    assert int(low_bits("x", (1000,), 1).max()) < 1 << 16
+
+
+def test_oracle_relu_forcing_takes_the_given_decisions():
+    """oracle/torch_cpu.RELU_FORCE (the kink-aware gradient gate's hook): ReLU i returns x * mask_i; forcing the decisions the oracle
+    makes by itself changes nothing, forcing a flipped unit changes exactly that unit's contribution; RELU_RECORD sees every ReLU."""
+    import torch
+    from oracle import torch_cpu
+    F_, d, h, S = 9, 32, 4, 2
+    shapes = seeded.model_shapes(F_, d, h, 1, 1, S)
+    state = {k: torch.from_numpy(np.ascontiguousarray(v)).double() if v.dtype.kind == "f" else torch.from_numpy(np.ascontiguousarray(v))
+             for k, v in seeded.fill_state(shapes, 5).items()}
+    mixed, lips = seeded.inputs(5, 2, F_, 6, 3, 8, 8)
+    x, l = torch.from_numpy(mixed).double(), torch.from_numpy(lips).double()
+    torch_cpu.RELU_RECORD = rec = []
+    try:
+        _, m0 = torch_cpu.forward_train({k: v.clone() for k, v in state.items()}, x, l, h, S)
+    finally:
+        torch_cpu.RELU_RECORD = None
+    assert len(rec) == 2 + 1 + 3 + 1                     # input_proj.0 / .2, audio linear1, three Conv2d blocks, visual linear1
+    torch_cpu.RELU_FORCE = [r.clone() for r in rec]
+    try:
+        _, m1 = torch_cpu.forward_train({k: v.clone() for k, v in state.items()}, x, l, h, S)
+        flipped = [r.clone() for r in rec]
+        flipped[2][0, 0, 0] = ~flipped[2][0, 0, 0]
+        torch_cpu.RELU_FORCE = flipped
+        _, m2 = torch_cpu.forward_train({k: v.clone() for k, v in state.items()}, x, l, h, S)
+    finally:
+        torch_cpu.RELU_FORCE = None
+    assert torch.equal(m0, m1)
+    assert not torch.equal(m0[0], m2[0]) and torch.equal(m0[1], m2[1])   # clip 0's unit flipped: only clip 0 moves
